@@ -1,0 +1,914 @@
+// lmat_oracle.hpp -- CPU restatement of LMAT's read_label classification hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing in the shipped engine (lmat_amd/, include/)
+// may include, link or execute this file; only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg use it, and only as the checker.
+//
+// This is a plain, scalar, STL-based restatement of the reference algorithm in
+// the reference's own 32-bit taxid space.  Each function cites the reference
+// file:line it follows (paths relative to /root/reference).  It deliberately
+// uses std::sort / std::set / std::map so that libstdc++ behaviour the
+// reference depends on (tie order of std::sort, in-order std::set iteration
+// while inserting) is inherited rather than re-modelled.
+//
+// PINNING STATUS (see DESIGN.md "Oracle"):
+//   * k-mer extraction / canonicalisation / per-read dedupe : pinned by the
+//     reference's example run (example/example.tgz: 1000 reads, cand-kmer and
+//     valid-kmer columns) -> tests/golden/example_kmer_counts.tsv
+//   * tax_histo ingest, k-mer -> taxid-list lookup, 16<->32 id conversion,
+//     taxonomy parse + getPathToRoot : pinned against the reference's own
+//     SortedDb / TaxNodeStat / TaxTree compiled from /root/reference
+//     (oracle/_ref/ref_lookup) -> tests/golden/ref_lookup_*.txt
+//   * fastsummary / nomatchsum tallies : pinned by the example run's outputs
+//   * per-read label filtering, scoring and findReadLabelVer2 decision
+//     (src/read_label.cpp:225-941,1031-1204): PARITY UNPINNED.  read_label.cpp
+//     itself cannot be built here without stand-ins for generated
+//     all_headers.hpp, gzstream and perm-je, and the reference ships no test
+//     vectors for it beyond the example run's statistics columns.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <list>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace orc {
+
+typedef uint32_t tid_t;
+typedef uint64_t kmer_t;
+
+// ---------------------------------------------------------------------------
+// include/tid_checks.hpp:10-28, src/read_label.cpp:25,69,82-104
+// ---------------------------------------------------------------------------
+static const tid_t kHumanTid = 9606;
+static const tid_t kArtSeqTid = 32630;
+inline bool is_human(tid_t t) { return t == 9606 || t == 63221 || t == 741158; }
+inline bool is_phix(tid_t t) { return t == 374840 || t == 10847 || t == 32630; }
+inline bool bad_genome(tid_t t) { return t == 12721 || t == 693660; }
+
+enum NoMatch { kReadTooShort = 0, kNoDbHits = 1, kLowScore = 2 };
+enum Match { kDirectMatch, kMultiMatch, kPartialMultiMatch, kNoMatchT, kNoLCAError };
+
+inline const char* match_str(Match m) {
+    switch (m) {  // src/read_label.cpp:203-223
+        case kDirectMatch: return "DirectMatch";
+        case kMultiMatch: return "MultiMatch";
+        case kPartialMultiMatch: return "PartialMultiMatch";
+        case kNoMatchT: return "NoMatch";
+        case kNoLCAError: return "LCA_ERROR";
+    }
+    return "error";
+}
+inline const char* nomatch_str(NoMatch m) {
+    switch (m) {  // src/read_label.cpp:183-200
+        case kReadTooShort: return "ReadTooShort";
+        case kNoDbHits: return "NoDbHits";
+        case kLowScore: return "LowScore";
+    }
+    return "Error";
+}
+
+// ---------------------------------------------------------------------------
+// Taxonomy and auxiliary tables (src/kmerdb/TaxTree.hpp:24-91,
+// src/kmerdb/TaxNode.hpp:131-147, src/read_label.cpp:1560-1602)
+// ---------------------------------------------------------------------------
+struct Taxonomy {
+    std::unordered_map<tid_t, tid_t> parent;        // tree node -> parent id
+    std::map<tid_t, tid_t> depth;                   // -e file (sopt._imap)
+    std::map<tid_t, std::string> rank;              // -w file (gRank_table)
+    std::unordered_map<uint16_t, uint32_t> conv;    // -f file: 16 -> 32 (conv_map)
+    std::unordered_map<uint32_t, uint16_t> br;      // -f file: 32 -> 16 (make_db_table.cpp:259-273)
+    std::unordered_set<int> low_plasmid;            // -r file (gLowNumPlasmid)
+
+    // TaxTree(const char*) : two comment lines, one count line, then per node
+    // "id nchild child... parent" + rest of line, then the name line.
+    bool load_tree(const std::string& fn) {
+        std::ifstream in(fn.c_str());
+        if (!in.is_open()) {
+            std::cerr << "failed to open " << fn << " for reading\n";
+            return false;
+        }
+        std::string line;
+        std::getline(in, line);
+        std::getline(in, line);
+        long count;
+        in >> count;
+        std::getline(in, line);
+        while (true) {
+            tid_t id, ct, child, par;
+            if (!(in >> id)) break;  // well-formed files only
+            if (!(in >> ct)) break;
+            for (tid_t j = 0; j < ct; ++j) in >> child;
+            if (!(in >> par)) break;
+            std::getline(in, line);
+            std::getline(in, line);  // name
+            parent[id] = par;
+        }
+        return true;
+    }
+    bool load_depth(const std::string& fn) {  // read_label.cpp:1574-1582
+        std::ifstream in(fn.c_str());
+        if (!in) return false;
+        tid_t t, d;
+        while (in >> t >> d) depth[t] = d;
+        return true;
+    }
+    bool load_rank(const std::string& fn) {  // read_label.cpp:1560-1567 (insert: first wins)
+        std::ifstream in(fn.c_str());
+        if (!in) return false;
+        tid_t t;
+        std::string r;
+        while (in >> t >> r) rank.insert(std::make_pair(t, r));
+        return true;
+    }
+    bool load_idmap(const std::string& fn) {  // read_label.cpp:1585-1602; last line wins
+        FILE* f = fopen(fn.c_str(), "r");
+        if (!f) return false;
+        uint32_t src;
+        uint16_t dest;
+        while (fscanf(f, "%d%hd", (int*)&src, (short*)&dest) > 0) {
+            conv[dest] = src;
+            br[src] = dest;
+        }
+        fclose(f);
+        return true;
+    }
+    bool load_plasmids(const std::string& fn) {  // read_label.cpp:499-510
+        std::ifstream in(fn.c_str());
+        if (!in) return false;
+        tid_t p;
+        while (in >> p) low_plasmid.insert((int)p);
+        return true;
+    }
+    bool is_plasmid(tid_t t) const {  // read_label.cpp:69
+        return (t >= 10000000 && t < 11000000) || low_plasmid.count((int)t);
+    }
+    // TaxTree.hpp:60-91 : ancestors of tid, parent first, root last, tid excluded.
+    void path_to_root(tid_t tid, std::vector<tid_t>& out) const {
+        out.clear();
+        auto it = parent.find(tid);
+        if (it == parent.end()) return;        // registerFailure(): note on cerr, empty path
+        if (it->second == tid) return;         // root
+        tid_t cur = it->second;
+        auto pit = parent.find(cur);
+        if (pit == parent.end()) {
+            std::cerr << "failed to find parent TaxNode for taxid " << tid << " whose parent is " << cur << "\n";
+            std::cerr << "fatal error!\n";
+            exit(-1);
+        }
+        out.push_back(cur);
+        while (true) {
+            if (pit->second == cur) return;
+            cur = pit->second;
+            pit = parent.find(cur);
+            if (pit == parent.end()) {  // reference dereferences end(): undefined; we stop loudly
+                std::cerr << "oracle: broken taxonomy above " << tid << "\n";
+                exit(-1);
+            }
+            out.push_back(cur);
+        }
+    }
+    bool is_ancestor(tid_t anc, tid_t desc) const {  // read_label.cpp:138-150
+        std::vector<tid_t> p;
+        path_to_root(desc, p);
+        for (size_t i = 0; i < p.size(); ++i)
+            if (p[i] == anc) return true;
+        return false;
+    }
+    tid_t depth_of(tid_t t) const {  // (*_imap.find(t)).second ; absent is UB upstream, 0 here
+        auto it = depth.find(t);
+        return it == depth.end() ? 0 : it->second;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// k-mer database: tax_histo binary -> k-mer -> list of 16-bit ids in file order.
+// Restates the un-pruned path of SortedDb::add_data (src/kmerdb/SortedDb.cpp:84-751)
+// and the lookup contract of begin_/next (src/kmerdb/SortedDb.hpp:188-385) +
+// TaxNodeStat::begin/next/taxid/taxidCount (src/kmerdb/TaxNodeStat.hpp:60-74,208-264).
+// ---------------------------------------------------------------------------
+struct KmerDb {
+    int k = 0;
+    std::unordered_map<kmer_t, std::vector<uint16_t>> table;
+    kmer_t last_kmer = 0;  // add_data's static last_kmer: ordering is checked across files
+
+    // KmerFileMetaData::read (src/kmerdb/KmerFileMetaData.cpp:44-94)
+    bool add_taxhisto(const std::string& fn, const Taxonomy& tax, std::string* err) {
+        FILE* in = fopen(fn.c_str(), "rb");
+        if (!in) { if (err) *err = "cannot open " + fn; return false; }
+        fseek(in, 0, SEEK_END);
+        long fsz = ftell(in);
+        fseek(in, 0, SEEK_SET);
+        uint32_t data_start, version, klen;
+        uint64_t kmer_count, test;
+        char loc;
+        bool ok = fread(&data_start, 4, 1, in) == 1 && fread(&kmer_count, 8, 1, in) == 1 &&
+                  fread(&test, 8, 1, in) == 1 && fread(&version, 4, 1, in) == 1 &&
+                  fread(&loc, 1, 1, in) == 1 && fread(&klen, 4, 1, in) == 1;
+        if (!ok || test != ~(uint64_t)0 || version != 999 || loc != 'N') {
+            if (err) *err = "bad tax_histo header in " + fn;
+            fclose(in);
+            return false;
+        }
+        if (k == 0) k = (int)klen;
+        for (uint64_t i = 0; i < kmer_count; ++i) {
+            if (ftell(in) == fsz) break;  // SortedDb.cpp:159
+            kmer_t kmer;
+            uint16_t n;
+            if (fread(&kmer, 8, 1, in) != 1 || fread(&n, 2, 1, in) != 1) {
+                if (err) *err = "truncated tax_histo record";
+                fclose(in);
+                return false;
+            }
+            if (last_kmer > 0 && kmer <= last_kmer) {  // SortedDb.cpp:164-167
+                if (err) *err = "Kmers arriving out of order";
+                fclose(in);
+                return false;
+            }
+            std::vector<uint16_t>& lst = table[kmer];
+            for (uint16_t j = 0; j < n; ++j) {
+                uint32_t tid;
+                if (fread(&tid, 4, 1, in) != 1) { if (err) *err = "truncated taxid list"; fclose(in); return false; }
+                auto b = tax.br.find(tid);  // SortedDb.cpp:503-511,678-690
+                uint16_t t16 = b == tax.br.end() ? 0 : b->second;
+                if (t16 == 0 || t16 > tax.br.size() + 1) {
+                    if (err) { std::ostringstream o; o << "bad read: " << tid << " " << t16; *err = o.str(); }
+                    fclose(in);
+                    return false;
+                }
+                lst.push_back(t16);
+            }
+            if ((i + 1) % 1500 == 0) {  // TAX_HISTO_SANITY_COUNT, SortedDb.cpp:717-722
+                if (fread(&test, 8, 1, in) != 1 || test != ~(uint64_t)0) {
+                    if (err) *err = "missing sanity word";
+                    fclose(in);
+                    return false;
+                }
+            }
+            last_kmer = kmer;
+        }
+        fclose(in);
+        return true;
+    }
+    void add_list(kmer_t kmer, const std::vector<uint16_t>& l) { table[kmer] = l; }
+    const std::vector<uint16_t>* lookup(kmer_t kmer) const {
+        auto it = table.find(kmer);
+        return it == table.end() ? nullptr : &it->second;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Options (src/read_label.cpp:487-497,1336-1347)
+// ---------------------------------------------------------------------------
+struct Options {
+    float diff_thresh = 1.0f;    // -b
+    float diff_thresh2 = 3.0f;   // -l
+    bool prn_all = false;        // -p
+    bool screen_phix = true;     // -h turns off
+    float min_score = 0.0f;      // -x
+    int min_kmer = 35;           // -j
+    int min_fnd_kmer = 1;        // -z
+    bool prn_read = true;        // -a turns off
+    bool fastq = false;          // -q
+};
+
+typedef std::pair<tid_t, float> ufpair_t;
+typedef std::pair<tid_t, uint16_t> tax_elem_t;
+typedef std::set<tax_elem_t> tax_data_t;
+typedef std::pair<int16_t, tax_data_t> label_info_t;
+typedef std::map<tid_t, tid_t> hmap_t;
+
+struct Tallies {
+    std::map<tid_t, int> count;
+    std::map<tid_t, float> score;
+    std::map<int, int> nomatch;
+};
+
+// Intermediate dump for kernel-level parity tests (not reference output).
+struct ReadTrace {
+    int valid_kmers = 0;
+    int bin_sel = 0;
+    std::vector<kmer_t> uniq_kmers;          // first occurrences, in position order
+    std::vector<int> uniq_pos;
+    std::vector<tid_t> reg_order;            // taxid_lst
+    std::vector<uint32_t> reg_count;         // per registered taxid: #positions containing it
+    int cand_kmer_cnt = -1;
+};
+
+// ---------------------------------------------------------------------------
+// Rolling canonical k-mer extraction (src/read_label.cpp:943-950,978-1010)
+// ---------------------------------------------------------------------------
+inline int encode_base(char c) {
+    switch (c) {
+        case 'a': case 'A': return 0;
+        case 'c': case 'C': return 1;
+        case 'g': case 'G': return 2;
+        case 't': case 'T': return 3;
+    }
+    return -1;
+}
+
+struct Classifier {
+    const Taxonomy& tax;
+    const KmerDb& db;
+    Options opt;
+    Classifier(const Taxonomy& t, const KmerDb& d, const Options& o) : tax(t), db(d), opt(o) {}
+
+    // src/read_label.cpp:225-262
+    bool add_to_cand_lineage(const ufpair_t cand, std::list<ufpair_t>& lineage) const {
+        bool add = false;
+        if (lineage.empty()) {
+            add = true;
+        } else {
+            unsigned cand_depth = tax.depth_of(cand.first);
+            add = true;
+            for (auto it = lineage.begin(); it != lineage.end(); ++it) {
+                const tid_t t = it->first;
+                unsigned chk_depth = tax.depth_of(t);
+                if (chk_depth > cand_depth && !tax.is_ancestor(cand.first, t)) { add = false; break; }
+                else if (chk_depth < cand_depth && !tax.is_ancestor(t, cand.first)) { add = false; break; }
+                else if (chk_depth == cand_depth) { add = false; break; }
+            }
+        }
+        if (add) lineage.push_back(cand);
+        return add;
+    }
+
+    // src/read_label.cpp:264-282
+    bool cmp_comp_lineage(ufpair_t cand, const std::vector<ufpair_t>& lineage, std::set<tid_t>& no_good,
+                          float diff_thresh) const {
+        const float undef = -10000;
+        bool keep_going = true;
+        for (unsigned i = 0; i < lineage.size(); ++i) {
+            if (tax.is_ancestor(lineage[i].first, cand.first)) break;
+            if (lineage[i].second != undef && (lineage[i].second - cand.second) > diff_thresh) {
+                keep_going = false;
+                break;
+            }
+            if ((lineage[i].second - cand.second) <= diff_thresh) no_good.insert(lineage[i].first);
+        }
+        return keep_going;
+    }
+
+    struct CmpDepthPair {  // read_label.cpp:159-167
+        const Taxonomy* t;
+        bool operator()(const ufpair_t& a, const ufpair_t& b) const {
+            return (int)t->depth_of(a.first) > (int)t->depth_of(b.first);
+        }
+    };
+    struct CmpDepth1 {  // read_label.cpp:169-177
+        const Taxonomy* t;
+        bool operator()(tid_t a, tid_t b) const { return (int)t->depth_of(a) > (int)t->depth_of(b); }
+    };
+    struct TCmp {  // read_label.cpp:475-485
+        const Taxonomy* t;
+        bool operator()(const ufpair_t& a, const ufpair_t& b) const {
+            if (fabs(a.second - b.second) < 0.001) {
+                return (int)t->depth_of(a.first) < (int)t->depth_of(b.first);
+            }
+            return a.second < b.second;
+        }
+    };
+
+    // src/read_label.cpp:284-419
+    std::pair<ufpair_t, Match> find_read_label(const std::vector<ufpair_t>& rank_label, float diff_thresh,
+                                               std::list<ufpair_t>& cand_lin,
+                                               const std::unordered_map<tid_t, float>& all_cand_set,
+                                               const float top_score) const {
+        Match match = kNoMatchT;
+        tid_t save_plasmid = 0;  // reference leaves this uninitialised
+        bool plasmid_top = false;
+        unsigned lowest_depth = 0, highest_depth = 0;
+        ufpair_t lowest = std::make_pair(0, 0), highest = std::make_pair(0, 0);
+        int lidx = -1;
+        bool lin_done = false;
+        const int n = (int)rank_label.size();
+        for (int i = n - 1; i >= 0; --i) {
+            if (rank_label[i].second >= top_score && tax.is_plasmid(rank_label[i].first)) {
+                plasmid_top = true;
+                save_plasmid = rank_label[i].first;
+            }
+            if (!lin_done && !add_to_cand_lineage(rank_label[i], cand_lin)) {
+                lidx = i;
+                lin_done = true;
+            } else if (!lin_done) {
+                const tid_t d = tax.depth_of(rank_label[i].first);
+                if (d > lowest_depth || i == n - 1) { lowest = rank_label[i]; lowest_depth = d; }
+                if (d < highest_depth || i == n - 1) { highest = rank_label[i]; highest_depth = d; }
+            }
+            if (lin_done && rank_label[i].second < top_score) break;
+        }
+        std::set<tid_t> add_set;
+        if (highest_depth != 0) {
+            std::vector<tid_t> path;
+            tax.path_to_root(highest.first, path);
+            for (unsigned i = 0; i < path.size(); ++i) {
+                add_set.insert(path[i]);
+                auto m = all_cand_set.find(path[i]);
+                if (m != all_cand_set.end()) cand_lin.push_back(std::make_pair(path[i], m->second));
+                else cand_lin.push_back(std::make_pair(path[i], (float)-10000));
+            }
+        }
+        std::vector<ufpair_t> cand_lin_vec(cand_lin.begin(), cand_lin.end());
+        CmpDepthPair cd{&tax};
+        std::sort(cand_lin_vec.begin(), cand_lin_vec.end(), cd);
+        std::set<tid_t> no_good;
+        for (int i = lidx; i >= 0; --i) {
+            if (add_set.find(rank_label[i].first) == add_set.end()) {
+                if (!cmp_comp_lineage(rank_label[i], cand_lin_vec, no_good, diff_thresh)) break;
+            }
+        }
+        ufpair_t call = std::make_pair(0, 0);  // reference: uninitialised (quirk Q5)
+        if (cand_lin.empty() && no_good.empty()) {
+            match = kNoMatchT;
+        } else if (!cand_lin.empty() && no_good.empty()) {
+            call = lowest;
+            match = kDirectMatch;
+        } else {
+            std::vector<ufpair_t> cand_vec(cand_lin.begin(), cand_lin.end());
+            std::sort(cand_vec.begin(), cand_vec.end(), cd);
+            float max_val = -10000;
+            std::pair<tid_t, bool> res = std::make_pair(0, false);
+            int root_idx = -1;
+            for (unsigned i = 0; i < cand_vec.size(); ++i) {
+                max_val = std::max(cand_vec[i].second, max_val);
+                if (no_good.find(cand_vec[i].first) == no_good.end()) {
+                    res = std::make_pair(cand_vec[i].first, true);
+                    root_idx = (int)i;
+                    break;
+                }
+            }
+            if (!res.second) {
+                call = std::make_pair(0, -1);
+                match = kNoLCAError;
+            } else {
+                match = kMultiMatch;
+                if (all_cand_set.find(res.first) != all_cand_set.end()) {
+                    if (max_val < cand_vec[root_idx].second) {
+                        match = kPartialMultiMatch;
+                        max_val = cand_vec[root_idx].second;
+                    }
+                }
+                call = std::make_pair(res.first, max_val);
+            }
+        }
+        if (plasmid_top) {
+            if (tax.is_ancestor(call.first, save_plasmid)) call.first = save_plasmid;
+        }
+        return std::make_pair(call, match);
+    }
+
+    // src/read_label.cpp:974-1209 (non-permissive, pruning off)
+    std::pair<int, int> retrieve_kmer_labels(const char* str, const int slen, const int klen,
+                                             std::vector<label_info_t>& label_vec, std::list<tid_t>& taxid_lst,
+                                             hmap_t& tax2idx, hmap_t& idx2tax, ReadTrace* tr) const {
+        int k = 0;
+        const int highbits = (klen - 1) * 2;
+        const kmer_t mask = ((kmer_t)1 << klen * 2) - 1;
+        kmer_t forward = 0, reverse = 0;
+        std::set<kmer_t> no_dups;
+        std::map<tid_t, unsigned> leaf_track;
+        int valid_kmers = 0, gc_cnt = 0, valid_gc_cnt = 0, valid_tot_cnt = 0, tot_cnt = 0;
+        for (int j = 0; j < slen; j++) {
+            const char base = str[j];
+            const int t = encode_base(base);
+            if (t < 0) { k = 0; gc_cnt = 0; tot_cnt = 0; continue; }
+            forward = ((forward << 2) | (kmer_t)t) & mask;
+            reverse = ((kmer_t)(t ^ 3) << highbits) | (reverse >> 2);
+            if (t == 1 || t == 2) { ++gc_cnt; ++tot_cnt; } else { ++tot_cnt; }
+            if (++k >= klen) {
+                valid_kmers++;
+                valid_gc_cnt += gc_cnt;
+                valid_tot_cnt += tot_cnt;
+                gc_cnt = 0;
+                tot_cnt = 0;
+                const kmer_t kmer_id = (forward < reverse) ? forward : reverse;
+                if (no_dups.find(kmer_id) != no_dups.end()) continue;
+                const int pos = j - klen + 1;
+                label_vec[pos].first = 0;
+                no_dups.insert(kmer_id);
+                if (tr) { tr->uniq_kmers.push_back(kmer_id); tr->uniq_pos.push_back(pos); }
+
+                const std::vector<uint16_t>* lst = db.lookup(kmer_id);
+                const uint16_t taxid_count = lst ? (uint16_t)lst->size() : 0;
+                unsigned dcnt = 0;
+                std::list<tid_t> obs_tids;
+                bool seen_human = false;
+                for (unsigned li = 0; li < taxid_count; ++li) {  // while(h->next())
+                    auto cv = tax.conv.find((*lst)[li]);
+                    tid_t tid = cv == tax.conv.end() ? 0 : cv->second;
+                    if (tid == 0) {  // TaxNodeStat.hpp:235-238 assert(0)
+                        std::cerr << "bad taxid: " << (*lst)[li] << " kmer: " << kmer_id << "\n";
+                        exit(-1);
+                    }
+                    if (is_human(tid) && seen_human) continue;
+                    else if (is_human(tid) && !seen_human) { tid = kHumanTid; seen_human = true; }
+                    if (tid == 20999999 || bad_genome(tid)) continue;
+                    uint16_t ng = taxid_count;
+                    if (dcnt == 0) label_vec[pos].first = (int16_t)ng;  // int16 store of a u16 (quirk Q4)
+                    obs_tids.push_back(tid);
+                    dcnt++;
+                }
+                std::vector<tid_t> obs(obs_tids.begin(), obs_tids.end());
+                CmpDepth1 cd{&tax};
+                std::sort(obs.begin(), obs.end(), cd);
+                std::unordered_set<tid_t> non_leaf;
+                for (unsigned i = 0; i < obs.size(); ++i) {
+                    const tid_t tid = obs[i];
+                    if (non_leaf.find(tid) == non_leaf.end()) {
+                        label_vec[pos].second.insert(std::make_pair(tid, (uint16_t)1));
+                        if (leaf_track.find(tid) != leaf_track.end()) leaf_track[tid] += 1;
+                        else leaf_track.insert(std::make_pair(tid, 1u));
+                        if (tax2idx.find(tid) == tax2idx.end()) {
+                            const unsigned idx = taxid_lst.size();
+                            tax2idx[tid] = idx;
+                            idx2tax[idx] = tid;
+                            taxid_lst.push_back(tid);
+                        }
+                        std::vector<tid_t> path;
+                        tax.path_to_root(tid, path);
+                        for (unsigned p = 0; p < path.size(); ++p) non_leaf.insert(path[p]);
+                    }
+                }
+            }
+        }
+        // post pass: representative strain per species, lineage closure (:1143-1204)
+        {
+            std::map<tid_t, std::pair<tid_t, unsigned>> save_spec_rep;
+            for (auto cb = leaf_track.begin(); cb != leaf_track.end(); ++cb) {
+                const tid_t stid = cb->first;
+                const unsigned stid_cnt = cb->second;
+                auto rk = tax.rank.find(stid);
+                if (rk != tax.rank.end() && rk->second == "strain") {
+                    std::vector<tid_t> path;
+                    tax.path_to_root(stid, path);
+                    for (unsigned p = 0; p < path.size(); ++p) {
+                        const tid_t ptid = path[p];
+                        auto prk = tax.rank.find(ptid);
+                        if (prk != tax.rank.end() && prk->second == "species") {
+                            if (save_spec_rep.find(ptid) == save_spec_rep.end())
+                                save_spec_rep.insert(std::make_pair(ptid, std::make_pair(stid, stid_cnt)));
+                            else if (stid_cnt > save_spec_rep[ptid].second)
+                                save_spec_rep[ptid] = std::make_pair(stid, stid_cnt);
+                            break;
+                        }
+                    }
+                }
+            }
+            std::unordered_set<tid_t> rep_strain;
+            for (auto sb = save_spec_rep.begin(); sb != save_spec_rep.end(); ++sb) rep_strain.insert(sb->second.first);
+            for (unsigned pos = 0; pos < label_vec.size(); ++pos) {
+                if (label_vec[pos].first >= 0) {
+                    // in-order walk of the std::set while inserting into it
+                    for (auto sb = label_vec[pos].second.begin(); sb != label_vec[pos].second.end(); ++sb) {
+                        const tid_t tid = sb->first;
+                        auto rk = tax.rank.find(tid);
+                        const bool not_strain = (rk == tax.rank.end()) || rk->second != "strain";
+                        if (rep_strain.find(tid) != rep_strain.end() || not_strain) {
+                            std::vector<tid_t> path;
+                            tax.path_to_root(tid, path);
+                            for (unsigned p = 0; p < path.size(); ++p) {
+                                const tid_t ptid = path[p];
+                                label_vec[pos].second.insert(std::make_pair(ptid, (uint16_t)1));
+                                if (tax2idx.find(ptid) == tax2idx.end()) {
+                                    const unsigned idx = taxid_lst.size();
+                                    tax2idx[ptid] = idx;
+                                    idx2tax[idx] = ptid;
+                                    taxid_lst.push_back(ptid);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        int bin_sel = 0;
+        if (valid_tot_cnt > 0) {  // reference: NaN->int is undefined when no valid k-mer; value unused then
+            float gc_pcnt = ((float)valid_gc_cnt / (float)valid_tot_cnt) * 100.0;
+            bin_sel = gc_pcnt / 10;
+        }
+        return std::make_pair(valid_kmers, bin_sel);
+    }
+
+    // src/read_label.cpp:692-941, no-null-model path (useRandMod == false)
+    std::pair<ufpair_t, Match> construct_labels(const std::vector<label_info_t>& label_vec,
+                                                const std::list<tid_t>& taxid_lst, const hmap_t& tax2idx,
+                                                const hmap_t& idx2taxid, std::ostream& ofs, int min_valid_kmers,
+                                                int min_fnd_kmers, ReadTrace* tr) const {
+        const unsigned num_tax_ids = taxid_lst.size();
+        unsigned cnt_fnd_kmers = 0;
+        std::vector<std::vector<tid_t>> label_matrix(label_vec.size());
+        uint16_t cand_kmer_cnt = 0;
+        for (unsigned pos = 0; pos < label_vec.size(); ++pos) {
+            if (label_vec[pos].first >= 0) ++cand_kmer_cnt;
+            label_matrix[pos].resize(num_tax_ids, 0);
+            for (auto it = label_vec[pos].second.begin(); it != label_vec[pos].second.end(); ++it) {
+                const unsigned idx = tax2idx.find(it->first)->second;
+                label_matrix[pos][idx] = it->second;
+            }
+            if (!label_vec[pos].second.empty()) ++cnt_fnd_kmers;
+        }
+        if (tr) tr->cand_kmer_cnt = cand_kmer_cnt;
+        if ((int)cnt_fnd_kmers < min_fnd_kmers) return std::make_pair(std::make_pair(0, -1), kNoMatchT);
+        if (cand_kmer_cnt < min_valid_kmers) return std::make_pair(std::make_pair(0, -1), kNoMatchT);
+
+        std::vector<float> rank_first(num_tax_ids, 0);
+        std::unordered_map<tid_t, float> all_cand_set;
+        bool has_human = false;
+        for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
+            float found = 0;
+            const tid_t taxid = idx2taxid.find(tax_idx)->second;
+            if (is_human(taxid)) has_human = true;
+            for (unsigned pos = 0; pos < label_vec.size(); ++pos)
+                if (label_matrix[pos][tax_idx] > 0) found += 1;
+            rank_first[tax_idx] = (float)found / (float)cand_kmer_cnt;
+            if (tr) tr->reg_count.push_back((uint32_t)found);
+        }
+        std::vector<ufpair_t> rank_label(num_tax_ids, std::make_pair(0, 0));
+        bool fnd_phix = false;
+        float log_sum = 0.0, pos_log_sum = 0.0, top_score = 0.0, phix_score = 0.0;
+        unsigned sig_hits = 0, pos_sig_hits = 0;
+        for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
+            const tid_t taxid = idx2taxid.find(tax_idx)->second;
+            const float log_odds = rank_first[tax_idx];  // useRandMod false: score = label_prob
+            rank_label[tax_idx] = std::make_pair(taxid, log_odds);
+            all_cand_set.insert(rank_label[tax_idx]);
+            log_sum += log_odds;
+            sig_hits++;
+            if (log_odds > 0) { pos_sig_hits++; pos_log_sum += log_odds; }
+            if (opt.screen_phix && is_phix(taxid)) { phix_score = log_odds; fnd_phix = true; }
+            if (tax_idx == 0 || log_odds > top_score) top_score = log_odds;
+        }
+        Match mtype;
+        ufpair_t best_guess = std::make_pair(0, 0);
+        if (opt.screen_phix && phix_score >= top_score && fnd_phix) {
+            best_guess = std::make_pair(kArtSeqTid, phix_score);
+            mtype = kDirectMatch;
+            ofs << (-1) << " " << (-1) << " " << cand_kmer_cnt << "\t";
+            ofs << best_guess.first << " " << best_guess.second;
+            ofs << "\t";
+            ofs << best_guess.first << " " << best_guess.second << " " << match_str(mtype);
+            ofs << std::endl;
+        } else {
+            std::list<ufpair_t> valid_cand;
+            std::pair<ufpair_t, Match> res = std::make_pair(std::make_pair(0, 0), kNoMatchT);
+            std::string match_type = match_str(res.second);
+            unsigned use_sig_hits = 0;
+            float log_avg;
+            const unsigned min_pos_examples = 3;
+            if (pos_sig_hits > min_pos_examples) {
+                use_sig_hits = pos_sig_hits;
+                log_avg = pos_log_sum / (float)pos_sig_hits;
+            } else {
+                use_sig_hits = sig_hits;
+                log_avg = sig_hits > 0 ? log_sum / (float)sig_hits : 0;
+            }
+            float log_std = 0;
+            for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
+                if (rank_label[tax_idx].second > 0) {
+                    if (pos_sig_hits > min_pos_examples) {
+                        const float val = log_avg - rank_label[tax_idx].second;
+                        log_std += (val * val);
+                    }
+                }
+                if (pos_sig_hits <= min_pos_examples) {
+                    const float val = log_avg - rank_label[tax_idx].second;
+                    log_std += (val * val);
+                }
+            }
+            float stdev1 = use_sig_hits > 1 ? sqrt(log_std / (use_sig_hits - 1)) : 0;
+            if (use_sig_hits > 0) {
+                if (has_human) {
+                    for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
+                        const tid_t taxid = idx2taxid.find(tax_idx)->second;
+                        if (is_human(taxid)) rank_label[tax_idx].second += (opt.diff_thresh2 * stdev1);
+                    }
+                }
+                TCmp tcmp{&tax};
+                std::sort(rank_label.begin(), rank_label.end(), tcmp);
+                ofs << log_avg << " " << stdev1 << " " << cand_kmer_cnt << "\t";
+                stdev1 *= opt.diff_thresh;
+                res = find_read_label(rank_label, stdev1, valid_cand, all_cand_set, top_score);
+                if (opt.prn_all) {
+                    bool prn = false;
+                    for (int i = (int)rank_label.size() - 1; i >= 0; --i) {
+                        if (rank_label[i].second >= 0) {
+                            ofs << " " << rank_label[i].first << " " << rank_label[i].second;
+                            prn = true;
+                        }
+                    }
+                    if (!prn) ofs << "-1 -1";
+                    ofs << "\t";
+                }
+                match_type = match_str(res.second);
+            }
+            if (res.second == kDirectMatch) {
+                best_guess = res.first;
+                ofs << best_guess.first << " " << best_guess.second << " " << match_type;
+            } else if (res.second == kMultiMatch || res.second == kPartialMultiMatch) {
+                if (!opt.prn_all) {
+                    for (auto it = valid_cand.begin(); it != valid_cand.end(); ++it)
+                        ofs << " " << it->first << " " << it->second;
+                    if (valid_cand.empty()) ofs << "-1 -1";
+                    ofs << "\t";
+                }
+                best_guess = res.first;
+                ofs << best_guess.first << " " << best_guess.second << " " << match_type;
+            } else if (res.second == kNoMatchT) {
+                ofs << -1 << " " << -1 << " " << match_type;
+            } else {
+                ofs << -1 << " " << -1 << " " << "Unmatched";
+            }
+            ofs << std::endl;
+            mtype = res.second;
+        }
+        return std::make_pair(best_guess, mtype);
+    }
+
+    // src/read_label.cpp:1211-1279
+    void proc_line(int ri_len, const std::string& line, int k_size, std::ostream& ofs, Tallies& tl,
+                   ReadTrace* tr = nullptr) const {
+        if (ri_len < 0 || ri_len > (int)line.length()) {
+            std::cout << "unexpected ri_len value: " << ri_len << std::endl;
+            return;
+        } else if (ri_len < k_size) {
+            ofs << "-1 -1 -1" << "\t-1 -1\t" << ri_len << " " << k_size << " ReadTooShort" << std::endl;
+            tl.nomatch[kReadTooShort] += 1;
+        } else {
+            std::vector<label_info_t> label_vec(ri_len - k_size + 1, std::make_pair((int16_t)-1, tax_data_t()));
+            std::list<tid_t> taxid_lst;
+            hmap_t tax2idx, idx2tax;
+            const std::pair<int, int> res =
+                retrieve_kmer_labels(line.c_str(), ri_len, k_size, label_vec, taxid_lst, tax2idx, idx2tax, tr);
+            const int valid_kmers = res.first;
+            if (tr) {
+                tr->valid_kmers = valid_kmers;
+                tr->bin_sel = res.second;
+                tr->reg_order.assign(taxid_lst.begin(), taxid_lst.end());
+            }
+            if (valid_kmers < opt.min_kmer) {
+                ofs << "-1 -1 -1" << "\t-1 -1\t" << valid_kmers << " " << opt.min_kmer << " ReadTooShort" << std::endl;
+                tl.nomatch[kReadTooShort] += 1;
+            } else if (!taxid_lst.empty()) {
+                std::pair<ufpair_t, Match> m =
+                    construct_labels(label_vec, taxid_lst, tax2idx, idx2tax, ofs, opt.min_kmer, opt.min_fnd_kmer, tr);
+                if (m.second == kNoMatchT && valid_kmers < opt.min_kmer) {
+                    ofs << "-1 -1 -1" << "\t-1 -1\t" << valid_kmers << " " << opt.min_kmer << " ReadTooShort" << std::endl;
+                    tl.nomatch[kReadTooShort] += 1;
+                } else if (m.second == kNoMatchT) {
+                    tl.nomatch[kNoDbHits] += 1;
+                } else if (m.first.second >= opt.min_score && valid_kmers >= opt.min_kmer) {
+                    if (tl.count.find(m.first.first) == tl.count.end()) {
+                        tl.count[m.first.first] = 1;
+                        tl.score[m.first.first] = m.first.second;
+                    } else {
+                        tl.count[m.first.first] += 1;
+                        tl.score[m.first.first] += m.first.second;
+                    }
+                } else if (m.first.second < opt.min_score) {
+                    tl.nomatch[kLowScore] += 1;
+                }
+            } else {
+                ofs << "-1 -1 " << valid_kmers << "\t-1 -1\t" << ri_len << " " << k_size << " NoDbHits" << std::endl;
+                tl.nomatch[kNoDbHits] += 1;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// FASTA/FASTQ record stream as main()'s producer sees it
+// (src/read_label.cpp:1651-1713), including the FASTQ header lag (quirk Q2)
+// and the short-line rule (quirk Q3).  Yields (read, header) in input order.
+// ---------------------------------------------------------------------------
+struct ReadStream {
+    std::istream& in;
+    bool fastq;
+    bool in_finished = false;
+    std::string hdr_buff, last_hdr_buff, read_buff;
+    size_t pushed = 0;
+    // The reference re-creates last_hdr_buff every 2*n_threads reads.  That reset is
+    // unobservable: every push is preceded by a header line that overwrites it, except
+    // for reads with no header line at all, which see "" either way ... unless the reset
+    // falls between a header and its push, which cannot happen since a push always ends
+    // the producer's inner iteration before the next header is consumed.
+    ReadStream(std::istream& i, bool fq) : in(i), fastq(fq) {}
+    bool next(std::string& read, std::string& hdr) {
+        while (!in_finished) {
+            std::string line;
+            bool eof = !std::getline(in, line);
+            if (eof) { in_finished = true; line = ""; }
+            const char c0 = line.empty() ? '\0' : line[0];
+            if (c0 == '>' || (fastq && c0 == '@')) {
+                last_hdr_buff = hdr_buff;
+                hdr_buff = line.substr(1, line.length() - 1);
+            }
+            bool consumed = false;
+            if (c0 != '>' && line.length() > 1 && !fastq) { read_buff += line; consumed = true; }
+            if (!consumed && fastq && c0 != '@' && c0 != '+' && c0 != '-') { read_buff += line; consumed = true; }
+            const char c1 = consumed ? '\0' : c0;
+            if (((c1 == '>' || in_finished) || (fastq && (c1 == '+' || c1 == '-'))) && read_buff.length() > 0) {
+                read = read_buff;
+                hdr = in_finished ? hdr_buff : last_hdr_buff;
+                read_buff = "";
+                ++pushed;
+                if (fastq) { std::string q; std::getline(in, q); }  // skip quality line
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
+// Whole-run driver: what main() does for -t 1 (src/read_label.cpp:1605-1867).
+struct RunOutputs {
+    std::string out;          // contents of <prefix>0.out
+    std::string fastsummary;  // contents of <prefix>.<x>.<j>.fastsummary
+    std::string nomatchsum;
+    size_t n_reads = 0;
+};
+
+inline void write_summaries(const Tallies& tl, const std::string& rank_ids_fn, RunOutputs& ro) {
+    // read_label.cpp:1801-1852
+    std::set<tid_t> cand_tid;
+    std::vector<std::pair<tid_t, float>> sort_val(tl.score.begin(), tl.score.end());
+    for (auto& p : sort_val) cand_tid.insert(p.first);
+    std::map<tid_t, std::string> save_id;
+    if (!rank_ids_fn.empty()) {
+        std::ifstream ts(rank_ids_fn.c_str());
+        std::string proc;
+        while (std::getline(ts, proc)) {
+            std::vector<char> buff(proc.begin(), proc.end());
+            buff.push_back('\0');
+            char* val = strtok(buff.data(), "=,");
+            while (val != NULL) {
+                if (strcmp(val, "taxid") == 0) {
+                    val = strtok(NULL, "=,");
+                    if (!val) break;
+                    std::istringstream is(val);
+                    tid_t cid = 0;
+                    is >> cid;
+                    if (cand_tid.count(cid)) {
+                        size_t pos = proc.rfind('\t');
+                        save_id.insert(std::make_pair(cid, proc.substr(pos + 1, proc.length() - pos)));
+                    }
+                    break;
+                }
+                val = strtok(NULL, "=,");
+            }
+        }
+    }
+    struct SimpleCmp {
+        bool operator()(const std::pair<tid_t, float>& a, const std::pair<tid_t, float>& b) const {
+            return a.second > b.second;
+        }
+    };
+    std::sort(sort_val.begin(), sort_val.end(), SimpleCmp());
+    std::ostringstream fs;
+    for (unsigned i = 0; i < sort_val.size(); ++i) {
+        const tid_t tid = sort_val[i].first;
+        fs << sort_val[i].second << "\t" << tl.count.find(tid)->second << "\t" << tid << "\t" << save_id[tid] << std::endl;
+    }
+    ro.fastsummary = fs.str();
+    std::ostringstream ns;
+    for (auto it = tl.nomatch.begin(); it != tl.nomatch.end(); ++it)
+        ns << nomatch_str((NoMatch)it->first) << "\t" << it->second << std::endl;
+    ro.nomatchsum = ns.str();
+}
+
+inline RunOutputs run_reads(const Classifier& cls, std::istream& in, int k_size, const std::string& rank_ids_fn) {
+    RunOutputs ro;
+    Tallies tl;
+    std::ostringstream ofs;
+    ReadStream rs(in, cls.opt.fastq);
+    std::string read, hdr;
+    size_t read_count_out = 0;
+    while (rs.next(read, hdr)) {
+        ++read_count_out;
+        if (hdr.empty() || hdr[0] == '\0') {  // read_label.cpp:1728-1732
+            std::ostringstream o;
+            o << "unknown_hdr:" << read_count_out;
+            hdr = o.str();
+        }
+        ofs << hdr << "\t";
+        if (cls.opt.prn_read) ofs << read << "\t"; else ofs << "X" << "\t";
+        cls.proc_line((int)read.length(), read, k_size, ofs, tl);
+    }
+    ro.n_reads = read_count_out;
+    ro.out = ofs.str();
+    write_summaries(tl, rank_ids_fn, ro);
+    return ro;
+}
+
+}  // namespace orc

@@ -1,0 +1,142 @@
+// lmat_oracle_capi.cpp -- C entry points of the CPU oracle for ctypes callers.
+// TEST INFRASTRUCTURE ONLY (see lmat_oracle.hpp header): used by tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker.
+#include "lmat_oracle.hpp"
+
+using namespace orc;
+
+struct orc_ctx {
+    Taxonomy tax;
+    KmerDb db;
+    Options opt;
+    std::string err;
+    std::string text;  // last classify output
+};
+
+extern "C" {
+
+orc_ctx* orc_create(const char* tree, const char* depth, const char* rank, const char* idmap, const char* plasmids) {
+    orc_ctx* c = new orc_ctx();
+    if (idmap && *idmap && !c->tax.load_idmap(idmap)) { delete c; return nullptr; }
+    if (rank && *rank) c->tax.load_rank(rank);
+    if (plasmids && *plasmids) c->tax.load_plasmids(plasmids);
+    if (!c->tax.load_tree(tree) || !c->tax.load_depth(depth)) { delete c; return nullptr; }
+    return c;
+}
+void orc_destroy(orc_ctx* c) { delete c; }
+const char* orc_error(orc_ctx* c) { return c->err.c_str(); }
+
+int orc_add_taxhisto(orc_ctx* c, const char* fn) { return c->db.add_taxhisto(fn, c->tax, &c->err) ? 0 : -1; }
+int orc_db_k(orc_ctx* c) { return c->db.k; }
+void orc_set_k(orc_ctx* c, int k) { c->db.k = k; }
+uint64_t orc_db_size(orc_ctx* c) { return c->db.table.size(); }
+
+// DB entries supplied directly as 32-bit ids in stored order (used when the lists
+// come from another lookup source); ids are mapped 32->16 like add_data would.
+int orc_add_list32(orc_ctx* c, uint64_t kmer, const uint32_t* tids, int n) {
+    std::vector<uint16_t> l;
+    for (int i = 0; i < n; ++i) {
+        auto b = c->tax.br.find(tids[i]);
+        if (b == c->tax.br.end() || b->second == 0) { c->err = "tid not in 32->16 map"; return -1; }
+        l.push_back(b->second);
+    }
+    c->db.add_list(kmer, l);
+    return 0;
+}
+
+// lookup: returns taxidCount, writes up to cap converted 32-bit ids in stored order; -1 = miss
+int orc_lookup(orc_ctx* c, uint64_t kmer, uint32_t* out, int cap) {
+    const std::vector<uint16_t>* l = c->db.lookup(kmer);
+    if (!l) return -1;
+    for (int i = 0; i < (int)l->size() && i < cap; ++i) {
+        auto cv = c->tax.conv.find((*l)[i]);
+        out[i] = cv == c->tax.conv.end() ? 0 : cv->second;
+    }
+    return (int)l->size();
+}
+
+int orc_path_to_root(orc_ctx* c, uint32_t tid, uint32_t* out, int cap) {
+    std::vector<tid_t> p;
+    c->tax.path_to_root(tid, p);
+    for (int i = 0; i < (int)p.size() && i < cap; ++i) out[i] = p[i];
+    return (int)p.size();
+}
+
+void orc_set_options(orc_ctx* c, float sdiff, float hbias, int prn_all, int screen_phix, float min_score, int min_kmer,
+                     int min_fnd_kmer, int prn_read, int fastq) {
+    c->opt.diff_thresh = sdiff;
+    c->opt.diff_thresh2 = hbias;
+    c->opt.prn_all = prn_all != 0;
+    c->opt.screen_phix = screen_phix != 0;
+    c->opt.min_score = min_score;
+    c->opt.min_kmer = min_kmer;
+    c->opt.min_fnd_kmer = min_fnd_kmer;
+    c->opt.prn_read = prn_read != 0;
+    c->opt.fastq = fastq != 0;
+}
+
+// unique canonical k-mers of one read in first-occurrence order (read_label.cpp:978-1017)
+int orc_extract(const char* read, int len, int k, uint64_t* kmers, int* pos, int cap, int* valid_kmers, int* bin_sel) {
+    Taxonomy tax;
+    KmerDb db;
+    Options opt;
+    Classifier cls(tax, db, opt);
+    std::vector<label_info_t> label_vec(len >= k ? len - k + 1 : 0, std::make_pair((int16_t)-1, tax_data_t()));
+    std::list<tid_t> lst;
+    hmap_t a, b;
+    ReadTrace tr;
+    if (len < k) { *valid_kmers = 0; *bin_sel = 0; return 0; }
+    std::pair<int, int> r = cls.retrieve_kmer_labels(read, len, k, label_vec, lst, a, b, &tr);
+    *valid_kmers = r.first;
+    *bin_sel = r.second;
+    int n = (int)tr.uniq_kmers.size();
+    for (int i = 0; i < n && i < cap; ++i) { kmers[i] = tr.uniq_kmers[i]; pos[i] = tr.uniq_pos[i]; }
+    return n;
+}
+
+// Classify n reads given as a blob + offsets (n+1 entries).  Headers are "r<first_index+i>".
+// Produces exactly the bytes read_label -t 1 would write to <prefix>0.out for these reads.
+// Returns length of the text; fetch it with orc_text().  Tallies are returned in the
+// caller's arrays when non-null: counts/scores for up to cap distinct taxids.
+long orc_classify(orc_ctx* c, const char* blob, const uint64_t* off, long n, long first_index, int k_size,
+                  uint32_t* t_tid, int* t_cnt, float* t_score, int t_cap, int* n_tids, int* nomatch3) {
+    Classifier cls(c->tax, c->db, c->opt);
+    Tallies tl;
+    std::ostringstream ofs;
+    for (long i = 0; i < n; ++i) {
+        std::string read(blob + off[i], blob + off[i + 1]);
+        ofs << "r" << (first_index + i) << "\t";
+        if (c->opt.prn_read) ofs << read << "\t"; else ofs << "X" << "\t";
+        cls.proc_line((int)read.length(), read, k_size, ofs, tl);
+    }
+    c->text = ofs.str();
+    if (n_tids) {
+        int j = 0;
+        for (auto it = tl.count.begin(); it != tl.count.end() && j < t_cap; ++it, ++j) {
+            t_tid[j] = it->first;
+            t_cnt[j] = it->second;
+            t_score[j] = tl.score[it->first];
+        }
+        *n_tids = (int)tl.count.size();
+    }
+    if (nomatch3) {
+        for (int i = 0; i < 3; ++i) nomatch3[i] = tl.nomatch.count(i) ? tl.nomatch[i] : 0;
+    }
+    return (long)c->text.size();
+}
+const char* orc_text(orc_ctx* c) { return c->text.c_str(); }
+
+// Whole-file run (FASTA/FASTQ parsing included), as the CLI does.
+long orc_run_file(orc_ctx* c, const char* query, int k_size, const char* rank_ids, char* fastsummary, long fs_cap,
+                  char* nomatchsum, long nm_cap) {
+    std::ifstream in(query);
+    if (!in) { c->err = "cannot open query"; return -1; }
+    Classifier cls(c->tax, c->db, c->opt);
+    RunOutputs ro = run_reads(cls, in, k_size, rank_ids ? rank_ids : "");
+    c->text = ro.out;
+    if (fastsummary) snprintf(fastsummary, fs_cap, "%s", ro.fastsummary.c_str());
+    if (nomatchsum) snprintf(nomatchsum, nm_cap, "%s", ro.nomatchsum.c_str());
+    return (long)c->text.size();
+}
+
+}  // extern "C"
