@@ -1,0 +1,165 @@
+/* lmat_hip.h -- C ABI of the MI355X-native read-labeling engine (liblmat_hip.so).
+ *
+ * The reference (LivGen/LMAT) has no plugin/FFI interface for this path; the
+ * engine is a drop-in at the three seams SURVEY.md 8(b) names.  Each entry
+ * point below cites the reference interface it replaces (paths relative to the
+ * LMAT source tree).  Plain pointers and sizes only; every function returns 0
+ * on success or a negative LMAT_E_* code and never throws; lmat_last_error()
+ * gives the message.  One context per GPU; distinct contexts are independent.
+ *
+ * The engine has NO CPU fallback: if no HIP device is usable, lmat_ctx_create
+ * fails with LMAT_E_DEVICE.
+ */
+#ifndef LMAT_HIP_H
+#define LMAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMAT_OK 0
+#define LMAT_E_ARG (-1)       /* bad argument / call order */
+#define LMAT_E_IO (-2)        /* file missing or malformed */
+#define LMAT_E_DEVICE (-3)    /* HIP error / no device */
+#define LMAT_E_CAPACITY (-4)  /* a fixed on-device capacity was exceeded (message says which) */
+#define LMAT_E_TAXONOMY (-5)  /* inconsistent taxonomy inputs */
+#define LMAT_E_NOMEM (-6)
+
+typedef struct lmat_ctx lmat_ctx;
+typedef struct lmat_reads lmat_reads;
+
+/* ScoreOptions + the scalar thresholds proc_line takes
+ * (src/read_label.cpp:487-497, :1211-1212, getopt cases :1353-1441). */
+typedef struct {
+    float sdiff;        /* -b  ScoreOptions::_diff_thresh   (default 1.0) */
+    float hbias;        /* -l  ScoreOptions::_diff_thresh2  (default 3.0) */
+    float min_score;    /* -x  min_label_score              (default 0)   */
+    int32_t min_kmer;   /* -j  min valid k-mers             (default 35)  */
+    int32_t min_fnd_kmer; /* -z                             (default 1)   */
+    int32_t prn_all;    /* -p  ScoreOptions::_prn_all                      */
+    int32_t screen_phix; /* 1 unless -h (screenPhiXGlobal)                 */
+} lmat_params;
+
+/* What one .out record needs (src/read_label.cpp:844-848,894-937,1218,1233,1271). */
+enum {
+    LMAT_ST_CALL = 0,           /* stats + candidates + call line              */
+    LMAT_ST_PHIX = 1,           /* PhiX short-circuit record (:841-848)        */
+    LMAT_ST_SHORT_LEN = 2,      /* ri_len < k      ReadTooShort (:1217-1218)   */
+    LMAT_ST_SHORT_VALID = 3,    /* valid < min     ReadTooShort (:1232-1233)   */
+    LMAT_ST_NODBHITS = 4,       /* no taxid registered (:1271)                 */
+    LMAT_ST_SILENT = 5          /* construct_labels returned before writing (:727-733): no record text, tallied NoDbHits */
+};
+enum { LMAT_MT_DIRECT = 0, LMAT_MT_MULTI = 1, LMAT_MT_PARTIAL = 2, LMAT_MT_NOMATCH = 3, LMAT_MT_LCA_ERROR = 4 };
+
+typedef struct {
+    uint8_t status;        /* LMAT_ST_*                                         */
+    uint8_t match_type;    /* LMAT_MT_* (status CALL only)                      */
+    uint16_t cand_kmer_cnt; /* distinct valid k-mers with first>=0              */
+    int32_t valid_kmers;   /* valid k-mer positions (dups included)             */
+    int32_t read_len;
+    float log_avg;         /* exact float bits; host formats with %g            */
+    float stdev;
+    uint32_t call_tid;     /* 32-bit NCBI id (0 => printed as -1 -1)            */
+    float call_score;
+    uint32_t cand_off;     /* first candidate of this read in the cands array   */
+    uint32_t n_cand;       /* candidates to print, best first                   */
+    int32_t bin_sel;       /* GC decile (read_label.cpp:1205-1206); null-model input */
+} lmat_read_result;
+
+typedef struct {
+    uint32_t tid;
+    float score;
+} lmat_cand;
+
+/* ---- context ------------------------------------------------------------ */
+int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out);
+void lmat_ctx_destroy(lmat_ctx* ctx);
+const char* lmat_last_error(const lmat_ctx* ctx);
+int lmat_set_params(lmat_ctx* ctx, const lmat_params* params);
+
+/* ---- taxonomy + id maps ---------------------------------------------------
+ * Replaces TaxTree<uint32_t>(file) + getPathToRoot (src/kmerdb/TaxTree.hpp:24-91),
+ * the depth map (read_label.cpp:1574-1582), gRank_table (:1560-1567), conv_map
+ * (:1585-1602) and gLowNumPlasmid (:499-510).  rank_fn / plasmid_fn may be NULL. */
+int lmat_taxonomy_load_files(lmat_ctx* ctx, const char* tree_fn, const char* depth_fn, const char* rank_fn,
+                             const char* idmap_fn, const char* plasmid_fn);
+
+/* ---- k-mer database --------------------------------------------------------
+ * Replaces the PERM-mapped SortedDb (read_label.cpp:1477-1491; lookup contract
+ * SortedDb::begin_/next, src/kmerdb/SortedDb.hpp:188,366, wrapped by
+ * TaxNodeStat::begin/next/taxid/taxidCount, src/kmerdb/TaxNodeStat.hpp:60,208,258,262)
+ * by an open-addressed hash in HBM.  Ingest format = make_db_table's input
+ * (tax_histo binary, SortedDb::add_data src/kmerdb/SortedDb.cpp:84-751, un-pruned path).
+ * table_bytes == 0 sizes the table for a 0.8 load factor. */
+int lmat_db_begin(lmat_ctx* ctx, int k, uint64_t n_kmers_hint, uint64_t table_bytes);
+int lmat_db_add_taxhisto(lmat_ctx* ctx, const char* fn);
+int lmat_db_finalize(lmat_ctx* ctx);
+int lmat_db_kmer_length(const lmat_ctx* ctx);   /* SortedDb::get_kmer_length (SortedDb.hpp:433) */
+uint64_t lmat_db_size(const lmat_ctx* ctx);      /* SortedDb::size (SortedDb.hpp:438)            */
+uint64_t lmat_db_table_bytes(const lmat_ctx* ctx);
+
+/* TaxNodeStat-style lookup of n k-mers on the GPU: counts[i] = taxidCount (0 = miss),
+ * tids[i*stride .. ] = taxid() sequence (32-bit, stored order), up to stride each. */
+int lmat_db_lookup(lmat_ctx* ctx, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids, uint32_t stride);
+
+/* Synthetic DB generated on the device straight into the hash (bench configs;
+ * SURVEY.md 8d).  Requires lmat_synth_taxonomy() first.  genome_len = bases per
+ * strain genome. */
+int lmat_synth_taxonomy(lmat_ctx* ctx, const uint32_t* branching6);
+int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes);
+
+/* ---- reads ----------------------------------------------------------------
+ * A batch of reads packed on the device (2-bit bases + validity bits).
+ * Replaces the (read,hdr) queue hand-off of main() (read_label.cpp:1716-1746):
+ * bases = concatenated ASCII, off[n+1] byte offsets. */
+int lmat_reads_upload(lmat_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint64_t n, lmat_reads** out);
+int lmat_reads_synth(lmat_ctx* ctx, uint64_t n, const uint32_t* lengths, uint32_t n_lengths, uint64_t seed,
+                     lmat_reads** out);
+int lmat_reads_download_ascii(lmat_ctx* ctx, const lmat_reads* r, uint64_t first, uint64_t count, uint8_t* bases,
+                              uint64_t* off);
+uint64_t lmat_reads_count(const lmat_reads* r);
+uint64_t lmat_reads_device_bytes(const lmat_reads* r);
+void lmat_reads_free(lmat_ctx* ctx, lmat_reads* r);
+
+/* ---- classification --------------------------------------------------------
+ * Replaces proc_line (read_label.cpp:1211-1279) for reads [first, first+count).
+ * results[count]; cands/cand_cap may be NULL/0 for calls-only output; *n_cands
+ * receives the number of candidate pairs written.  Per-taxid tallies
+ * (read_label.cpp:1241-1276) accumulate in the context until lmat_counts_reset. */
+int lmat_classify(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count, lmat_read_result* results,
+                  lmat_cand* cands, uint64_t cand_cap, uint64_t* n_cands);
+
+/* Same kernels, results left in device memory (throughput runs).  Asynchronous on
+ * the context's stream; lmat_sync waits.  kernel_ms (may be NULL) = HIP-event time
+ * of the classify kernel, valid after lmat_sync. */
+int lmat_classify_async(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count);
+int lmat_sync(lmat_ctx* ctx, float* kernel_ms_total, uint64_t* kernel_launches);
+int lmat_results_fetch(lmat_ctx* ctx, uint64_t first, uint64_t count, lmat_read_result* results);
+
+/* ---- tallies (merge step read_label.cpp:1760-1800) --------------------------
+ * Dense arrays indexed by the engine's internal taxid index; n_ids = number of
+ * internal ids + 1.  counts_device_ptr exposes the device buffer
+ * [u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]] for an RCCL all-reduce
+ * done by the caller (one process per GPU). */
+int lmat_counts_reset(lmat_ctx* ctx);
+int lmat_counts_layout(const lmat_ctx* ctx, uint32_t* n_ids, uint64_t* bytes);
+void* lmat_counts_device_ptr(lmat_ctx* ctx);
+int lmat_counts_get(lmat_ctx* ctx, uint32_t* tid32, uint64_t* count, double* score, uint32_t cap, uint32_t* n_nonzero,
+                    uint64_t nomatch3[3]);
+
+/* ---- record text -------------------------------------------------------------
+ * The bytes read_label writes to a .out file for these results (prefix
+ * read_label.cpp:1733-1738, body :844-848,894-937,1218,1233,1271).  Headers are
+ * "r<first_index+i>"; bases/off may be NULL when prn_read == 0 ("X" is written, -a).
+ * Returns the text length (excluding the terminating NUL); writes at most cap bytes. */
+int64_t lmat_format_out(const lmat_ctx* ctx, const lmat_read_result* results, uint64_t n, const lmat_cand* cands,
+                        const uint8_t* bases, const uint64_t* off, int prn_read, uint64_t first_index, char* buf,
+                        uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMAT_HIP_H */

@@ -1,0 +1,270 @@
+"""ctypes mirror of include/lmat_hip.h (same names, same argument order, same error codes)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmat_hip.so")
+
+
+class LmatError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lmat error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """lmat_params: ScoreOptions + proc_line thresholds (src/read_label.cpp:487-497,1336-1337)."""
+    _fields_ = [("sdiff", C.c_float), ("hbias", C.c_float), ("min_score", C.c_float), ("min_kmer", C.c_int32),
+                ("min_fnd_kmer", C.c_int32), ("prn_all", C.c_int32), ("screen_phix", C.c_int32)]
+
+    @classmethod
+    def run_rl(cls, prn_all=1):
+        """The flags bin/run_rl.sh passes with --nullm=no: -x 0 -j 30 -l 0 -b 1.0 -p."""
+        return cls(1.0, 0.0, 0.0, 30, 1, prn_all, 1)
+
+
+READ_RESULT_DTYPE = np.dtype([("status", "u1"), ("match_type", "u1"), ("cand_kmer_cnt", "<u2"), ("valid_kmers", "<i4"),
+                              ("read_len", "<i4"), ("log_avg", "<f4"), ("stdev", "<f4"), ("call_tid", "<u4"),
+                              ("call_score", "<f4"), ("cand_off", "<u4"), ("n_cand", "<u4"), ("bin_sel", "<i4")])
+CAND_DTYPE = np.dtype([("tid", "<u4"), ("score", "<f4")])
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Loads liblmat_hip.so.  There is no fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(f"{p} not found: build it with `make -C lmat_amd/csrc` (hipcc, gfx950); "
+                          "lmat_amd has no CPU implementation")
+    lib = C.CDLL(p)
+    vp, u64, u32, i32, cp = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p
+    P = C.POINTER
+    sig = {
+        "lmat_ctx_create": (i32, [i32, P(Params), P(vp)]),
+        "lmat_ctx_destroy": (None, [vp]),
+        "lmat_last_error": (cp, [vp]),
+        "lmat_set_params": (i32, [vp, P(Params)]),
+        "lmat_taxonomy_load_files": (i32, [vp, cp, cp, cp, cp, cp]),
+        "lmat_db_begin": (i32, [vp, i32, u64, u64]),
+        "lmat_db_add_taxhisto": (i32, [vp, cp]),
+        "lmat_db_finalize": (i32, [vp]),
+        "lmat_db_kmer_length": (i32, [vp]),
+        "lmat_db_size": (u64, [vp]),
+        "lmat_db_table_bytes": (u64, [vp]),
+        "lmat_db_lookup": (i32, [vp, vp, u64, vp, vp, u32]),
+        "lmat_synth_taxonomy": (i32, [vp, vp]),
+        "lmat_synth_db_build": (i32, [vp, i32, u64, u64, u64]),
+        "lmat_reads_upload": (i32, [vp, vp, vp, u64, P(vp)]),
+        "lmat_reads_synth": (i32, [vp, u64, vp, u32, u64, P(vp)]),
+        "lmat_reads_download_ascii": (i32, [vp, vp, u64, u64, vp, vp]),
+        "lmat_reads_count": (u64, [vp]),
+        "lmat_reads_device_bytes": (u64, [vp]),
+        "lmat_reads_free": (None, [vp, vp]),
+        "lmat_classify": (i32, [vp, vp, u64, u64, vp, vp, u64, P(u64)]),
+        "lmat_classify_async": (i32, [vp, vp, u64, u64]),
+        "lmat_sync": (i32, [vp, P(C.c_float), P(u64)]),
+        "lmat_results_fetch": (i32, [vp, u64, u64, vp]),
+        "lmat_counts_reset": (i32, [vp]),
+        "lmat_counts_layout": (i32, [vp, P(u32), P(u64)]),
+        "lmat_counts_device_ptr": (vp, [vp]),
+        "lmat_counts_get": (i32, [vp, vp, vp, vp, u32, P(u32), vp]),
+        "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
+            "lmat_db_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
+            "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_reads_upload",
+            "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
+            "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_results_fetch",
+            "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_format_out"]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Reads:
+    def __init__(self, eng, handle):
+        self.eng, self.h = eng, handle
+
+    def __len__(self):
+        return int(self.eng.lib.lmat_reads_count(self.h))
+
+    @property
+    def device_bytes(self):
+        return int(self.eng.lib.lmat_reads_device_bytes(self.h))
+
+    def ascii(self, first=0, count=None):
+        """-> (bases uint8 array, offsets uint64[count+1]) decoded back from the packed device records."""
+        n = len(self) - first if count is None else count
+        off = np.zeros(n + 1, dtype=np.uint64)
+        self.eng._chk(self.eng.lib.lmat_reads_download_ascii(self.eng.ctx, self.h, first, n, None, _ptr(off)))
+        bases = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        self.eng._chk(self.eng.lib.lmat_reads_download_ascii(self.eng.ctx, self.h, first, n, _ptr(bases), _ptr(off)))
+        return bases[:-1], off
+
+    def free(self):
+        if self.h:
+            self.eng.lib.lmat_reads_free(self.eng.ctx, self.h)
+            self.h = None
+
+
+class Engine:
+    """One context on one GPU (lmat_ctx)."""
+
+    def __init__(self, device=0, params: Params | None = None):
+        self.lib = load_library()
+        self.params = params or Params.run_rl()
+        ctx = C.c_void_p()
+        rc = self.lib.lmat_ctx_create(device, C.byref(self.params), C.byref(ctx))
+        if rc != 0:
+            raise LmatError(rc, "lmat_ctx_create failed (no usable HIP device?)")
+        self.ctx = ctx
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LmatError(rc, self.lib.lmat_last_error(self.ctx).decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.lmat_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def set_params(self, p: Params):
+        self.params = p
+        self._chk(self.lib.lmat_set_params(self.ctx, C.byref(p)))
+
+    # taxonomy / DB --------------------------------------------------------------
+    def load_taxonomy(self, tree, depth, rank, idmap, plasmids=None):
+        e = lambda s: s.encode() if s else None
+        self._chk(self.lib.lmat_taxonomy_load_files(self.ctx, e(tree), e(depth), e(rank), e(idmap), e(plasmids)))
+
+    def build_db(self, files, k=20, table_bytes=0):
+        self._chk(self.lib.lmat_db_begin(self.ctx, k, 0, table_bytes))
+        for f in ([files] if isinstance(files, str) else files):
+            self._chk(self.lib.lmat_db_add_taxhisto(self.ctx, f.encode()))
+        self._chk(self.lib.lmat_db_finalize(self.ctx))
+
+    def synth_taxonomy(self, branching=(3, 4, 4, 4, 4, 3)):
+        b = np.asarray(branching, dtype=np.uint32)
+        self._chk(self.lib.lmat_synth_taxonomy(self.ctx, _ptr(b)))
+
+    def synth_db(self, genome_len, k=20, seed=2002, table_bytes=0):
+        self._chk(self.lib.lmat_synth_db_build(self.ctx, k, int(genome_len), seed, int(table_bytes)))
+
+    @property
+    def k(self):
+        return int(self.lib.lmat_db_kmer_length(self.ctx))
+
+    @property
+    def db_size(self):
+        return int(self.lib.lmat_db_size(self.ctx))
+
+    @property
+    def table_bytes(self):
+        return int(self.lib.lmat_db_table_bytes(self.ctx))
+
+    def lookup(self, kmers, stride=64):
+        km = np.ascontiguousarray(kmers, dtype=np.uint64)
+        counts = np.zeros(km.size, dtype=np.uint32)
+        tids = np.zeros((km.size, stride), dtype=np.uint32)
+        self._chk(self.lib.lmat_db_lookup(self.ctx, _ptr(km), km.size, _ptr(counts), _ptr(tids), stride))
+        return counts, tids
+
+    # reads ----------------------------------------------------------------------
+    def upload_reads(self, seqs) -> Reads:
+        """seqs: list of str/bytes, or (uint8 blob, uint64 offsets)."""
+        if isinstance(seqs, tuple):
+            blob, off = seqs
+        else:
+            bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+            off = np.zeros(len(bs) + 1, dtype=np.uint64)
+            np.cumsum([len(b) for b in bs], out=off[1:])
+            blob = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        h = C.c_void_p()
+        self._chk(self.lib.lmat_reads_upload(self.ctx, _ptr(blob), _ptr(off), off.size - 1, C.byref(h)))
+        return Reads(self, h)
+
+    def synth_reads(self, n, lengths=(150,), seed=3003) -> Reads:
+        ln = np.asarray(lengths, dtype=np.uint32)
+        h = C.c_void_p()
+        self._chk(self.lib.lmat_reads_synth(self.ctx, int(n), _ptr(ln), ln.size, seed, C.byref(h)))
+        return Reads(self, h)
+
+    # classify -------------------------------------------------------------------
+    def classify(self, reads: Reads, first=0, count=None, want_cands=True, cand_cap=None):
+        n = len(reads) - first if count is None else count
+        res = np.zeros(n, dtype=READ_RESULT_DTYPE)
+        ncand = C.c_uint64(0)
+        if want_cands:
+            cap = cand_cap or max(64 * n, 1024)
+            cands = np.zeros(cap, dtype=CAND_DTYPE)
+            self._chk(self.lib.lmat_classify(self.ctx, reads.h, first, n, _ptr(res), _ptr(cands), cap, C.byref(ncand)))
+            return res, cands
+        self._chk(self.lib.lmat_classify(self.ctx, reads.h, first, n, _ptr(res), None, 0, C.byref(ncand)))
+        return res, None
+
+    def classify_async(self, reads: Reads, first=0, count=None):
+        n = len(reads) - first if count is None else count
+        self._chk(self.lib.lmat_classify_async(self.ctx, reads.h, first, n))
+
+    def sync(self):
+        ms, nl = C.c_float(0), C.c_uint64(0)
+        self._chk(self.lib.lmat_sync(self.ctx, C.byref(ms), C.byref(nl)))
+        return float(ms.value), int(nl.value)
+
+    def fetch_results(self, first, count):
+        res = np.zeros(count, dtype=READ_RESULT_DTYPE)
+        self._chk(self.lib.lmat_results_fetch(self.ctx, first, count, _ptr(res)))
+        return res
+
+    def format_out(self, res, cands, reads_ascii=None, first_index=0):
+        """.out text for these results; reads_ascii = (blob, off) to echo the read, else 'X' (-a)."""
+        blob, off = reads_ascii if reads_ascii is not None else (None, None)
+        need = self.lib.lmat_format_out(self.ctx, _ptr(res), res.size, _ptr(cands), _ptr(blob), _ptr(off),
+                                        1 if blob is not None else 0, first_index, None, 0)
+        buf = C.create_string_buffer(int(need) + 1)
+        self.lib.lmat_format_out(self.ctx, _ptr(res), res.size, _ptr(cands), _ptr(blob), _ptr(off),
+                                 1 if blob is not None else 0, first_index, buf, need + 1)
+        return buf.raw[:need].decode()
+
+    # tallies ----------------------------------------------------------------------
+    def counts_reset(self):
+        self._chk(self.lib.lmat_counts_reset(self.ctx))
+
+    def counts_layout(self):
+        n, b = C.c_uint32(0), C.c_uint64(0)
+        self._chk(self.lib.lmat_counts_layout(self.ctx, C.byref(n), C.byref(b)))
+        return int(n.value), int(b.value)
+
+    def counts_device_ptr(self):
+        return int(self.lib.lmat_counts_device_ptr(self.ctx) or 0)
+
+    def counts(self):
+        n, _ = self.counts_layout()
+        tid = np.zeros(n, dtype=np.uint32)
+        cnt = np.zeros(n, dtype=np.uint64)
+        sc = np.zeros(n, dtype=np.float64)
+        nz = C.c_uint32(0)
+        nm = np.zeros(3, dtype=np.uint64)
+        self._chk(self.lib.lmat_counts_get(self.ctx, _ptr(tid), _ptr(cnt), _ptr(sc), n, C.byref(nz), _ptr(nm)))
+        k = int(nz.value)
+        return {int(t): (int(c), float(s)) for t, c, s in zip(tid[:k], cnt[:k], sc[:k])}, [int(x) for x in nm]

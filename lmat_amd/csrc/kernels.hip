@@ -1,0 +1,1028 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the read-labeling engine.
+//
+// One wavefront classifies one read end to end (k-mer extraction -> dedupe -> hash probe
+// -> taxid registration / lineage closure / counting -> score + LCA decision), keeping
+// all per-read state in LDS.  The k-mer database is an open-addressed hash in HBM probed
+// 8 lanes per 64-byte bucket.  No MFMA: this is a hash/gather path.
+//
+// Reference semantics restated here (paths relative to the LMAT tree):
+//   K1 extract/canonical/dedupe   src/read_label.cpp:943-950, 978-1017
+//   K2 lookup                     src/kmerdb/SortedDb.hpp:279-385, TaxNodeStat.hpp:60-74,208-264
+//   K3 registration/closure/count src/read_label.cpp:1104-1204, 692-764
+//   K4 score + decision           src/read_label.cpp:803-941, 284-419, 225-282
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+
+namespace lmat {
+
+#define WSYNC()                                              \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
+
+__device__ __forceinline__ uint64_t lt_mask(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+__device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+    x *= 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(x >> 40);
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: ASCII -> packed records.  One wave per read, 16 bases per lane per step.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t* __restrict__ bases,
+                                                         const uint64_t* __restrict__ off,
+                                                         const uint64_t* __restrict__ rec_off,
+                                                         uint32_t* __restrict__ words, uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t r = wave; r < n; r += nw) {
+        const uint64_t b0 = off[r];
+        const uint32_t len = (uint32_t)(off[r + 1] - b0);
+        uint32_t* rec = words + rec_off[r];
+        if (lane == 0) rec[0] = len;
+        const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
+        for (uint32_t w0 = 0; w0 < nb; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            uint32_t code = 0, valid = 0;
+            if (w < nb) {
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t p = w * 16 + j;
+                    if (p < len) {
+                        uint8_t ch = bases[b0 + p];
+                        uint32_t t = 4;
+                        switch (ch) {  // ENCODE, read_label.cpp:943-950
+                            case 'a': case 'A': t = 0; break;
+                            case 'c': case 'C': t = 1; break;
+                            case 'g': case 'G': t = 2; break;
+                            case 't': case 'T': t = 3; break;
+                        }
+                        if (t < 4) { code |= t << (2 * j); valid |= 1u << j; }
+                    }
+                }
+                rec[1 + w] = code;
+            }
+            // two neighbouring lanes hold the 32 validity bits of one mask word
+            uint32_t other = __shfl_down(valid, 1);
+            if (w < nb && (w & 1) == 0) rec[1 + nb + (w >> 1)] = valid | (((w + 1 < nb) ? other : 0u) << 16);
+        }
+        (void)nm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// DB build: insert (k-mer, payload) pairs.  Equal keys keep the smaller payload, which makes
+// the synthetic generator deterministic; ingested files never repeat a key.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool hash_insert(uint64_t* slots, uint32_t nbuckets, uint64_t kmer, uint32_t payload) {
+    const uint64_t val = (kmer << kPayloadBits) | payload;
+    uint32_t b = bucket_of(kmer, nbuckets);
+    for (uint32_t tries = 0; tries < nbuckets; ++tries) {
+        unsigned long long* s = (unsigned long long*)(slots + (uint64_t)b * kSlotsPerBucket);
+        for (int j = 0; j < kSlotsPerBucket; ++j) {
+            unsigned long long old = s[j];
+            while (true) {
+                if (old == 0) {
+                    unsigned long long prev = atomicCAS(&s[j], 0ull, (unsigned long long)val);
+                    if (prev == 0) return true;
+                    old = prev;
+                    continue;
+                }
+                if ((old >> kPayloadBits) == kmer) {
+                    if (old <= val) return true;
+                    unsigned long long prev = atomicCAS(&s[j], old, (unsigned long long)val);
+                    if (prev == old) return true;
+                    old = prev;
+                    continue;
+                }
+                break;
+            }
+        }
+        b = b + 1 == nbuckets ? 0 : b + 1;
+    }
+    return false;
+}
+
+__global__ void insert_pairs_kernel(uint64_t* slots, uint32_t nbuckets, const uint64_t* __restrict__ kmers,
+                                    const uint32_t* __restrict__ payload, uint64_t n, uint32_t* fail) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        if (!hash_insert(slots, nbuckets, kmers[i], payload[i])) atomicAdd(fail, 1u);
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic genomes (bench configs): species ancestor = iid bases from a
+// counter-based PRNG; strain = ancestor with 1% substitutions.  All pure functions of
+// (seed, species/strain, position) so host code can reproduce any window.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t synth_anc_base(uint64_t seed, uint32_t species, uint64_t pos) {
+    return (uint32_t)(splitmix(seed ^ ((uint64_t)(species + 1) << 40) ^ pos) >> 13) & 3u;
+}
+__host__ __device__ __forceinline__ uint32_t synth_strain_base(uint64_t seed, uint32_t species, uint32_t strain_global,
+                                                               uint64_t pos) {
+    uint32_t b = synth_anc_base(seed, species, pos);
+    uint64_t h = splitmix((seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
+    if ((h % 100) == 0) b = (b + 1 + (uint32_t)((h >> 32) % 3)) & 3u;
+    return b;
+}
+__host__ __device__ __forceinline__ bool synth_strain_mut(uint64_t seed, uint32_t strain_global, uint64_t pos) {
+    uint64_t h = splitmix((seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
+    return (h % 100) == 0;
+}
+__host__ __device__ __forceinline__ uint64_t canon_from_fwd(uint64_t fwd, int k) {
+    // reverse complement of a forward-encoded k-mer (first base in the high bits)
+    uint64_t x = ~fwd;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    x = (x >> 32) | (x << 32);
+    x >>= (64 - 2 * k);
+    return fwd < x ? fwd : x;
+}
+
+// one thread per (species, window start); S strains per species (S <= 8)
+__global__ void synth_db_kernel(uint64_t* slots, uint32_t nbuckets, uint64_t seed, uint32_t n_species, uint32_t S,
+                                uint64_t G, int k, const uint16_t* __restrict__ strain_idx,
+                                const uint32_t* __restrict__ list_payload /*[species*(1<<S)+mask]*/, uint32_t* fail,
+                                unsigned long long* inserted) {
+    const uint64_t npos = G - k + 1;
+    const uint64_t total = (uint64_t)n_species * npos;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long local = 0;
+    for (; i < total; i += stride) {
+        const uint32_t sp = (uint32_t)(i / npos);
+        const uint64_t pos = i % npos;
+        uint64_t anc = 0;
+        for (int j = 0; j < k; ++j) anc = (anc << 2) | synth_anc_base(seed, sp, pos + j);
+        uint32_t mask = 0;
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint32_t sg = sp * S + s;
+            bool mut = false;
+            for (int j = 0; j < k; ++j) mut |= synth_strain_mut(seed, sg, pos + j);
+            if (!mut) {
+                mask |= 1u << s;
+            } else {
+                uint64_t f = 0;
+                for (int j = 0; j < k; ++j) f = (f << 2) | synth_strain_base(seed, sp, sg, pos + j);
+                if (!hash_insert(slots, nbuckets, canon_from_fwd(f, k), strain_idx[sg])) atomicAdd(fail, 1u);
+                ++local;
+            }
+        }
+        if (mask) {
+            if (!hash_insert(slots, nbuckets, canon_from_fwd(anc, k), list_payload[(uint64_t)sp * (1u << S) + mask]))
+                atomicAdd(fail, 1u);
+            ++local;
+        }
+    }
+    atomicAdd(inserted, local);
+}
+
+__global__ void count_slots_kernel(const uint64_t* __restrict__ slots, uint64_t nslots, unsigned long long* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (; i < nslots; i += stride) c += slots[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// Synthetic reads written directly as packed records.  Fixed record stride so offsets are
+// implicit in rec_off.  Mix per SURVEY 8d: 88% genome samples with 1% substitutions, 10%
+// iid random, 1% with a single N, 1% low-complexity (25-base period).
+__global__ void synth_reads_kernel(uint32_t* words, const uint64_t* __restrict__ rec_off,
+                                   const uint32_t* __restrict__ lengths, uint32_t n_lengths, uint64_t n, uint64_t seed,
+                                   uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t r = wave; r < n; r += nw) {
+        const uint64_t h0 = splitmix(seed ^ (r * 0x9E3779B97F4A7C15ull));
+        const uint32_t len = lengths[(uint32_t)((h0 >> 48) % n_lengths)];
+        uint32_t* rec = words + rec_off[r];
+        if (lane == 0) rec[0] = len;
+        const uint32_t kind = (uint32_t)(h0 % 100);  // 0..9 random, 10 low complexity, 11 single N, else genome
+        const uint32_t sg = (uint32_t)((h0 >> 8) % ((uint64_t)n_species * S));
+        const uint32_t sp = sg / S;
+        const uint64_t maxoff = G > len ? G - len : 0;
+        const uint64_t goff = (splitmix(h0) >> 4) % (maxoff + 1);
+        const bool rc = (h0 >> 40) & 1;
+        const uint32_t npos = (uint32_t)((splitmix(h0 ^ 77) >> 7) % len);
+        const uint32_t nb = (len + 15) / 16;
+        for (uint32_t w0 = 0; w0 < nb; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            uint32_t code = 0, valid = 0;
+            if (w < nb) {
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t p = w * 16 + j;
+                    if (p >= len) break;
+                    uint32_t b;
+                    if (kind < 10) {
+                        b = (uint32_t)(splitmix(h0 ^ ((uint64_t)p << 20) ^ 0x1234567) >> 9) & 3u;
+                    } else if (kind == 10) {
+                        b = (uint32_t)(splitmix(h0 ^ ((uint64_t)(p % 25) << 20) ^ 0x7654321) >> 9) & 3u;
+                    } else {
+                        const uint64_t gp = rc ? goff + (len - 1 - p) : goff + p;
+                        b = synth_strain_base(db_seed, sp, sg, gp < G ? gp : G - 1);
+                        if (rc) b ^= 3u;
+                        const uint64_t e = splitmix(h0 ^ ((uint64_t)p << 24) ^ 0xABCDEF);
+                        if ((e % 100) == 0) b = (b + 1 + (uint32_t)((e >> 32) % 3)) & 3u;
+                    }
+                    bool ok = !(kind == 11 && p == npos);
+                    code |= b << (2 * j);
+                    valid |= (ok ? 1u : 0u) << j;
+                }
+                rec[1 + w] = code;
+            }
+            uint32_t other = __shfl_down(valid, 1);
+            if (w < nb && (w & 1) == 0) rec[1 + nb + (w >> 1)] = valid | (((w + 1 < nb) ? other : 0u) << 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TaxNodeStat-style lookup for tests and tooling: one thread per k-mer.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t probe_scalar(const uint64_t* __restrict__ slots, uint32_t nbuckets, uint64_t kmer) {
+    uint32_t b = bucket_of(kmer, nbuckets);
+    for (uint32_t tries = 0; tries < nbuckets; ++tries) {
+        const uint64_t* s = slots + (uint64_t)b * kSlotsPerBucket;
+        bool empty = false;
+        for (int j = 0; j < kSlotsPerBucket; ++j) {
+            const uint64_t v = s[j];
+            if (v == 0) empty = true;
+            else if ((v >> kPayloadBits) == kmer) return (uint32_t)(v & kPayloadMask);
+        }
+        if (empty) return 0;
+        b = b + 1 == nbuckets ? 0 : b + 1;
+    }
+    return 0;
+}
+
+__global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmers, uint64_t n, uint32_t* counts,
+                              uint32_t* tids, uint32_t stride) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pay = probe_scalar(tb.slots, tb.nbuckets, kmers[i]);
+    if (pay == 0) { counts[i] = 0; return; }
+    if (pay < kListBase) {
+        counts[i] = 1;
+        if (stride) tids[i * stride] = tb.tid32[pay];
+        return;
+    }
+    const uint32_t eoff = 2 * (pay - kListBase);
+    const uint32_t nk = tb.arena[eoff + 1], nr = tb.arena[eoff + 2];
+    counts[i] = nr;
+    for (uint32_t j = 0; j < nr && j < stride; ++j) tids[i * stride + j] = tb.conv[tb.arena[eoff + kListHdr + 2 * nk + j]];
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-wave LDS layout of the classify kernel.
+//   U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in
+//   registered taxids.  Regions are reused across phases (see classify_one).
+// ------------------------------------------------------------------------------------------
+struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351)
+    uint16_t tid;
+    uint16_t flag;  // bit0: member of no_good
+    float score;
+};
+
+template <int U, int T>
+struct WL {
+    static constexpr int H = 2 * U;    // k-mer / payload hash slots (power of two)
+    static constexpr int TH = 4 * T;   // taxid hash slots: <= T registered + <= T unregistered species keys
+    static constexpr int LIN = T + 72; // lineage scratch entries
+    static constexpr int RD_WORDS = (U + 96) / 16 + (U + 96) / 32 + 4;
+    static constexpr int R1_HASH = 8 * H + 4 * H;                  // u64 hv[H], u32 haux[H]
+    static constexpr int R1_TID = 2 * T * 6 + 4 * T + 4 * TH + 4 * TH;  // reg,cnt,leaf,stamp,dep,ord | score | hent | best
+    static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
+    static constexpr int R2_K = 8 * U + 4 * U;                     // ukmer, ubucket
+    static constexpr int R2_D = 4 * U + 4 * U + 8 * LIN;           // dpay, dmult, lineage
+    static constexpr int R2 = R2_K > R2_D ? R2_K : R2_D;
+    static constexpr int R3 = 4 * U;                               // upay
+    static constexpr int OFF_RD = 0;
+    static constexpr int OFF_R1 = ((RD_WORDS * 4 + 15) / 16) * 16;
+    static constexpr int OFF_R2 = OFF_R1 + ((R1 + 15) / 16) * 16;
+    static constexpr int OFF_R3 = OFF_R2 + ((R2 + 15) / 16) * 16;
+    static constexpr int BYTES = OFF_R3 + ((R3 + 15) / 16) * 16;
+};
+
+static const uint64_t kEmpty64 = ~0ull;
+
+// min-insert (key << 16 | idx) into a u64 LDS hash; returns the key's slot (stable once claimed).
+__device__ __forceinline__ uint32_t lds_min_insert(unsigned long long* hv, int hmask, uint64_t key, uint32_t idx) {
+    const unsigned long long v = (key << 16) | idx;
+    uint32_t h = hash32(key) & hmask;
+    while (true) {
+        unsigned long long old = hv[h];
+        if (old == kEmpty64 || (old >> 16) == key) {
+            if (old != kEmpty64 && old <= v) return h;
+            unsigned long long prev = atomicCAS(&hv[h], old, v);
+            if (prev == old) return h;
+        } else {
+            h = (h + 1) & hmask;
+        }
+    }
+}
+__device__ __forceinline__ uint32_t lds_find(const unsigned long long* hv, int hmask, uint64_t key) {
+    uint32_t h = hash32(key) & hmask;
+    while ((hv[h] >> 16) != key) h = (h + 1) & hmask;
+    return h;
+}
+
+// taxid hash entry: low 16 bits = taxid index (0 = empty), high 16 = registration slot or 0xFFFF
+__device__ __forceinline__ uint32_t tid_hash(uint32_t t, int thmask) { return ((t * 0x9E3779B1u) >> 12) & thmask; }
+__device__ __forceinline__ uint32_t tid_find_or_claim(unsigned int* hent, int thmask, uint32_t t) {
+    uint32_t h = tid_hash(t, thmask);
+    while (true) {
+        unsigned int cur = hent[h];
+        if ((cur & 0xFFFFu) == t) return h;
+        if (cur == 0) {
+            unsigned int prev = atomicCAS(&hent[h], 0u, t | 0xFFFF0000u);
+            if (prev == 0 || (prev & 0xFFFFu) == t) return h;
+        }
+        h = (h + 1) & thmask;
+    }
+}
+__device__ __forceinline__ int tid_find(const unsigned int* hent, int thmask, uint32_t t) {
+    uint32_t h = tid_hash(t, thmask);
+    while (true) {
+        unsigned int cur = hent[h];
+        if ((cur & 0xFFFFu) == t) return (int)h;
+        if (cur == 0) return -1;
+        h = (h + 1) & thmask;
+    }
+}
+// registration slot of taxid t, or -1 when t is not registered
+__device__ __forceinline__ int tid_slot(const unsigned int* hent, int thmask, uint32_t t) {
+    const int h = tid_find(hent, thmask, t);
+    if (h < 0) return -1;
+    const uint32_t s = hent[h] >> 16;
+    return s == 0xFFFFu ? -1 : (int)s;
+}
+
+// isAncestor (read_label.cpp:138-150): a is on b's path to root (b itself excluded).
+__device__ __forceinline__ bool is_ancestor(const DeviceTables& tb, uint32_t a, uint32_t b) {
+    if (b == 0) return false;
+    const uint32_t la = tb.path_len[a], lb = tb.path_len[b];
+    if (lb <= la) return false;
+    return tb.paths[tb.path_off[b] + (lb - la - 1)] == a;
+}
+
+struct TCmpDev {  // TCmp, read_label.cpp:475-485
+    const float* score;
+    const uint16_t* dep;
+    __device__ bool operator()(uint16_t a, uint16_t b) const {
+        const float d = score[a] - score[b];
+        if ((double)fabsf(d) < 0.001) return (int)dep[a] < (int)dep[b];
+        return score[a] < score[b];
+    }
+};
+struct CmpDepthDev {  // CmpDepth, read_label.cpp:159-167
+    const uint16_t* fdepth;
+    __device__ bool operator()(const LinEnt& a, const LinEnt& b) const { return (int)fdepth[a.tid] > (int)fdepth[b.tid]; }
+};
+
+// K4, executed by lane 0.  cnt[]/reg[] are final, registration order = slot order.
+template <int U, int T>
+__device__ void decide_read(const ClassifyArgs& A, lmat_read_result& res, const uint16_t* reg, const uint16_t* cnt,
+                            float* score, const uint16_t* dep, uint16_t* ord, const unsigned int* hent, LinEnt* lin,
+                            int nT, uint32_t cand, lmat_cand* cand_out, uint32_t* n_cand_out, uint32_t* call_idx_out,
+                            uint32_t* errflags) {
+    const KernelParams& P = A.prm;
+    const DeviceTables& tb = A.tb;
+    constexpr int THM = WL<U, T>::TH - 1;
+    // --- scores and running sums in registration order, read_label.cpp:748-764,803-837
+    bool fnd_phix = false, has_human = false;
+    float log_sum = 0.0f, pos_log_sum = 0.0f, top_score = 0.0f, phix_score = 0.0f;
+    unsigned sig_hits = 0, pos_sig_hits = 0;
+    const float fcand = (float)cand;
+    for (int s = 0; s < nT; ++s) {
+        const float sc = (float)cnt[s] / fcand;
+        score[s] = sc;
+        const uint8_t fl = tb.flags[reg[s]];
+        if (fl & kFlagHuman) has_human = true;
+        log_sum += sc;
+        sig_hits++;
+        if (sc > 0) { pos_sig_hits++; pos_log_sum += sc; }
+        if (P.screen_phix && (fl & kFlagPhiX)) { phix_score = sc; fnd_phix = true; }
+        if (s == 0 || sc > top_score) top_score = sc;
+    }
+    res.cand_kmer_cnt = (uint16_t)cand;
+    *n_cand_out = 0;
+    if (P.screen_phix && phix_score >= top_score && fnd_phix) {  // :841-848
+        res.status = LMAT_ST_PHIX;
+        res.match_type = LMAT_MT_DIRECT;
+        res.call_tid = 32630;
+        res.call_score = phix_score;
+        *call_idx_out = A.phix_call_idx;
+        return;
+    }
+    // --- mean / stdev, :850-881
+    unsigned use_sig_hits;
+    float log_avg;
+    if (pos_sig_hits > 3) { use_sig_hits = pos_sig_hits; log_avg = pos_log_sum / (float)pos_sig_hits; }
+    else { use_sig_hits = sig_hits; log_avg = sig_hits > 0 ? log_sum / (float)sig_hits : 0; }
+    float log_std = 0;
+    for (int s = 0; s < nT; ++s) {
+        const float sc = score[s];
+        if (sc > 0 && pos_sig_hits > 3) { const float v = log_avg - sc; log_std += (v * v); }
+        if (pos_sig_hits <= 3) { const float v = log_avg - sc; log_std += (v * v); }
+    }
+    float stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0;
+    res.status = LMAT_ST_CALL;
+    res.log_avg = log_avg;
+    res.stdev = stdev1;
+    // --- human bias, sort by TCmp, :883-893
+    if (has_human) {
+        for (int s = 0; s < nT; ++s)
+            if (tb.flags[reg[s]] & kFlagHuman) score[s] += (P.hbias * stdev1);
+    }
+    for (int s = 0; s < nT; ++s) ord[s] = (uint16_t)s;
+    ss_sort(ord, nT, TCmpDev{score, dep});
+    const float diff_thresh = stdev1 * P.sdiff;  // :895
+
+    // --- findReadLabelVer2, :284-419
+    uint8_t match = LMAT_MT_NOMATCH;
+    uint32_t save_plasmid = 0;
+    bool plasmid_top = false;
+    unsigned lowest_depth = 0, highest_depth = 0;
+    int lowest = -1, highest = -1;  // slots
+    int lidx = -1;
+    bool lin_done = false;
+    int nlin = 0;
+    for (int i = nT - 1; i >= 0; --i) {
+        const int s = ord[i];
+        const uint32_t t = reg[s];
+        if (score[s] >= top_score && (tb.flags[t] & kFlagPlasmid)) { plasmid_top = true; save_plasmid = t; }
+        if (!lin_done) {
+            bool add = true;  // addToCandLineage :225-262
+            const unsigned cd = dep[s];
+            for (int j = 0; j < nlin; ++j) {
+                const uint32_t lt = lin[j].tid;
+                const unsigned chk = tb.fdepth[lt];
+                if (chk > cd && !is_ancestor(tb, t, lt)) { add = false; break; }
+                else if (chk < cd && !is_ancestor(tb, lt, t)) { add = false; break; }
+                else if (chk == cd) { add = false; break; }
+            }
+            if (!add) {
+                lidx = i;
+                lin_done = true;
+            } else {
+                lin[nlin].tid = (uint16_t)t; lin[nlin].flag = 0; lin[nlin].score = score[s];
+                ++nlin;
+                if (cd > lowest_depth || i == nT - 1) { lowest = s; lowest_depth = cd; }
+                if (cd < highest_depth || i == nT - 1) { highest = s; highest_depth = cd; }
+            }
+        }
+        if (lin_done && score[s] < top_score) break;
+    }
+    // ancestors of the shallowest accepted node, :326-343 (all_cand_set holds pre-bias scores)
+    const uint32_t high_tid = highest >= 0 ? reg[highest] : 0;
+    const bool have_add = highest_depth != 0 && high_tid != 0;
+    if (have_add) {
+        const int anc_len = tb.path_len[high_tid];
+        const uint32_t off = tb.path_off[high_tid];
+        for (int j = 0; j < anc_len; ++j) {
+            if (nlin >= WL<U, T>::LIN) { atomicOr(errflags, (uint32_t)kErrLineageTrunc); break; }
+            const uint32_t a = tb.paths[off + j];
+            const int s = tid_slot(hent, THM, a);
+            lin[nlin].tid = (uint16_t)a; lin[nlin].flag = 0;
+            lin[nlin].score = s >= 0 ? (float)cnt[s] / fcand : -10000.0f;
+            ++nlin;
+        }
+    }
+    // without -p, MultiMatch prints cand_lin in list order (:917-927): save it before sorting
+    const int nlin_total = nlin;
+    if (!P.prn_all && cand_out) {
+        for (int j = 0; j < nlin; ++j) { cand_out[j].tid = tb.tid32[lin[j].tid]; cand_out[j].score = lin[j].score; }
+    }
+    ss_sort(lin, nlin, CmpDepthDev{tb.fdepth});  // :344-351
+    // competitors, :355-362 with cmpCompLineage :264-282
+    bool any_no_good = false;
+    for (int i = lidx; i >= 0; --i) {
+        const int s = ord[i];
+        const uint32_t t = reg[s];
+        if (have_add && is_ancestor(tb, t, high_tid)) continue;  // member of add_set
+        bool keep_going = true;
+        const float cs = score[s];
+        for (int j = 0; j < nlin; ++j) {
+            if (is_ancestor(tb, lin[j].tid, t)) break;
+            const float ls = lin[j].score;
+            if (ls != -10000.0f && (ls - cs) > diff_thresh) { keep_going = false; break; }
+            if ((ls - cs) <= diff_thresh) { lin[j].flag |= 1; any_no_good = true; }
+        }
+        if (!keep_going) break;
+    }
+    uint32_t call_tid = 0;
+    float call_score = 0;
+    if (nlin == 0 && !any_no_good) {
+        match = LMAT_MT_NOMATCH;
+    } else if (nlin > 0 && !any_no_good) {
+        call_tid = reg[lowest];
+        call_score = score[lowest];
+        match = LMAT_MT_DIRECT;
+    } else {
+        float max_val = -10000.0f;
+        int root_idx = -1;
+        for (int j = 0; j < nlin; ++j) {
+            max_val = max_val < lin[j].score ? lin[j].score : max_val;  // std::max(cand, max_val)
+            if (!(lin[j].flag & 1)) { root_idx = j; break; }
+        }
+        if (root_idx < 0) {
+            // LCA_ERROR: construct_labels leaves best_guess at (0,0) (:931-936)
+            call_tid = 0; call_score = 0; match = LMAT_MT_LCA_ERROR;
+        } else {
+            match = LMAT_MT_MULTI;
+            const uint32_t lca = lin[root_idx].tid;
+            if (tid_slot(hent, THM, lca) >= 0) {
+                if (max_val < lin[root_idx].score) { match = LMAT_MT_PARTIAL; max_val = lin[root_idx].score; }
+            }
+            call_tid = lca;
+            call_score = max_val;
+        }
+    }
+    if (plasmid_top && match != LMAT_MT_LCA_ERROR && is_ancestor(tb, call_tid, save_plasmid)) call_tid = save_plasmid;
+    res.match_type = match;
+    res.call_tid = call_tid ? tb.tid32[call_tid] : 0;
+    res.call_score = call_score;
+    *call_idx_out = call_tid;
+    uint32_t ncand = 0;
+    if (P.prn_all) {  // :898-910
+        if (cand_out) {
+            for (int i = nT - 1; i >= 0; --i) {
+                const int s = ord[i];
+                if (score[s] >= 0) { cand_out[ncand].tid = tb.tid32[reg[s]]; cand_out[ncand].score = score[s]; ++ncand; }
+            }
+        }
+    } else if ((match == LMAT_MT_MULTI || match == LMAT_MT_PARTIAL) && cand_out) {
+        ncand = nlin_total;
+    }
+    *n_cand_out = ncand;
+}
+
+__device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {  // (hi:lo) |= (hi:lo) << s, 0 < s < 64
+    const uint64_t nh = (hi << s) | (lo >> (64 - s)), nl = lo << s;
+    hi |= nh;
+    lo |= nl;
+}
+
+template <int U, int T>
+__device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane) {
+    using L = WL<U, T>;
+    uint32_t* rd = (uint32_t*)(lds + L::OFF_RD);
+    // hash phase views of R1
+    unsigned long long* hv = (unsigned long long*)(lds + L::OFF_R1);
+    unsigned int* haux = (unsigned int*)(lds + L::OFF_R1 + 8 * L::H);
+    // taxid phase views of R1
+    uint16_t* reg = (uint16_t*)(lds + L::OFF_R1);
+    uint16_t* cnt = reg + T;
+    uint16_t* leaf = cnt + T;
+    uint16_t* stamp = leaf + T;
+    uint16_t* dep = stamp + T;
+    uint16_t* ord = dep + T;
+    float* score = (float*)(ord + T);
+    unsigned int* hent = (unsigned int*)(score + T);
+    unsigned int* best = hent + L::TH;
+    // R2: k-mer phase, then distinct payloads + lineage scratch
+    unsigned long long* ukmer = (unsigned long long*)(lds + L::OFF_R2);
+    uint32_t* ubucket = (uint32_t*)(lds + L::OFF_R2 + 8 * U);
+    uint32_t* dpay = (uint32_t*)(lds + L::OFF_R2);
+    uint32_t* dmult = (uint32_t*)(lds + L::OFF_R2 + 4 * U);
+    LinEnt* lin = (LinEnt*)(lds + L::OFF_R2 + 8 * U);
+    uint32_t* upay = (uint32_t*)(lds + L::OFF_R3);
+
+    const DeviceTables& tb = A.tb;
+    const int k = tb.k;
+    const uint32_t* rec = A.words + A.rec_off[r];
+    const uint32_t len = rec[0];
+    lmat_read_result res;
+    res.status = LMAT_ST_NODBHITS; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = 0;
+    res.read_len = (int)len; res.log_avg = 0; res.stdev = 0; res.call_tid = 0; res.call_score = 0;
+    res.cand_off = 0; res.n_cand = 0; res.bin_sel = 0;
+    lmat_read_result* out = A.results + (r - A.result_base);
+    unsigned long long* tally_count = (unsigned long long*)A.counts;
+    double* tally_score = (double*)(tally_count + tb.n_ids);
+    unsigned long long* tally_nomatch = (unsigned long long*)(tally_score + tb.n_ids);
+
+    if ((int)len < k) {  // proc_line :1217-1223
+        if (lane == 0) { res.status = LMAT_ST_SHORT_LEN; *out = res; atomicAdd(&tally_nomatch[0], 1ull); }
+        return;
+    }
+    const uint32_t P = len - k + 1;
+    if (P > (uint32_t)U) {  // the host sizes U from the batch's longest read
+        if (lane == 0) { res.status = 255; *out = res; atomicOr(&A.cursor[1], (uint32_t)kErrReadTooLong); }
+        return;
+    }
+    // ---- packed record -> LDS (coalesced), zero tail so windows past the end are invalid
+    const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
+    for (uint32_t w = lane; w < (uint32_t)L::RD_WORDS; w += 64) rd[w] = w < nb + nm ? rec[1 + w] : 0u;
+    for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
+    WSYNC();
+    const uint32_t* codes = rd;
+    const uint32_t* vmask = rd + nb;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;  // k <= 20
+    const uint32_t wmask = (1u << k) - 1;
+
+    // canonical k-mer of the window starting at base p (read_label.cpp:992-1009).  Bases are
+    // packed little-endian, so the 2k-bit window w has base p in its low bits: the reference's
+    // "reverse" is ~w and its "forward" is the pair-reversal of w.
+    auto window = [&](uint32_t p, uint64_t& canon) -> bool {
+        const uint32_t mb = p >> 5, ms = p & 31;
+        const uint64_t m2 = ((uint64_t)vmask[mb + 1] << 32) | vmask[mb];
+        const bool ok = ((uint32_t)(m2 >> ms) & wmask) == wmask;
+        const uint32_t wb = (2 * p) >> 5, ws = (2 * p) & 31;
+        const uint64_t lo = ((uint64_t)codes[wb + 1] << 32) | codes[wb];
+        uint64_t w = ws ? ((lo >> ws) | ((uint64_t)codes[wb + 2] << (64 - ws))) : lo;
+        w &= kmask;
+        const uint64_t rev = (~w) & kmask;
+        uint64_t f = __builtin_bitreverse64(w);
+        f = ((f & 0x5555555555555555ull) << 1) | ((f >> 1) & 0x5555555555555555ull);
+        f >>= (64 - 2 * k);
+        canon = f < rev ? f : rev;
+        return ok;
+    };
+
+    // ---- K1 pass 1: valid k-mers, first-occurrence hash, GC accounting
+    int valid_kmers = 0, gc = 0, tot = 0;
+    uint64_t prevV = 0;
+    for (uint32_t p0 = 0; p0 < len; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        uint64_t km = 0;
+        const bool ok = (p < P) && window(p, km);
+        const uint64_t V = __ballot(ok);
+        valid_kmers += popc64(V);
+        if (ok) lds_min_insert(hv, L::H - 1, km, p);
+        // bases covered by at least one valid k-mer (read_label.cpp:987-1008): base b is covered
+        // iff some window start in [b-k+1, b] is valid
+        uint64_t lo = prevV, hi = V;
+        int span = 1;
+        while (span * 2 <= k) { spread_left(lo, hi, span); span *= 2; }
+        if (k - span > 0) spread_left(lo, hi, k - span);
+        bool isgc = false;
+        if (p < len) {
+            const uint32_t code = (codes[p >> 4] >> (2 * (p & 15))) & 3u;
+            isgc = code == 1 || code == 2;
+        }
+        const bool covered = (hi >> lane) & 1ull;
+        gc += popc64(__ballot(covered && isgc));
+        tot += popc64(hi);
+        prevV = V;
+    }
+    WSYNC();
+    res.valid_kmers = valid_kmers;
+    if (tot > 0) {  // :1205-1206
+        const float q = (float)gc / (float)tot;
+        const float gc_pcnt = (float)((double)q * 100.0);
+        res.bin_sel = (int)(gc_pcnt / 10.0f);
+    }
+    if (valid_kmers < A.prm.min_kmer) {  // proc_line :1232-1238
+        if (lane == 0) { res.status = LMAT_ST_SHORT_VALID; *out = res; atomicAdd(&tally_nomatch[0], 1ull); }
+        return;
+    }
+    // ---- K1 pass 2: compact first occurrences in position order
+    uint32_t nuniq = 0;
+    for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        uint64_t km = 0;
+        bool first = false;
+        if (p < P && window(p, km)) {
+            const uint32_t h = lds_find(hv, L::H - 1, km);
+            first = (uint32_t)(hv[h] & 0xFFFF) == p;
+        }
+        const uint64_t bm = __ballot(first);
+        if (first) {
+            const uint32_t rk = nuniq + popc64(bm & lt_mask(lane));
+            ukmer[rk] = km;
+            ubucket[rk] = bucket_of(km, tb.nbuckets);
+            upay[rk] = 0;
+        }
+        nuniq += popc64(bm);
+    }
+    WSYNC();
+    // ---- K2: probe.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets;
+    //      8 loads are issued back to back before the first is consumed.
+    {
+        const int g = lane >> 3, sub = lane & 7;
+        const uint64_t* __restrict__ slots = tb.slots;
+        for (uint32_t base = 0; base < nuniq; base += 64) {
+            unsigned long long sl[8];
+            uint32_t bk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t idx = base + i * 8 + g;
+                bk[i] = idx < nuniq ? ubucket[idx] : 0u;
+                sl[i] = idx < nuniq ? slots[(uint64_t)bk[i] * kSlotsPerBucket + sub] : 0ull;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t idx = base + i * 8 + g;
+                const bool act = idx < nuniq;
+                const uint64_t km = act ? ukmer[idx] : 0;
+                unsigned long long s = sl[i];
+                uint32_t b = bk[i];
+                bool pending = act;
+                while (__ballot(pending)) {
+                    const bool match = pending && s != 0 && (s >> kPayloadBits) == km;
+                    const bool empty = pending && s == 0;
+                    const uint64_t mm = __ballot(match), em = __ballot(empty);
+                    if (match) upay[idx] = (uint32_t)(s & kPayloadMask);
+                    const uint32_t gm = (uint32_t)(mm >> (g * 8)) & 0xFF, ge = (uint32_t)(em >> (g * 8)) & 0xFF;
+                    if (gm || ge) pending = false;
+                    if (pending) {  // bucket full, key absent: linear probe to the next bucket
+                        b = b + 1 == tb.nbuckets ? 0 : b + 1;
+                        s = slots[(uint64_t)b * kSlotsPerBucket + sub];
+                    }
+                }
+            }
+        }
+    }
+    WSYNC();
+    // ---- K3a: distinct payloads in first-occurrence order with multiplicities.  Identical payload
+    //      means identical taxid list, hence identical contribution at every such position.
+    for (int i = lane; i < L::H; i += 64) { hv[i] = kEmpty64; haux[i] = 0; }
+    WSYNC();
+    for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t pay = i < nuniq ? upay[i] : 0;
+        if (pay) {
+            const uint32_t h = lds_min_insert(hv, L::H - 1, pay, i);
+            atomicAdd(&haux[h], 1u);
+        }
+    }
+    WSYNC();
+    uint32_t ndist = 0;
+    for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // dpay/dmult overlay the (dead) k-mer arrays
+        const uint32_t i = i0 + lane;
+        const uint32_t pay = i < nuniq ? upay[i] : 0;
+        bool owner = false;
+        uint32_t mult = 0;
+        if (pay) {
+            const uint32_t h = lds_find(hv, L::H - 1, pay);
+            owner = (uint32_t)(hv[h] & 0xFFFF) == i;
+            mult = haux[h];
+        }
+        const uint64_t bm = __ballot(owner);
+        if (owner) {
+            const uint32_t rk = ndist + popc64(bm & lt_mask(lane));
+            dpay[rk] = pay;
+            dmult[rk] = mult;
+        }
+        ndist += popc64(bm);
+    }
+    WSYNC();
+    // ---- K3b: taxid tables (overlay the hash region)
+    for (int i = lane; i < L::TH; i += 64) { hent[i] = 0; best[i] = 0; }
+    WSYNC();
+    uint32_t nT = 0, cand = nuniq, fnd = 0;
+    bool overflow = false;
+    const uint16_t* __restrict__ arena = tb.arena;
+    // phase 1 registration (read_label.cpp:1104-1122): first-lookup position order, then the
+    // depth-sorted order inside a k-mer's kept list
+    for (uint32_t d = 0; d < ndist && !overflow; ++d) {
+        const uint32_t pay = dpay[d], m = dmult[d];
+        uint32_t n = 1, eoff = 0;
+        if (pay >= kListBase) {
+            eoff = 2 * (pay - kListBase);
+            n = arena[eoff + 1];
+            if (arena[eoff] & kListNegFirst) cand -= m;  // label_vec.first < 0 (quirk Q4)
+        }
+        if (n) fnd += m;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool act = j < n;
+            const uint32_t t = act ? (pay < kListBase ? pay : arena[eoff + kListHdr + j]) : 0;
+            uint32_t h = 0;
+            bool isnew = false;
+            if (act) { h = tid_find_or_claim(hent, L::TH - 1, t); isnew = (hent[h] >> 16) == 0xFFFFu; }
+            const uint64_t nm_ = __ballot(isnew);
+            const uint32_t newcnt = popc64(nm_);
+            if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
+            if (isnew) {
+                const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+                hent[h] = t | (s << 16);
+                reg[s] = (uint16_t)t; cnt[s] = 0; leaf[s] = 0; stamp[s] = 0xFFFF;
+            }
+            nT += newcnt;
+            WSYNC();
+            if (act) leaf[hent[h] >> 16] += (uint16_t)m;
+            WSYNC();
+        }
+    }
+    if (overflow) {
+        if (lane == 0) { res.status = 255; *out = res; atomicOr(&A.cursor[1], (uint32_t)kErrTidOverflow); }
+        return;
+    }
+    if (nT == 0) {  // taxid_lst empty: NoDbHits record, proc_line :1270-1277
+        if (lane == 0) { res.status = LMAT_ST_NODBHITS; *out = res; atomicAdd(&tally_nomatch[1], 1ull); }
+        return;
+    }
+    // representative strain per species (read_label.cpp:1144-1177): max leaf count, ties -> smallest taxid
+    const uint32_t nT1 = nT;
+    for (uint32_t s0 = 0; s0 < nT1; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        if (s < nT1) {
+            const uint32_t t = reg[s];
+            if (tb.flags[t] & kFlagStrain) {
+                const uint32_t sp = tb.species_of[t];
+                if (sp) {
+                    const uint32_t h = tid_find_or_claim(hent, L::TH - 1, sp);
+                    atomicMax(&best[h], ((uint32_t)leaf[s] << 16) | (0xFFFFu - t));
+                }
+            }
+        }
+    }
+    WSYNC();
+    // phase 2 (read_label.cpp:1178-1203 + 701-764): per-position sets = kept ids + ancestors of the
+    // eligible ones; positions ascending == distinct payloads in first-occurrence order
+    for (uint32_t d = 0; d < ndist && !overflow; ++d) {
+        const uint32_t pay = dpay[d], m = dmult[d];
+        uint32_t n = 1, eoff = 0, fl = 0;
+        if (pay >= kListBase) { eoff = 2 * (pay - kListBase); fl = arena[eoff]; n = arena[eoff + 1]; }
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {  // (a) the kept ids themselves
+            const uint32_t j = j0 + lane;
+            if (j < n) {
+                const uint32_t t = pay < kListBase ? pay : arena[eoff + kListHdr + j];
+                const uint32_t s = hent[tid_find(hent, L::TH - 1, t)] >> 16;
+                cnt[s] += (uint16_t)m;
+                stamp[s] = (uint16_t)d;
+            }
+        }
+        WSYNC();
+        if (fl & kListNegFirst) continue;  // closure only where first >= 0 (:1179)
+        for (uint32_t j = 0; j < n && !overflow; ++j) {  // (b) members ascending by taxid
+            const uint32_t u = pay < kListBase ? pay : arena[eoff + kListHdr + n + j];
+            bool eligible = !(tb.flags[u] & kFlagStrain);  // rank != "strain" (:1184)
+            if (!eligible) {
+                const uint32_t sp = tb.species_of[u];
+                if (sp) {
+                    const int h = tid_find(hent, L::TH - 1, sp);
+                    eligible = h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - u);
+                }
+            }
+            if (!eligible) continue;
+            const uint32_t plen = tb.path_len[u], poff = tb.path_off[u];
+            for (uint32_t c0 = 0; c0 < plen; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const bool act = c < plen;
+                const uint32_t a = act ? tb.paths[poff + c] : 0;
+                uint32_t h = 0;
+                bool unreg = false;
+                if (act) { h = tid_find_or_claim(hent, L::TH - 1, a); unreg = (hent[h] >> 16) == 0xFFFFu; }
+                const uint64_t nm_ = __ballot(unreg);
+                const uint32_t newcnt = popc64(nm_);
+                if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
+                if (unreg) {
+                    const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+                    hent[h] = a | (s << 16);
+                    reg[s] = (uint16_t)a; cnt[s] = 0; leaf[s] = 0; stamp[s] = 0xFFFF;
+                }
+                nT += newcnt;
+                WSYNC();
+                if (act) {
+                    const uint32_t s = hent[h] >> 16;
+                    if (stamp[s] != (uint16_t)d) { stamp[s] = (uint16_t)d; cnt[s] += (uint16_t)m; }
+                }
+                WSYNC();
+            }
+        }
+    }
+    if (overflow) {
+        if (lane == 0) { res.status = 255; *out = res; atomicOr(&A.cursor[1], (uint32_t)kErrTidOverflow); }
+        return;
+    }
+    for (uint32_t s = lane; s < nT; s += 64) dep[s] = tb.fdepth[reg[s]];
+    WSYNC();
+    cand &= 0xFFFF;  // uint16_t cand_kmer_cnt (:699)
+    // ---- construct_labels early exits (:727-733): nothing is written (quirk Q1), tallied NoDbHits
+    if ((int)fnd < A.prm.min_fnd_kmer || (int)cand < A.prm.min_kmer) {
+        if (lane == 0) {
+            res.status = LMAT_ST_SILENT;
+            res.cand_kmer_cnt = (uint16_t)cand;
+            *out = res;
+            atomicAdd(&tally_nomatch[1], 1ull);
+        }
+        return;
+    }
+    // ---- K4 on lane 0
+    if (lane == 0) {
+        uint32_t ncand = 0, call_idx = 0, coff = 0;
+        lmat_cand* cout_ = nullptr;
+        if (A.cands) {
+            const uint32_t reserve = A.prm.prn_all ? nT : (uint32_t)L::LIN;
+            coff = atomicAdd(&A.cursor[0], reserve);
+            if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = A.cands + coff;
+            else atomicOr(&A.cursor[1], (uint32_t)kErrCandOverflow);
+        }
+        decide_read<U, T>(A, res, reg, cnt, score, dep, ord, hent, lin, (int)nT, cand, cout_, &ncand, &call_idx,
+                          &A.cursor[1]);
+        res.cand_off = coff;
+        res.n_cand = ncand;
+        *out = res;
+        // tallies, proc_line :1241-1268
+        if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {
+            atomicAdd(&tally_nomatch[1], 1ull);
+        } else if (res.call_score >= A.prm.min_score) {
+            atomicAdd(&tally_count[call_idx], 1ull);
+            atomicAdd(&tally_score[call_idx], (double)res.call_score);
+        } else if (res.call_score < A.prm.min_score) {
+            atomicAdd(&tally_nomatch[2], 1ull);
+        }
+    }
+}
+
+template <int U, int T>
+__global__ __launch_bounds__(64) void classify_kernel(ClassifyArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    for (uint64_t it = blockIdx.x; it < A.count; it += gridDim.x) {
+        const uint64_t r = A.index ? (uint64_t)A.index[it] : A.first + it;
+        classify_one<U, T>(A, r, smem, lane);
+        WSYNC();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int grid_for(uint64_t n, int per_block, int cap) {
+    uint64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)cap) b = cap;
+    return (int)b;
+}
+
+void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t* rec_off, uint32_t* words, uint64_t n,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(n, 4, 8192)), dim3(256), 0, stream, bases, off, rec_off, words, n);
+}
+void launch_insert_pairs(uint64_t* slots, uint32_t nbuckets, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
+                         uint32_t* fail, hipStream_t stream) {
+    hipLaunchKernelGGL(insert_pairs_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, slots, nbuckets, kmers,
+                       payload, n, fail);
+}
+void launch_synth_db(uint64_t* slots, uint32_t nbuckets, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
+                     const uint16_t* strain_idx, const uint32_t* list_payload, uint32_t* fail,
+                     unsigned long long* inserted, hipStream_t stream) {
+    const uint64_t total = (uint64_t)n_species * (G - k + 1);
+    hipLaunchKernelGGL(synth_db_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, stream, slots, nbuckets, seed,
+                       n_species, S, G, k, strain_idx, list_payload, fail, inserted);
+}
+void launch_count_slots(const uint64_t* slots, uint64_t nslots, unsigned long long* out, hipStream_t stream) {
+    hipLaunchKernelGGL(count_slots_kernel, dim3(grid_for(nslots, 256, 16384)), dim3(256), 0, stream, slots, nslots, out);
+}
+void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t* lengths, uint32_t n_lengths, uint64_t n,
+                        uint64_t seed, uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G, hipStream_t stream) {
+    hipLaunchKernelGGL(synth_reads_kernel, dim3(grid_for(n, 4, 16384)), dim3(256), 0, stream, words, rec_off, lengths,
+                       n_lengths, n, seed, db_seed, n_species, S, G);
+}
+void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids,
+                   uint32_t stride, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tb, kmers, n, counts, tids,
+                       stride);
+}
+
+template <int U, int T>
+static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        constexpr int lds_bytes0 = WL<U, T>::BYTES;
+        hipFuncSetAttribute((const void*)classify_kernel<U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
+        attr_set = true;
+    }
+    // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
+    const int per_cu = 160 * 1024 / WL<U, T>::BYTES;
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * 2;
+    if ((uint64_t)grid > a.count) grid = (int)a.count;
+    if (grid < 1) grid = 1;
+    constexpr int lds_bytes = WL<U, T>::BYTES;
+    classify_kernel<U, T><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
+}
+
+int classify_max_read_len() { return 2048 + 19; }
+
+bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream) {
+    const int k = a.tb.k;
+    const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
+    if (P <= 256) {
+        if (tcap_class == 0) launch_classify_t<256, 128>(a, stream); else launch_classify_t<256, 1024>(a, stream);
+    } else if (P <= 512) {
+        if (tcap_class == 0) launch_classify_t<512, 128>(a, stream); else launch_classify_t<512, 1024>(a, stream);
+    } else if (P <= 2048) {
+        launch_classify_t<2048, 1024>(a, stream);
+    } else {
+        return false;
+    }
+    return true;
+}
+
+uint32_t synth_strain_base_host(uint64_t seed, uint32_t species, uint32_t strain_global, uint64_t pos) {
+    return synth_strain_base(seed, species, strain_global, pos);
+}
+
+}  // namespace lmat

@@ -1,0 +1,45 @@
+// kernels.hpp -- launch interface between the C-ABI host code and kernels.hip.
+#pragma once
+#include "lmat_internal.hpp"
+
+namespace lmat {
+
+struct ClassifyArgs {
+    DeviceTables tb;
+    KernelParams prm;
+    const uint32_t* words;     // packed read records
+    const uint64_t* rec_off;   // [n+1] word offsets
+    const uint32_t* index;     // optional explicit read list (re-runs), else first+i
+    uint64_t first, count;
+    uint64_t result_base;      // results[r - result_base]
+    lmat_read_result* results;
+    lmat_cand* cands;          // may be null (calls-only)
+    uint64_t cand_cap;
+    uint32_t* cursor;          // [0] candidate bump cursor, [1] error flags
+    void* counts;              // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
+    uint32_t phix_call_idx;    // internal index of 32630
+};
+
+enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8 };
+
+// launchers (all asynchronous on `stream`)
+void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t* rec_off, uint32_t* words, uint64_t n,
+                       hipStream_t stream);
+void launch_insert_pairs(uint64_t* slots, uint32_t nbuckets, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
+                         uint32_t* fail, hipStream_t stream);
+void launch_synth_db(uint64_t* slots, uint32_t nbuckets, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
+                     const uint16_t* strain_idx, const uint32_t* list_payload, uint32_t* fail,
+                     unsigned long long* inserted, hipStream_t stream);
+void launch_count_slots(const uint64_t* slots, uint64_t nslots, unsigned long long* out, hipStream_t stream);
+void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t* lengths, uint32_t n_lengths, uint64_t n,
+                        uint64_t seed, uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G, hipStream_t stream);
+void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids,
+                   uint32_t stride, hipStream_t stream);
+// tcap_class: 0 = fast (T=128), 1 = large (T=1024).  Returns false if max_len exceeds every U class.
+bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
+int classify_max_read_len();
+
+// host-callable copies of the synthetic genome functions (tests / oracle cross-checks)
+uint32_t synth_strain_base_host(uint64_t seed, uint32_t species, uint32_t strain_global, uint64_t pos);
+
+}  // namespace lmat

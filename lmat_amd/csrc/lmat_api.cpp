@@ -1,0 +1,723 @@
+// lmat_api.cpp -- C-ABI entry points (include/lmat_hip.h) over the HIP kernels.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "kernels.hpp"
+#include "outfmt.hpp"
+
+using namespace lmat;
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return set_err(ctx, LMAT_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+template <class T>
+static int dev_upload(lmat_ctx* c, T** dst, const std::vector<T>& src) {
+    if (*dst) { hipFree(*dst); *dst = nullptr; }
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(c, hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIPCHK(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LMAT_OK;
+}
+
+namespace lmat {
+int upload_taxonomy(lmat_ctx* c) {
+    HostTaxonomy& T = c->tax;
+    int rc;
+    if ((rc = dev_upload(c, &c->dev.tid32, T.tid32))) return rc;
+    if ((rc = dev_upload(c, &c->dev.fdepth, T.fdepth))) return rc;
+    if ((rc = dev_upload(c, &c->dev.flags, T.flags))) return rc;
+    if ((rc = dev_upload(c, &c->dev.species_of, T.species_of))) return rc;
+    if ((rc = dev_upload(c, &c->dev.path_off, T.path_off))) return rc;
+    if ((rc = dev_upload(c, &c->dev.path_len, T.path_len))) return rc;
+    if ((rc = dev_upload(c, &c->dev.paths, T.paths))) return rc;
+    if ((rc = dev_upload(c, &c->dev.conv, T.conv))) return rc;
+    c->dev.n_ids = T.n + 1;
+    // tallies: u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
+    if (c->d_counts) { hipFree(c->d_counts); c->d_counts = nullptr; }
+    c->counts_bytes = (uint64_t)c->dev.n_ids * 16 + 24;
+    HIPCHK(c, hipMalloc(&c->d_counts, c->counts_bytes));
+    HIPCHK(c, hipMemset(c->d_counts, 0, c->counts_bytes));
+    return LMAT_OK;
+}
+}  // namespace lmat
+
+static KernelParams kparams(const lmat_params& p) {
+    KernelParams k;
+    k.sdiff = p.sdiff; k.hbias = p.hbias; k.min_score = p.min_score;
+    k.min_kmer = p.min_kmer; k.min_fnd_kmer = p.min_fnd_kmer; k.prn_all = p.prn_all; k.screen_phix = p.screen_phix;
+    return k;
+}
+
+extern "C" {
+
+int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out) {
+    if (!out) return LMAT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return LMAT_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LMAT_E_DEVICE;
+    lmat_ctx* c = new lmat_ctx();
+    c->device = device;
+    lmat_params def = {1.0f, 3.0f, 0.0f, 35, 1, 0, 1};
+    c->params = params ? *params : def;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
+    if (hipMalloc((void**)&c->d_cursor, 16) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
+    hipMemset(c->d_cursor, 0, 16);
+    *out = c;
+    return LMAT_OK;
+}
+
+void lmat_ctx_destroy(lmat_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
+                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.conv, c->d_results, c->d_cands, c->d_cursor,
+                    c->d_counts, c->d_synth_strain_idx};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* lmat_last_error(const lmat_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int lmat_set_params(lmat_ctx* c, const lmat_params* p) {
+    if (!c || !p) return LMAT_E_ARG;
+    c->params = *p;
+    return LMAT_OK;
+}
+
+int lmat_taxonomy_load_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, const char* rank_fn,
+                             const char* idmap_fn, const char* plasmid_fn) {
+    if (!c) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    return load_taxonomy_files(c, tree_fn, depth_fn, rank_fn, idmap_fn, plasmid_fn);
+}
+
+// ---------------------------------------------------------------------------------- DB
+int lmat_db_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_bytes) {
+    if (!c) return LMAT_E_ARG;
+    if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
+    if (k < 1 || k > 20) return set_err(c, LMAT_E_ARG, "k must be in 1..20 (40-bit keys)");
+    c->builder = DbBuilder();
+    c->builder.k = k;
+    c->builder.table_bytes = table_bytes;
+    c->builder.open = true;
+    if (n_kmers_hint) { c->builder.kmers.reserve(n_kmers_hint); c->builder.payload.reserve(n_kmers_hint); }
+    c->db_ready = false;
+    return LMAT_OK;
+}
+
+// tax_histo binary: KmerFileMetaData header (src/kmerdb/KmerFileMetaData.cpp:44-94) then
+// u64 kmer | u16 n | n x u32 taxid, a u64 ~0 after every 1500th record
+// (src/tax_histo.cpp:257-281, src/kmerdb/SortedDb.cpp:159-167,236-243,717-722).
+int lmat_db_add_taxhisto(lmat_ctx* c, const char* fn) {
+    if (!c || !fn) return LMAT_E_ARG;
+    DbBuilder& B = c->builder;
+    if (!B.open) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
+    FILE* in = fopen(fn, "rb");
+    if (!in) return set_err(c, LMAT_E_IO, std::string("Error: unable to open kmer db [") + fn + "]");
+    fseek(in, 0, SEEK_END);
+    const long fsz = ftell(in);
+    fseek(in, 0, SEEK_SET);
+    uint32_t data_start, version, klen;
+    uint64_t kmer_count, test;
+    char loc;
+    bool ok = fread(&data_start, 4, 1, in) == 1 && fread(&kmer_count, 8, 1, in) == 1 && fread(&test, 8, 1, in) == 1 &&
+              fread(&version, 4, 1, in) == 1 && fread(&loc, 1, 1, in) == 1 && fread(&klen, 4, 1, in) == 1;
+    if (!ok || test != ~0ull) { fclose(in); return set_err(c, LMAT_E_IO, "kmer data file is invalid; should have read 64 1s, but didn't"); }
+    if (version != 999 || loc != 'N') { fclose(in); return set_err(c, LMAT_E_IO, "not a tax_histo file (version/location flag)"); }
+    if ((int)klen != B.k) { fclose(in); return set_err(c, LMAT_E_IO, "k-mer length of file differs from lmat_db_begin"); }
+    const HostTaxonomy& T = c->tax;
+    std::vector<uint16_t> raw;
+    int rc = LMAT_OK;
+    for (uint64_t i = 0; i < kmer_count; ++i) {
+        if (ftell(in) == fsz) break;
+        uint64_t kmer;
+        uint16_t n;
+        if (fread(&kmer, 8, 1, in) != 1 || fread(&n, 2, 1, in) != 1) { rc = set_err(c, LMAT_E_IO, "truncated tax_histo record"); break; }
+        if (B.last_kmer > 0 && kmer <= B.last_kmer) { rc = set_err(c, LMAT_E_IO, "Kmers arriving out of order."); break; }
+        if (kmer >> (2 * B.k)) { rc = set_err(c, LMAT_E_IO, "k-mer wider than 2k bits"); break; }
+        raw.resize(n);
+        bool plain = n == 1;
+        for (uint16_t j = 0; j < n; ++j) {
+            uint32_t tid;
+            if (fread(&tid, 4, 1, in) != 1) { rc = set_err(c, LMAT_E_IO, "truncated taxid list"); break; }
+            auto b = T.br.find(tid);
+            const uint16_t t16 = b == T.br.end() ? 0 : b->second;
+            if (t16 == 0 || t16 > T.br.size() + 1) {  // SortedDb.cpp:503-511,678-690
+                rc = set_err(c, LMAT_E_TAXONOMY, "bad read: " + std::to_string(tid) + " " + std::to_string(t16));
+                break;
+            }
+            raw[j] = t16;
+        }
+        if (rc) break;
+        uint32_t payload = 0;
+        if (plain) {
+            const uint32_t t32 = T.conv[raw[0]];
+            const bool special = t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
+            auto it = T.index_of.find(t32);
+            if (!special && it != T.index_of.end()) payload = it->second;
+        }
+        if (!payload) {
+            auto li = B.list_index.find(raw);
+            uint32_t idx;
+            if (li == B.list_index.end()) {
+                idx = (uint32_t)B.lists.size();
+                B.lists.push_back(raw);
+                B.list_index[raw] = idx;
+            } else idx = li->second;
+            payload = kListBase + idx;
+        }
+        B.kmers.push_back(kmer);
+        B.payload.push_back(payload);
+        if ((i + 1) % 1500 == 0) {
+            if (fread(&test, 8, 1, in) != 1 || test != ~0ull) { rc = set_err(c, LMAT_E_IO, "tax_histo sanity word missing"); break; }
+        }
+        B.last_kmer = kmer;
+    }
+    fclose(in);
+    return rc;
+}
+
+static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes) {
+    uint64_t nb;
+    if (table_bytes) nb = table_bytes / 64;
+    else nb = (uint64_t)((double)n_kmers / (0.8 * kSlotsPerBucket)) + 1;
+    if (nb < 16) nb = 16;
+    if (nb > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "hash table above 2^32 buckets");
+    if (nb * kSlotsPerBucket < n_kmers + n_kmers / 64)
+        return set_err(c, LMAT_E_CAPACITY, "table_bytes too small for the number of k-mers");
+    if (c->dev.slots) { hipFree(c->dev.slots); c->dev.slots = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&c->dev.slots, nb * 64));
+    HIPCHK(c, hipMemsetAsync(c->dev.slots, 0, nb * 64, c->stream));
+    c->dev.nbuckets = (uint32_t)nb;
+    return LMAT_OK;
+}
+
+int lmat_db_finalize(lmat_ctx* c) {
+    if (!c) return LMAT_E_ARG;
+    DbBuilder& B = c->builder;
+    if (!B.open) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
+    hipSetDevice(c->device);
+    // arena of distinct list records
+    std::vector<uint16_t> arena(2, 0);  // offset 0 reserved
+    std::vector<uint32_t> list_off(B.lists.size());
+    std::vector<uint16_t> rec;
+    for (size_t i = 0; i < B.lists.size(); ++i) {
+        if (!build_list_record(c, B.lists[i], rec)) return c->err.empty() ? LMAT_E_TAXONOMY : LMAT_E_TAXONOMY;
+        list_off[i] = (uint32_t)(arena.size() / 2);
+        arena.insert(arena.end(), rec.begin(), rec.end());
+    }
+    if (arena.size() / 2 + kListBase > kPayloadMask)
+        return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
+    for (size_t i = 0; i < B.payload.size(); ++i)
+        if (B.payload[i] >= kListBase) B.payload[i] = kListBase + list_off[B.payload[i] - kListBase];
+    int rc;
+    if ((rc = dev_upload(c, &c->dev.arena, arena))) return rc;
+    c->arena_words = arena.size();
+    const uint64_t n = B.kmers.size();
+    if ((rc = alloc_table(c, n, B.table_bytes))) return rc;
+    c->dev.k = B.k;
+    // upload pairs in chunks and insert
+    const uint64_t chunk = 1ull << 24;
+    uint64_t* d_k = nullptr;
+    uint32_t* d_p = nullptr;
+    uint32_t* d_fail = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_k, std::min(chunk, std::max<uint64_t>(n, 1)) * 8));
+    HIPCHK(c, hipMalloc((void**)&d_p, std::min(chunk, std::max<uint64_t>(n, 1)) * 4));
+    HIPCHK(c, hipMalloc((void**)&d_fail, 4));
+    HIPCHK(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
+    for (uint64_t s = 0; s < n; s += chunk) {
+        const uint64_t m = std::min(chunk, n - s);
+        HIPCHK(c, hipMemcpyAsync(d_k, B.kmers.data() + s, m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_p, B.payload.data() + s, m * 4, hipMemcpyHostToDevice, c->stream));
+        launch_insert_pairs(c->dev.slots, c->dev.nbuckets, d_k, d_p, m, d_fail, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    uint32_t fail = 0;
+    HIPCHK(c, hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost));
+    hipFree(d_k); hipFree(d_p); hipFree(d_fail);
+    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during insert");
+    c->n_kmers = n;
+    c->db_ready = true;
+    B = DbBuilder();
+    return LMAT_OK;
+}
+
+int lmat_db_kmer_length(const lmat_ctx* c) { return c ? c->dev.k : 0; }
+uint64_t lmat_db_size(const lmat_ctx* c) { return c ? c->n_kmers : 0; }
+uint64_t lmat_db_table_bytes(const lmat_ctx* c) { return c ? (uint64_t)c->dev.nbuckets * 64 : 0; }
+
+int lmat_db_lookup(lmat_ctx* c, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids, uint32_t stride) {
+    if (!c || !c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
+    if (!n) return LMAT_OK;
+    hipSetDevice(c->device);
+    uint64_t* d_k = nullptr;
+    uint32_t *d_c = nullptr, *d_t = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_k, n * 8));
+    HIPCHK(c, hipMalloc((void**)&d_c, n * 4));
+    HIPCHK(c, hipMalloc((void**)&d_t, std::max<uint64_t>(n * stride, 1) * 4));
+    HIPCHK(c, hipMemcpyAsync(d_k, kmers, n * 8, hipMemcpyHostToDevice, c->stream));
+    launch_lookup(c->dev, d_k, n, d_c, d_t, stride, c->stream);
+    HIPCHK(c, hipMemcpyAsync(counts, d_c, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (stride && tids) HIPCHK(c, hipMemcpyAsync(tids, d_t, n * stride * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_k); hipFree(d_c); hipFree(d_t);
+    return LMAT_OK;
+}
+
+// ---------------------------------------------------------------------------------- synthetic
+// Taxonomy of SURVEY 8(d): root(1) -> b0 superkingdoms -> .. -> species -> strains, 32-bit ids
+// 1000 + 7*dense, 16-bit map = ascending rank from 2.  Built in memory (no files).
+int lmat_synth_taxonomy(lmat_ctx* c, const uint32_t* br) {
+    if (!c || !br) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    static const char* ranks[] = {"no_rank", "superkingdom", "phylum", "family", "genus", "species", "strain"};
+    (void)ranks;
+    HostTaxonomy& T = c->tax;
+    T = HostTaxonomy();
+    std::vector<uint32_t> ids{1}, parent{1}, depth{0}, level_of{0};
+    std::vector<uint32_t> level{0};  // indices into ids
+    uint32_t dense = 0;
+    for (int lv = 0; lv < 6; ++lv) {
+        std::vector<uint32_t> nxt;
+        for (uint32_t p : level)
+            for (uint32_t j = 0; j < br[lv]; ++j) {
+                ++dense;
+                ids.push_back(1000 + 7 * dense);
+                parent.push_back(p);
+                depth.push_back(lv + 1);
+                level_of.push_back(lv + 1);
+                nxt.push_back((uint32_t)ids.size() - 1);
+            }
+        level = nxt;
+    }
+    if (ids.size() > 65535) return set_err(c, LMAT_E_CAPACITY, "synthetic taxonomy above 65535 nodes");
+    // ids are already ascending, so internal index = position + 1
+    T.n = (uint32_t)ids.size();
+    T.tid32.assign(T.n + 1, 0); T.fdepth.assign(T.n + 1, 0); T.flags.assign(T.n + 1, 0);
+    T.species_of.assign(T.n + 1, 0); T.path_off.assign(T.n + 1, 0); T.path_len.assign(T.n + 1, 0);
+    T.conv.assign(65536, 0);
+    for (uint32_t i = 0; i < T.n; ++i) {
+        const uint32_t ix = i + 1;
+        T.tid32[ix] = ids[i];
+        T.index_of[ids[i]] = (uint16_t)ix;
+        T.fdepth[ix] = (uint16_t)depth[i];
+        if (level_of[i] == 6) T.flags[ix] |= kFlagStrain;
+        const uint16_t t16 = (uint16_t)(i == 0 ? 1 : i + 1);
+        T.conv[t16] = ids[i];
+        T.br[ids[i]] = t16;
+        T.path_off[ix] = (uint32_t)T.paths.size();
+        uint32_t cur = i;
+        while (parent[cur] != cur) { cur = parent[cur]; T.paths.push_back((uint16_t)(cur + 1)); }
+        T.path_len[ix] = (uint16_t)(T.paths.size() - T.path_off[ix]);
+        if (level_of[i] == 6) T.species_of[ix] = (uint16_t)(parent[i] + 1);
+    }
+    T.loaded = true;
+    for (int i = 0; i < 6; ++i) c->synth_branching[i] = br[i];
+    c->synth_strains_per_species = br[5];
+    c->synth_n_species = (uint32_t)level.size() / br[5];
+    c->synth_strain_idx.clear();
+    c->synth_species_idx.clear();
+    for (uint32_t s : level) c->synth_strain_idx.push_back((uint16_t)(s + 1));
+    for (uint32_t sp = 0; sp < c->synth_n_species; ++sp)
+        c->synth_species_idx.push_back((uint16_t)(parent[level[sp * br[5]]] + 1));
+    return upload_taxonomy(c);
+}
+
+int lmat_synth_db_build(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t table_bytes) {
+    if (!c || !c->tax.loaded || !c->synth_n_species) return set_err(c, LMAT_E_ARG, "lmat_synth_taxonomy first");
+    if (k < 1 || k > 20 || G < (uint64_t)k) return set_err(c, LMAT_E_ARG, "bad k / genome length");
+    hipSetDevice(c->device);
+    const uint32_t S = c->synth_strains_per_species, NS = c->synth_n_species;
+    if (S > 8) return set_err(c, LMAT_E_ARG, "at most 8 strains per species");
+    // one list per (species, non-empty strain subset): owners + the species when >= 2 owners,
+    // i.e. what tax_histo's LCA closure yields (src/kmerdb/TaxTree.hpp:160-260)
+    std::vector<uint16_t> arena(2, 0), rec;
+    std::vector<uint32_t> list_payload((size_t)NS << S, 0);
+    const HostTaxonomy& T = c->tax;
+    for (uint32_t sp = 0; sp < NS; ++sp)
+        for (uint32_t mask = 1; mask < (1u << S); ++mask) {
+            std::vector<uint16_t> raw;
+            for (uint32_t s = 0; s < S; ++s)
+                if (mask & (1u << s)) raw.push_back(T.br.at(T.tid32[c->synth_strain_idx[sp * S + s]]));
+            if (raw.size() == 1) {
+                list_payload[((size_t)sp << S) + mask] = c->synth_strain_idx[sp * S + __builtin_ctz(mask)];
+                continue;
+            }
+            raw.push_back(T.br.at(T.tid32[c->synth_species_idx[sp]]));
+            if (!build_list_record(c, raw, rec)) return LMAT_E_TAXONOMY;
+            list_payload[((size_t)sp << S) + mask] = kListBase + (uint32_t)(arena.size() / 2);
+            arena.insert(arena.end(), rec.begin(), rec.end());
+        }
+    if (arena.size() / 2 + kListBase > kPayloadMask) return set_err(c, LMAT_E_CAPACITY, "arena too large");
+    int rc;
+    if ((rc = dev_upload(c, &c->dev.arena, arena))) return rc;
+    c->arena_words = arena.size();
+    uint32_t* d_lp = nullptr;
+    if ((rc = dev_upload(c, &d_lp, list_payload))) return rc;
+    if ((rc = dev_upload(c, &c->d_synth_strain_idx, c->synth_strain_idx))) return rc;
+    // expected distinct k-mers ~ species * positions * (1 + S * P(window mutated)); size the table from that
+    const double pm = 1.0 - std::pow(0.99, k);
+    const uint64_t est = (uint64_t)((double)NS * (double)(G - k + 1) * (1.0 + S * pm));
+    if ((rc = alloc_table(c, est, table_bytes))) return rc;
+    c->dev.k = k;
+    uint32_t* d_fail = nullptr;
+    unsigned long long* d_ins = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_fail, 4));
+    HIPCHK(c, hipMalloc((void**)&d_ins, 16));
+    HIPCHK(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_ins, 0, 16, c->stream));
+    launch_synth_db(c->dev.slots, c->dev.nbuckets, seed, NS, S, G, k, c->d_synth_strain_idx, d_lp, d_fail, d_ins, c->stream);
+    launch_count_slots(c->dev.slots, (uint64_t)c->dev.nbuckets * kSlotsPerBucket, d_ins + 1, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t fail = 0;
+    unsigned long long ins[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ins, d_ins, 16, hipMemcpyDeviceToHost));
+    hipFree(d_fail); hipFree(d_ins); hipFree(d_lp);
+    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during synthetic build");
+    c->n_kmers = ins[1];
+    c->synth_genome_len = G;
+    c->synth_seed = seed;
+    c->db_ready = true;
+    return LMAT_OK;
+}
+
+// ---------------------------------------------------------------------------------- reads
+static int reads_alloc(lmat_ctx* c, const std::vector<uint64_t>& rec_off, uint32_t max_len, lmat_reads** out) {
+    lmat_reads* r = new lmat_reads();
+    r->n = rec_off.size() - 1;
+    r->n_words = rec_off.back();
+    r->max_len = max_len;
+    if (hipMalloc((void**)&r->words, std::max<uint64_t>(r->n_words, 1) * 4 + 64) != hipSuccess ||
+        hipMalloc((void**)&r->rec_off, rec_off.size() * 8) != hipSuccess) {
+        if (r->words) hipFree(r->words);
+        delete r;
+        return set_err(c, LMAT_E_NOMEM, "out of device memory for reads");
+    }
+    hipMemcpyAsync(r->rec_off, rec_off.data(), rec_off.size() * 8, hipMemcpyHostToDevice, c->stream);
+    *out = r;
+    return LMAT_OK;
+}
+
+int lmat_reads_upload(lmat_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, lmat_reads** out) {
+    if (!c || !out || (n && (!bases || !off))) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    std::vector<uint64_t> rec_off(n + 1, 0);
+    uint32_t max_len = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t len = off[i + 1] - off[i];
+        if (len > 0x7FFFFFFF) return set_err(c, LMAT_E_ARG, "read too long");
+        max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+        rec_off[i + 1] = rec_off[i] + rec_words((uint32_t)len);
+    }
+    int rc = reads_alloc(c, rec_off, max_len, out);
+    if (rc) return rc;
+    if (!n) return LMAT_OK;
+    uint8_t* d_b = nullptr;
+    uint64_t* d_o = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_b, std::max<uint64_t>(off[n], 1)));
+    HIPCHK(c, hipMalloc((void**)&d_o, (n + 1) * 8));
+    HIPCHK(c, hipMemcpyAsync(d_b, bases, off[n], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_o, off, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    launch_pack_reads(d_b, d_o, (*out)->rec_off, (*out)->words, n, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_b); hipFree(d_o);
+    return LMAT_OK;
+}
+
+int lmat_reads_synth(lmat_ctx* c, uint64_t n, const uint32_t* lengths, uint32_t n_lengths, uint64_t seed, lmat_reads** out) {
+    if (!c || !out || !lengths || !n_lengths) return LMAT_E_ARG;
+    if (!c->db_ready || !c->synth_genome_len) return set_err(c, LMAT_E_ARG, "synthetic reads need lmat_synth_db_build");
+    hipSetDevice(c->device);
+    // the kernel picks lengths[(h>>48) % n_lengths]; offsets must match, so mirror that choice here
+    std::vector<uint64_t> rec_off(n + 1, 0);
+    uint32_t max_len = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint64_t h0 = splitmix(seed ^ (r * 0x9E3779B97F4A7C15ull));
+        const uint32_t len = lengths[(uint32_t)((h0 >> 48) % n_lengths)];
+        max_len = std::max(max_len, len);
+        rec_off[r + 1] = rec_off[r] + rec_words(len);
+    }
+    int rc = reads_alloc(c, rec_off, max_len, out);
+    if (rc) return rc;
+    uint32_t* d_len = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_len, n_lengths * 4));
+    HIPCHK(c, hipMemcpyAsync(d_len, lengths, n_lengths * 4, hipMemcpyHostToDevice, c->stream));
+    launch_synth_reads((*out)->words, (*out)->rec_off, d_len, n_lengths, n, seed, c->synth_seed, c->synth_n_species,
+                       c->synth_strains_per_species, c->synth_genome_len, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_len);
+    return LMAT_OK;
+}
+
+int lmat_reads_download_ascii(lmat_ctx* c, const lmat_reads* r, uint64_t first, uint64_t count, uint8_t* bases,
+                              uint64_t* off) {
+    if (!c || !r || first + count > r->n) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    std::vector<uint64_t> ro(count + 1);
+    HIPCHK(c, hipMemcpy(ro.data(), r->rec_off + first, (count + 1) * 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> w(ro[count] - ro[0]);
+    if (!w.empty()) HIPCHK(c, hipMemcpy(w.data(), r->words + ro[0], w.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t o = 0;
+    static const char A[4] = {'A', 'C', 'G', 'T'};
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t* rec = w.data() + (ro[i] - ro[0]);
+        const uint32_t len = rec[0], nb = (len + 15) / 16;
+        off[i] = o;
+        if (bases)
+            for (uint32_t p = 0; p < len; ++p) {
+                const bool valid = (rec[1 + nb + (p >> 5)] >> (p & 31)) & 1u;
+                bases[o + p] = valid ? A[(rec[1 + (p >> 4)] >> (2 * (p & 15))) & 3u] : 'N';
+            }
+        o += len;
+    }
+    off[count] = o;
+    return LMAT_OK;
+}
+
+uint64_t lmat_reads_count(const lmat_reads* r) { return r ? r->n : 0; }
+uint64_t lmat_reads_device_bytes(const lmat_reads* r) { return r ? r->n_words * 4 + (r->n + 1) * 8 : 0; }
+void lmat_reads_free(lmat_ctx* c, lmat_reads* r) {
+    if (!r) return;
+    if (c) hipSetDevice(c->device);
+    if (r->words) hipFree(r->words);
+    if (r->rec_off) hipFree(r->rec_off);
+    delete r;
+}
+
+// ---------------------------------------------------------------------------------- classify
+static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
+    if (count > c->results_cap) {
+        if (c->d_results) hipFree(c->d_results);
+        c->d_results = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_results, count * sizeof(lmat_read_result)));
+        c->results_cap = count;
+    }
+    if (cand_cap > c->cands_cap) {
+        if (c->d_cands) hipFree(c->d_cands);
+        c->d_cands = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_cands, cand_cap * sizeof(lmat_cand)));
+        c->cands_cap = cand_cap;
+    }
+    return LMAT_OK;
+}
+
+static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, bool want_cands,
+                              uint64_t cand_cap) {
+    ClassifyArgs a;
+    a.tb = c->dev;
+    a.prm = kparams(c->params);
+    a.words = reads->words;
+    a.rec_off = reads->rec_off;
+    a.index = nullptr;
+    a.first = first;
+    a.count = count;
+    a.result_base = first;
+    a.results = c->d_results;
+    a.cands = want_cands ? c->d_cands : nullptr;
+    a.cand_cap = cand_cap;
+    a.cursor = c->d_cursor;
+    a.counts = c->d_counts;
+    auto it = c->tax.index_of.find(32630);
+    a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
+    return a;
+}
+
+static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, bool want_cands,
+                        uint64_t cand_cap, bool timed) {
+    if (!c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
+    if (first + count > reads->n) return set_err(c, LMAT_E_ARG, "read range out of bounds");
+    if (count > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "batch above 2^32 reads");
+    hipSetDevice(c->device);
+    int rc = ensure_results(c, count, want_cands ? cand_cap : 0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+    ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        HIPCHK(c, hipEventCreate(&e0));
+        HIPCHK(c, hipEventCreate(&e1));
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+    }
+    if (!launch_classify(a, reads->max_len, 0, c->stream))
+        return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+    if (timed) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->pending_events.push_back(std::make_pair(e0, e1));
+    }
+    HIPCHK(c, hipGetLastError());
+    return LMAT_OK;
+}
+
+// re-run reads whose taxid table overflowed the fast kernel's capacity with the large-capacity kernel
+static int rerun_overflow(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, bool want_cands,
+                          uint64_t cand_cap, std::vector<lmat_read_result>& host) {
+    std::vector<uint32_t> idx;
+    for (uint64_t i = 0; i < count; ++i)
+        if (host[i].status == 255) idx.push_back((uint32_t)(first + i));
+    if (idx.empty()) return LMAT_OK;
+    if (first + count > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "overflow re-run needs read indices below 2^32");
+    uint32_t* d_idx = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_idx, idx.size() * 4));
+    HIPCHK(c, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    uint32_t zero = 0;
+    HIPCHK(c, hipMemcpyAsync(c->d_cursor + 1, &zero, 4, hipMemcpyHostToDevice, c->stream));
+    ClassifyArgs a = make_args(c, reads, first, idx.size(), want_cands, cand_cap);
+    a.index = d_idx;
+    a.result_base = first;
+    launch_classify(a, reads->max_len, 1, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_idx);
+    uint32_t cur[2];
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read registers more than 1024 taxids");
+    if (cur[1] & kErrCandOverflow) return LMAT_E_CAPACITY;
+    for (uint32_t r : idx)
+        HIPCHK(c, hipMemcpy(&host[r - first], c->d_results + (r - first), sizeof(lmat_read_result), hipMemcpyDeviceToHost));
+    return LMAT_OK;
+}
+
+int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, lmat_read_result* results,
+                  lmat_cand* cands, uint64_t cand_cap, uint64_t* n_cands) {
+    if (!c || !reads || (count && !results)) return LMAT_E_ARG;
+    if (!count) { if (n_cands) *n_cands = 0; return LMAT_OK; }
+    const bool want = cands != nullptr && cand_cap > 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc = run_classify(c, reads, first, count, want, cand_cap, false);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        uint32_t cur[2];
+        HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+        if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
+        if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
+        if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
+        std::vector<lmat_read_result> host(count);
+        HIPCHK(c, hipMemcpy(host.data(), c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
+        if (cur[1] & kErrTidOverflow) {
+            rc = rerun_overflow(c, reads, first, count, want, cand_cap, host);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+        }
+        memcpy(results, host.data(), count * sizeof(lmat_read_result));
+        if (want) {
+            const uint64_t used = std::min<uint64_t>(cur[0], cand_cap);
+            if (used) HIPCHK(c, hipMemcpy(cands, c->d_cands, used * sizeof(lmat_cand), hipMemcpyDeviceToHost));
+            if (n_cands) *n_cands = used;
+        } else if (n_cands) *n_cands = 0;
+        return LMAT_OK;
+    }
+    return LMAT_OK;
+}
+
+int lmat_classify_async(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count) {
+    if (!c || !reads) return LMAT_E_ARG;
+    if (!count) return LMAT_OK;
+    return run_classify(c, reads, first, count, false, 0, true);
+}
+
+int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
+    if (!c) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& e : c->pending_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { c->kernel_ms_total += ms; c->kernel_launches++; }
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    c->pending_events.clear();
+    if (kernel_ms_total) *kernel_ms_total = c->kernel_ms_total;
+    if (kernel_launches) *kernel_launches = c->kernel_launches;
+    c->kernel_ms_total = 0;
+    c->kernel_launches = 0;
+    uint32_t cur[2];
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
+    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "taxid table overflow in async classify (use lmat_classify)");
+    return LMAT_OK;
+}
+
+int lmat_results_fetch(lmat_ctx* c, uint64_t first, uint64_t count, lmat_read_result* results) {
+    if (!c || !results || first + count > c->results_cap) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpy(results, c->d_results + first, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
+    return LMAT_OK;
+}
+
+// ---------------------------------------------------------------------------------- tallies
+int lmat_counts_reset(lmat_ctx* c) {
+    if (!c || !c->d_counts) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->counts_bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LMAT_OK;
+}
+int lmat_counts_layout(const lmat_ctx* c, uint32_t* n_ids, uint64_t* bytes) {
+    if (!c) return LMAT_E_ARG;
+    if (n_ids) *n_ids = c->dev.n_ids;
+    if (bytes) *bytes = c->counts_bytes;
+    return LMAT_OK;
+}
+void* lmat_counts_device_ptr(lmat_ctx* c) { return c ? c->d_counts : nullptr; }
+
+int lmat_counts_get(lmat_ctx* c, uint32_t* tid32, uint64_t* count, double* score, uint32_t cap, uint32_t* n_nonzero,
+                    uint64_t nomatch3[3]) {
+    if (!c || !c->d_counts) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned char> buf(c->counts_bytes);
+    HIPCHK(c, hipMemcpy(buf.data(), c->d_counts, c->counts_bytes, hipMemcpyDeviceToHost));
+    const uint32_t n = c->dev.n_ids;
+    const uint64_t* cn = (const uint64_t*)buf.data();
+    const double* sc = (const double*)(cn + n);
+    const uint64_t* nm = (const uint64_t*)(sc + n);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (cn[i]) {
+            if (k < cap) {
+                if (tid32) tid32[k] = c->tax.tid32[i];
+                if (count) count[k] = cn[i];
+                if (score) score[k] = sc[i];
+            }
+            ++k;
+        }
+    if (n_nonzero) *n_nonzero = k;
+    if (nomatch3) { nomatch3[0] = nm[0]; nomatch3[1] = nm[1]; nomatch3[2] = nm[2]; }
+    return LMAT_OK;
+}
+
+int64_t lmat_format_out(const lmat_ctx* c, const lmat_read_result* results, uint64_t n, const lmat_cand* cands,
+                        const uint8_t* bases, const uint64_t* off, int prn_read, uint64_t first_index, char* buf,
+                        uint64_t cap) {
+    if (!c || (n && !results)) return LMAT_E_ARG;
+    std::string s;
+    for (uint64_t i = 0; i < n; ++i) {
+        s += 'r';
+        put_int(s, (long long)(first_index + i));
+        s += '\t';
+        if (prn_read && bases && off) s.append((const char*)bases + off[i], off[i + 1] - off[i]);
+        else s += 'X';
+        s += '\t';
+        format_call(s, c->params, c->dev.k, results[i], cands);
+    }
+    if (buf && cap) {
+        const uint64_t m = std::min<uint64_t>(s.size(), cap - 1);
+        memcpy(buf, s.data(), m);
+        buf[m] = 0;
+    }
+    return (int64_t)s.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// lmat_common.hpp -- layouts and small pure functions shared by host and device code.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LM_HD __host__ __device__ __forceinline__
+#else
+#define LM_HD inline
+#endif
+
+namespace lmat {
+
+// ---- device hash of the k-mer database -------------------------------------------------
+// slot (u64) = canonical k-mer (40 bits for k<=20) << 24 | payload (24 bits); 0 = empty.
+// payload 1..65535          : plain singleton, value = internal taxid index
+// payload 65536 + o         : taxid-list record at arena[2*o] (arena in u16 units)
+// bucket = 8 slots = 64 B = one HBM sector read by 8 lanes; linear probing over buckets.
+static const int kPayloadBits = 24;
+static const uint32_t kPayloadMask = (1u << kPayloadBits) - 1;
+static const uint32_t kListBase = 65536;
+static const int kSlotsPerBucket = 8;
+
+// list record in the arena (u16 units, record starts 4-byte aligned):
+//   [0] flags  bit0: raw count >= 32768 (label_vec.first goes negative, read_label.cpp:49,1045)
+//   [1] n_kept [2] n_raw
+//   [3 .. 3+n_kept)            kept ids, registration order (depth-sorted leaf-most set)
+//   [3+n_kept .. 3+2*n_kept)   kept ids ascending by 32-bit taxid
+//   [3+2*n_kept .. +n_raw)     raw list as stored in the DB (16-bit DB ids), for lookups
+static const int kListHdr = 3;
+static const uint16_t kListNegFirst = 1;
+
+// per-taxid flags (internal index space)
+static const uint8_t kFlagStrain = 1;   // rank file says "strain"  (read_label.cpp:1150,1184)
+static const uint8_t kFlagHuman = 2;    // isHuman (tid_checks.hpp:15-28)
+static const uint8_t kFlagPhiX = 4;     // isPhiX (tid_checks.hpp:13)
+static const uint8_t kFlagPlasmid = 8;  // isPlasmid (read_label.cpp:69)
+
+LM_HD uint64_t mix64(uint64_t x) {  // murmur3 finaliser: k-mers of one genome overlap heavily
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+LM_HD uint32_t bucket_of(uint64_t kmer, uint32_t nbuckets) {
+    uint64_t h = mix64(kmer);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__umul64hi(h, (uint64_t)nbuckets);
+#else
+    return (uint32_t)(((unsigned __int128)h * nbuckets) >> 64);
+#endif
+}
+
+// ---- packed read record (4-byte words) ---------------------------------------------------
+//   word 0: length in bases; then ceil(len/16) words of 2-bit codes (base j at bits 2*(j%16)),
+//   then ceil(len/32) words of validity bits (1 = ACGT).
+LM_HD uint32_t rec_words(uint32_t len) { return 1 + (len + 15) / 16 + (len + 31) / 32; }
+
+// ---- counter-based PRNG for the synthetic genomes / reads --------------------------------
+LM_HD uint64_t splitmix(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+
+// ---- libstdc++ std::sort, restated ---------------------------------------------------------
+// read_label sorts candidates with comparators that are not strict weak orders
+// (TCmp, read_label.cpp:475-485) and relies on whatever libstdc++'s introsort does
+// with ties, so the device needs the same algorithm, not just "a sort": insertion
+// sort for n <= 16 (stable), median-of-3 quicksort + final insertion sort above,
+// heapsort when the depth limit 2*floor(log2 n) is exhausted.  Works on any
+// random-access array T with cmp(a,b).  Unguarded scans are clamped to the array:
+// the reference would run out of bounds there (undefined behaviour).
+template <class T, class Cmp>
+LM_HD void ss_unguarded_linear_insert(T* first, int last, Cmp& cmp) {
+    T val = first[last];
+    int next = last - 1;
+    while (next >= 0 && cmp(val, first[next])) {
+        first[last] = first[next];
+        last = next;
+        --next;
+    }
+    first[last] = val;
+}
+template <class T, class Cmp>
+LM_HD void ss_insertion_sort(T* a, int first, int last, Cmp& cmp) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (cmp(a[i], a[first])) {
+            T val = a[i];
+            for (int j = i; j > first; --j) a[j] = a[j - 1];
+            a[first] = val;
+        } else {
+            // unguarded within [first, i]: a[first] stops the scan in the reference
+            T val = a[i];
+            int lastp = i, next = i - 1;
+            while (next >= first && cmp(val, a[next])) {
+                a[lastp] = a[next];
+                lastp = next;
+                --next;
+            }
+            a[lastp] = val;
+        }
+    }
+}
+template <class T, class Cmp>
+LM_HD void ss_adjust_heap(T* a, int first, int hole, int len, T value, Cmp& cmp) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (cmp(a[first + child], a[first + child - 1])) child--;
+        a[first + hole] = a[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[first + hole] = a[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && cmp(a[first + parent], value)) {
+        a[first + hole] = a[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[first + hole] = value;
+}
+template <class T, class Cmp>
+LM_HD void ss_heapsort(T* a, int first, int last, Cmp& cmp) {
+    const int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            T v = a[first + parent];
+            ss_adjust_heap(a, first, parent, len, v, cmp);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (int l = last; l - first > 1;) {
+        --l;
+        T v = a[l];
+        a[l] = a[first];
+        ss_adjust_heap(a, first, 0, l - first, v, cmp);
+    }
+}
+template <class T, class Cmp>
+LM_HD void ss_sort(T* a, int n, Cmp cmp) {
+    if (n <= 0) return;
+    // introsort loop, recursion on the right part made explicit with a small stack
+    int stack_first[64], stack_last[64], stack_depth[64];
+    int sp = 0;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+        while (last - first > 16) {
+            if (depth == 0) {
+                ss_heapsort(a, first, last, cmp);
+                break;
+            }
+            --depth;
+            // median of (first+1, mid, last-1) moved to first
+            int mid = first + (last - first) / 2;
+            int ia = first + 1, ib = mid, ic = last - 1, r = first;
+            int pick;
+            if (cmp(a[ia], a[ib])) {
+                if (cmp(a[ib], a[ic])) pick = ib;
+                else if (cmp(a[ia], a[ic])) pick = ic;
+                else pick = ia;
+            } else if (cmp(a[ia], a[ic])) pick = ia;
+            else if (cmp(a[ib], a[ic])) pick = ic;
+            else pick = ib;
+            { T t = a[r]; a[r] = a[pick]; a[pick] = t; }
+            // unguarded partition of [first+1, last) around a[first]
+            int lo = first + 1, hi = last;
+            while (true) {
+                while (lo < last && cmp(a[lo], a[first])) ++lo;
+                --hi;
+                while (hi > first && cmp(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                T t = a[lo]; a[lo] = a[hi]; a[hi] = t;
+                ++lo;
+            }
+            const int cut = lo;
+            // reference recurses on [cut,last) first, then loops on [first,cut)
+            // (order of processing disjoint ranges does not change the result)
+            if (sp < 64) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
+            last = cut;
+        }
+    }
+    if (n > 16) {
+        ss_insertion_sort(a, 0, 16, cmp);
+        for (int i = 16; i < n; ++i) ss_unguarded_linear_insert(a, i, cmp);
+    } else {
+        ss_insertion_sort(a, 0, n, cmp);
+    }
+}
+
+}  // namespace lmat

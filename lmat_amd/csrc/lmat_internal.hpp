@@ -1,0 +1,114 @@
+// lmat_internal.hpp -- context and host-side tables of the engine (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#include "../../include/lmat_hip.h"
+#include "lmat_common.hpp"
+
+namespace lmat {
+
+// Taxonomy in the engine's internal index space: index 1..n in ascending 32-bit
+// taxid order (so "ascending tid" loops of the reference become ascending index),
+// 0 = none.  Covers every taxid the 16-bit map can produce plus all their ancestors.
+struct HostTaxonomy {
+    uint32_t n = 0;
+    std::vector<uint32_t> tid32;      // [n+1]
+    std::vector<uint16_t> fdepth;     // [n+1] depth from the -e file (read_label.cpp:1579-1582)
+    std::vector<uint8_t> flags;       // [n+1] kFlag*
+    std::vector<uint16_t> species_of; // [n+1] for strain-ranked ids: first ancestor ranked "species"
+    std::vector<uint32_t> path_off;   // [n+1] into paths
+    std::vector<uint16_t> path_len;   // [n+1] number of ancestors (tree depth)
+    std::vector<uint16_t> paths;      // ancestors parent..root as internal indices (TaxTree.hpp:60-91)
+    std::unordered_map<uint32_t, uint16_t> index_of;  // tid32 -> internal
+    std::unordered_map<uint32_t, uint16_t> br;        // 32 -> 16 (make_db_table.cpp:259-273)
+    std::vector<uint32_t> conv;                       // [65536] 16 -> 32 (read_label.cpp:1593-1598), 0 = unmapped
+    uint16_t human_idx = 0;                           // internal index of 9606
+    bool loaded = false;
+};
+
+struct DeviceTables {
+    uint64_t* slots = nullptr;
+    uint32_t nbuckets = 0;
+    uint16_t* arena = nullptr;
+    uint32_t* tid32 = nullptr;
+    uint16_t* fdepth = nullptr;
+    uint8_t* flags = nullptr;
+    uint16_t* species_of = nullptr;
+    uint32_t* path_off = nullptr;
+    uint16_t* path_len = nullptr;
+    uint16_t* paths = nullptr;
+    uint32_t* conv = nullptr;  // [65536] 16 -> 32, lookup API only
+    uint32_t n_ids = 0;
+    int k = 0;
+};
+
+struct KernelParams {
+    float sdiff, hbias, min_score;
+    int min_kmer, min_fnd_kmer, prn_all, screen_phix;
+};
+
+struct DbBuilder {
+    int k = 0;
+    uint64_t table_bytes = 0;
+    std::vector<uint64_t> kmers;
+    std::vector<uint32_t> payload;  // provisional: < kListBase = singleton internal idx, else kListBase + list number
+    std::vector<std::vector<uint16_t>> lists;  // distinct raw lists (16-bit DB ids, stored order)
+    std::map<std::vector<uint16_t>, uint32_t> list_index;
+    uint64_t last_kmer = 0;
+    bool open = false;
+};
+
+}  // namespace lmat
+
+struct lmat_reads {
+    uint32_t* words = nullptr;    // device: packed records
+    uint64_t* rec_off = nullptr;  // device: [n+1] word offsets
+    uint64_t n = 0;
+    uint64_t n_words = 0;
+    uint32_t max_len = 0;
+};
+
+struct lmat_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    lmat_params params;
+    std::string err;
+    lmat::HostTaxonomy tax;
+    lmat::DeviceTables dev;
+    lmat::DbBuilder builder;
+    uint64_t n_kmers = 0;
+    uint64_t arena_words = 0;  // u16 units
+    bool db_ready = false;
+    // synthetic generator state
+    uint32_t synth_branching[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t synth_n_species = 0, synth_strains_per_species = 0;
+    uint64_t synth_genome_len = 0, synth_seed = 0;
+    std::vector<uint16_t> synth_strain_idx;   // [species*S + s] internal index
+    std::vector<uint16_t> synth_species_idx;  // [species]
+    uint16_t* d_synth_strain_idx = nullptr;
+    // results / tallies on device
+    lmat_read_result* d_results = nullptr;
+    uint64_t results_cap = 0;
+    lmat_cand* d_cands = nullptr;
+    uint64_t cands_cap = 0;
+    uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags
+    void* d_counts = nullptr;      // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
+    uint64_t counts_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    float kernel_ms_total = 0;
+    uint64_t kernel_launches = 0;
+};
+
+namespace lmat {
+int set_err(lmat_ctx* c, int code, const std::string& msg);
+int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, const char* rank_fn,
+                        const char* idmap_fn, const char* plasmid_fn);
+int upload_taxonomy(lmat_ctx* c);
+// compute the arena record of one raw list; returns false (err set) on invalid ids
+bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec);
+}  // namespace lmat

@@ -1,0 +1,244 @@
+// taxonomy.cpp -- loads the reference's taxonomy inputs and flattens them into the
+// dense tables the kernels use.
+//
+// Replaces, for the classification path only:
+//   TaxTree<uint32_t>(file) + TaxNode::read      src/kmerdb/TaxTree.hpp:24-57, TaxNode.hpp:131-147
+//   TaxTree::getPathToRoot                        src/kmerdb/TaxTree.hpp:60-91
+//   depth map / gRank_table / conv_map loading    src/read_label.cpp:1560-1602
+//   isHuman / isPhiX / isPlasmid / badGenomes     include/tid_checks.hpp:13-28, read_label.cpp:69,82-104
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include "lmat_internal.hpp"
+
+namespace lmat {
+
+int set_err(lmat_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+static bool is_human32(uint32_t t) { return t == 9606 || t == 63221 || t == 741158; }
+static bool is_phix32(uint32_t t) { return t == 374840 || t == 10847 || t == 32630; }
+
+int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, const char* rank_fn,
+                        const char* idmap_fn, const char* plasmid_fn) {
+    HostTaxonomy& T = c->tax;
+    T = HostTaxonomy();
+    if (!tree_fn || !depth_fn || !idmap_fn) return set_err(c, LMAT_E_ARG, "tree, depth and 32->16 map files are required");
+
+    // --- tree: two comment lines, one count line, then "id nchild child.. parent" / name pairs
+    std::unordered_map<uint32_t, uint32_t> parent;
+    {
+        std::ifstream in(tree_fn);
+        if (!in.is_open()) return set_err(c, LMAT_E_IO, std::string("failed to open ") + tree_fn + " for reading");
+        std::string line;
+        std::getline(in, line);
+        std::getline(in, line);
+        std::getline(in, line);  // count (ignored, as upstream)
+        while (std::getline(in, line)) {
+            std::istringstream is(line);
+            std::vector<uint32_t> tok;
+            uint64_t v;
+            while (is >> v) tok.push_back((uint32_t)v);
+            std::string name;
+            std::getline(in, name);
+            if (tok.size() < 3) {
+                if (tok.empty()) continue;  // tolerate a trailing blank line
+                return set_err(c, LMAT_E_IO, "malformed taxonomy node line: " + line);
+            }
+            parent[tok[0]] = tok.back();
+        }
+    }
+    // --- depth file
+    std::unordered_map<uint32_t, uint32_t> fdepth;
+    {
+        std::ifstream in(depth_fn);
+        if (!in) return set_err(c, LMAT_E_IO, std::string("ERROR! Unable to open: ") + depth_fn);
+        uint32_t t, d;
+        while (in >> t >> d) fdepth[t] = d;
+    }
+    // --- rank file: first entry per taxid wins (std::map::insert)
+    std::unordered_map<uint32_t, std::string> rank;
+    if (rank_fn && *rank_fn) {
+        std::ifstream in(rank_fn);
+        if (!in) return set_err(c, LMAT_E_IO, std::string("cannot open rank file ") + rank_fn);
+        uint32_t t;
+        std::string r;
+        while (in >> t >> r) rank.insert(std::make_pair(t, r));
+    }
+    // --- 32 -> 16 map; later lines overwrite (operator[])
+    T.conv.assign(65536, 0);
+    {
+        FILE* f = fopen(idmap_fn, "r");
+        if (!f) return set_err(c, LMAT_E_IO, std::string("ERROR! Unable to read 16-bit map file:") + idmap_fn);
+        int src;
+        short dest;
+        while (fscanf(f, "%d%hd", &src, &dest) > 0) {
+            T.conv[(uint16_t)dest] = (uint32_t)src;
+            T.br[(uint32_t)src] = (uint16_t)dest;
+        }
+        fclose(f);
+    }
+    std::unordered_set<uint32_t> low_plasmid;
+    if (plasmid_fn && *plasmid_fn) {
+        std::ifstream in(plasmid_fn);
+        if (!in) return set_err(c, LMAT_E_IO, std::string("Unexpected reading error (plasmids): ") + plasmid_fn);
+        uint32_t p;
+        while (in >> p) low_plasmid.insert(p);
+    }
+
+    // --- internal index space: map targets, 9606 when any human id is mapped, all ancestors
+    std::unordered_set<uint32_t> S;
+    bool any_human = false;
+    for (uint32_t t16 = 0; t16 < 65536; ++t16) {
+        uint32_t t = T.conv[t16];
+        if (t) {
+            S.insert(t);
+            if (is_human32(t)) any_human = true;
+        }
+    }
+    if (any_human) S.insert(9606);
+    // the PhiX short-circuit reports ART_SEQ_TID 32630 (read_label.cpp:842): give it a tally slot
+    for (uint32_t t16 = 0; t16 < 65536; ++t16)
+        if (T.conv[t16] && is_phix32(T.conv[t16])) { S.insert(32630); break; }
+    std::vector<uint32_t> work(S.begin(), S.end());
+    for (size_t i = 0; i < work.size(); ++i) {
+        uint32_t cur = work[i];
+        int guard = 0;
+        while (true) {
+            auto it = parent.find(cur);
+            if (it == parent.end()) {
+                if (cur != work[i])
+                    return set_err(c, LMAT_E_TAXONOMY, "failed to find parent TaxNode " + std::to_string(cur) +
+                                                           " above taxid " + std::to_string(work[i]));
+                break;  // taxid itself not in tree: empty path, as TaxTree::getPathToRoot
+            }
+            if (it->second == cur) break;
+            cur = it->second;
+            if (S.insert(cur).second) work.push_back(cur);
+            if (++guard > 10000) return set_err(c, LMAT_E_TAXONOMY, "cycle in taxonomy above " + std::to_string(work[i]));
+        }
+    }
+    if (S.size() > 65535)
+        return set_err(c, LMAT_E_CAPACITY, "taxonomy closure has " + std::to_string(S.size()) + " ids; engine limit is 65535");
+    std::vector<uint32_t> ids(S.begin(), S.end());
+    std::sort(ids.begin(), ids.end());
+    T.n = (uint32_t)ids.size();
+    T.tid32.assign(T.n + 1, 0);
+    T.fdepth.assign(T.n + 1, 0);
+    T.flags.assign(T.n + 1, 0);
+    T.species_of.assign(T.n + 1, 0);
+    T.path_off.assign(T.n + 1, 0);
+    T.path_len.assign(T.n + 1, 0);
+    for (uint32_t i = 0; i < T.n; ++i) {
+        T.tid32[i + 1] = ids[i];
+        T.index_of[ids[i]] = (uint16_t)(i + 1);
+    }
+    for (uint32_t i = 1; i <= T.n; ++i) {
+        const uint32_t t = T.tid32[i];
+        auto d = fdepth.find(t);
+        T.fdepth[i] = d == fdepth.end() ? 0 : (uint16_t)std::min<uint32_t>(d->second, 65535);
+        uint8_t f = 0;
+        auto r = rank.find(t);
+        if (r != rank.end() && r->second == "strain") f |= kFlagStrain;
+        if (is_human32(t)) f |= kFlagHuman;
+        if (is_phix32(t)) f |= kFlagPhiX;
+        if ((t >= 10000000 && t < 11000000) || low_plasmid.count(t)) f |= kFlagPlasmid;
+        T.flags[i] = f;
+        // path to root
+        T.path_off[i] = (uint32_t)T.paths.size();
+        uint32_t cur = t;
+        auto it = parent.find(cur);
+        if (it != parent.end()) {
+            while (it->second != cur) {
+                cur = it->second;
+                T.paths.push_back(T.index_of[cur]);
+                it = parent.find(cur);
+            }
+        }
+        size_t len = T.paths.size() - T.path_off[i];
+        if (len > 65535) return set_err(c, LMAT_E_TAXONOMY, "taxonomy too deep");
+        T.path_len[i] = (uint16_t)len;
+    }
+    // species_of: first ancestor whose rank is "species" (read_label.cpp:1154-1163)
+    for (uint32_t i = 1; i <= T.n; ++i) {
+        if (!(T.flags[i] & kFlagStrain)) continue;
+        for (uint32_t p = 0; p < T.path_len[i]; ++p) {
+            uint16_t a = T.paths[T.path_off[i] + p];
+            auto r = rank.find(T.tid32[a]);
+            if (r != rank.end() && r->second == "species") {
+                T.species_of[i] = a;
+                break;
+            }
+        }
+    }
+    auto h = T.index_of.find(9606);
+    T.human_idx = h == T.index_of.end() ? 0 : h->second;
+    T.loaded = true;
+    return upload_taxonomy(c);
+}
+
+// One raw DB list -> arena record.  Restates the per-k-mer part of retrieve_kmer_labels
+// (src/read_label.cpp:1028-1134): 16->32 conversion, human folding, ignored ids, int16
+// store of the raw count, std::sort by depth descending, leaf-most filter.  It is a pure
+// function of the list, so it is evaluated once per distinct list at DB build time.
+bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec) {
+    const HostTaxonomy& T = c->tax;
+    std::vector<uint16_t> obs;
+    bool seen_human = false, neg_first = false;
+    unsigned dcnt = 0;
+    for (size_t i = 0; i < raw.size(); ++i) {
+        uint32_t tid = T.conv[raw[i]];
+        if (tid == 0) {  // TaxNodeStat.hpp:235-238: "bad taxid" assert
+            set_err(c, LMAT_E_TAXONOMY, "bad taxid: 16-bit id " + std::to_string(raw[i]) + " has no 32-bit mapping");
+            return false;
+        }
+        if (is_human32(tid)) {
+            if (seen_human) continue;
+            tid = 9606;
+            seen_human = true;
+        }
+        if (tid == 20999999 || tid == 12721 || tid == 693660) continue;
+        if (dcnt == 0) neg_first = ((int16_t)(uint16_t)raw.size()) < 0;
+        auto it = T.index_of.find(tid);
+        if (it == T.index_of.end()) {
+            set_err(c, LMAT_E_TAXONOMY, "taxid " + std::to_string(tid) + " missing from internal index");
+            return false;
+        }
+        obs.push_back(it->second);
+        dcnt++;
+    }
+    // CmpDepth1 (read_label.cpp:169-177) through the same std::sort the reference calls
+    std::sort(obs.begin(), obs.end(), [&T](uint16_t a, uint16_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
+    std::unordered_set<uint16_t> non_leaf;
+    std::vector<uint16_t> kept;
+    for (size_t i = 0; i < obs.size(); ++i) {
+        const uint16_t t = obs[i];
+        if (non_leaf.count(t)) continue;
+        if (std::find(kept.begin(), kept.end(), t) != kept.end()) {
+            set_err(c, LMAT_E_IO, "taxid list holds taxid " + std::to_string(T.tid32[t]) + " twice");
+            return false;
+        }
+        kept.push_back(t);
+        for (uint32_t p = 0; p < T.path_len[t]; ++p) non_leaf.insert(T.paths[T.path_off[t] + p]);
+    }
+    if (kept.size() > 65535 || raw.size() > 65535) {
+        set_err(c, LMAT_E_CAPACITY, "taxid list too long");
+        return false;
+    }
+    std::vector<uint16_t> asc(kept);
+    std::sort(asc.begin(), asc.end());  // internal index order == 32-bit taxid order
+    rec.clear();
+    rec.push_back(neg_first ? kListNegFirst : 0);
+    rec.push_back((uint16_t)kept.size());
+    rec.push_back((uint16_t)raw.size());
+    rec.insert(rec.end(), kept.begin(), kept.end());
+    rec.insert(rec.end(), asc.begin(), asc.end());
+    rec.insert(rec.end(), raw.begin(), raw.end());
+    if (rec.size() & 1) rec.push_back(0);
+    return true;
+}
+
+}  // namespace lmat

@@ -1,0 +1,124 @@
+"""ctypes binding of the CPU oracle (oracle/liblmat_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg as the checker; never by the lmat_amd package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liblmat_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "lmat_oracle", "liblmat_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def _load():
+    if not os.path.exists(LIB):
+        build()
+    L = C.CDLL(LIB)
+    vp, cp, u64, i32 = C.c_void_p, C.c_char_p, C.c_uint64, C.c_int
+    L.orc_create.restype = vp
+    L.orc_create.argtypes = [cp, cp, cp, cp, cp]
+    L.orc_destroy.argtypes = [vp]
+    L.orc_error.restype = cp
+    L.orc_error.argtypes = [vp]
+    L.orc_add_taxhisto.argtypes = [vp, cp]
+    L.orc_db_k.argtypes = [vp]
+    L.orc_set_k.argtypes = [vp, i32]
+    L.orc_db_size.restype = u64
+    L.orc_db_size.argtypes = [vp]
+    L.orc_add_list32.argtypes = [vp, u64, vp, i32]
+    L.orc_lookup.argtypes = [vp, u64, vp, i32]
+    L.orc_path_to_root.argtypes = [vp, C.c_uint32, vp, i32]
+    L.orc_set_options.argtypes = [vp, C.c_float, C.c_float, i32, i32, C.c_float, i32, i32, i32, i32]
+    L.orc_extract.argtypes = [cp, i32, i32, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.orc_classify.restype = C.c_long
+    L.orc_classify.argtypes = [vp, vp, vp, C.c_long, C.c_long, i32, vp, vp, vp, i32, C.POINTER(i32), vp]
+    L.orc_text.restype = vp
+    L.orc_text.argtypes = [vp]
+    L.orc_run_file.restype = C.c_long
+    L.orc_run_file.argtypes = [vp, cp, i32, cp, vp, C.c_long, vp, C.c_long]
+    return L
+
+
+class Oracle:
+    def __init__(self, tree, depth, rank, idmap, plasmids=None):
+        self.L = _load()
+        e = lambda s: s.encode() if s else b""
+        self.h = self.L.orc_create(e(tree), e(depth), e(rank), e(idmap), e(plasmids))
+        if not self.h:
+            raise RuntimeError("oracle: cannot load taxonomy files")
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def add_taxhisto(self, fn):
+        if self.L.orc_add_taxhisto(self.h, fn.encode()) != 0:
+            raise RuntimeError("oracle: " + self.L.orc_error(self.h).decode())
+
+    def add_list32(self, kmer, tids):
+        a = np.ascontiguousarray(tids, dtype=np.uint32)
+        if self.L.orc_add_list32(self.h, int(kmer), a.ctypes.data, a.size) != 0:
+            raise RuntimeError("oracle: " + self.L.orc_error(self.h).decode())
+
+    @property
+    def k(self):
+        return self.L.orc_db_k(self.h)
+
+    def set_k(self, k):
+        self.L.orc_set_k(self.h, k)
+
+    def lookup(self, kmer, cap=4096):
+        out = np.zeros(cap, dtype=np.uint32)
+        n = self.L.orc_lookup(self.h, int(kmer), out.ctypes.data, cap)
+        return n, out[:max(n, 0)].copy()
+
+    def path_to_root(self, tid, cap=256):
+        out = np.zeros(cap, dtype=np.uint32)
+        n = self.L.orc_path_to_root(self.h, int(tid), out.ctypes.data, cap)
+        return out[:n].tolist()
+
+    def set_options(self, sdiff=1.0, hbias=0.0, prn_all=1, screen_phix=1, min_score=0.0, min_kmer=30, min_fnd_kmer=1,
+                    prn_read=1, fastq=0):
+        self.L.orc_set_options(self.h, sdiff, hbias, prn_all, screen_phix, min_score, min_kmer, min_fnd_kmer, prn_read,
+                               fastq)
+
+    def extract(self, read: bytes, k=20):
+        cap = max(len(read), 1)
+        km = np.zeros(cap, dtype=np.uint64)
+        ps = np.zeros(cap, dtype=np.int32)
+        v, b = C.c_int(0), C.c_int(0)
+        n = self.L.orc_extract(read, len(read), k, km.ctypes.data, ps.ctypes.data, cap, C.byref(v), C.byref(b))
+        return km[:n].copy(), ps[:n].copy(), v.value, b.value
+
+    def classify(self, blob, off, k, first_index=0, tally_cap=70000):
+        """-> (.out text, {tid: (count, score)}, [ReadTooShort, NoDbHits, LowScore])"""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        tid = np.zeros(tally_cap, dtype=np.uint32)
+        cnt = np.zeros(tally_cap, dtype=np.int32)
+        sc = np.zeros(tally_cap, dtype=np.float32)
+        nt = C.c_int(0)
+        nm = np.zeros(3, dtype=np.int32)
+        ln = self.L.orc_classify(self.h, blob.ctypes.data, off.ctypes.data, off.size - 1, first_index, k, tid.ctypes.data,
+                                 cnt.ctypes.data, sc.ctypes.data, tally_cap, C.byref(nt), nm.ctypes.data)
+        text = C.string_at(self.L.orc_text(self.h), ln).decode()
+        n = nt.value
+        return text, {int(t): (int(c), float(s)) for t, c, s in zip(tid[:n], cnt[:n], sc[:n])}, nm.tolist()
+
+    def run_file(self, query, k, rank_ids=None):
+        fs = C.create_string_buffer(1 << 22)
+        ns = C.create_string_buffer(1 << 12)
+        ln = self.L.orc_run_file(self.h, query.encode(), k, (rank_ids or "").encode(), fs, len(fs), ns, len(ns))
+        if ln < 0:
+            raise RuntimeError("oracle: " + self.L.orc_error(self.h).decode())
+        return C.string_at(self.L.orc_text(self.h), ln).decode(), fs.value.decode(), ns.value.decode()

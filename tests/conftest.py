@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def small_dataset(tmp_path_factory):
+    """Synthetic taxonomy + tax_histo DB + reads, seeds 1001/2002/3003, small enough for seconds."""
+    from lmat_amd import synth
+    d = tmp_path_factory.mktemp("ds_small")
+    info = synth.generate_dataset(str(d), (2, 2, 2, 2, 3, 3), 600, 400, frac_short=0.03, lower_frac=0.05)
+    reads = []
+    with open(info["fasta"]) as f:
+        for line in f:
+            if not line.startswith(">"):
+                reads.append(line.rstrip("\n"))
+    info["reads"] = reads
+    return info
+
+
+@pytest.fixture(scope="session")
+def oracle_small(small_dataset):
+    import oracle_py
+    o = oracle_py.Oracle(small_dataset["tree"], small_dataset["depth"], small_dataset["rank"], small_dataset["idmap"])
+    o.add_taxhisto(small_dataset["db"])
+    o.set_options()
+    yield o
+    o.close()
