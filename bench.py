@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the read-labeling hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the classify path (k-mer extraction -> hash probe -> taxid
+accumulation -> LCA/score call) over one batch of synthetic 150 bp reads that are
+already packed in HBM, against a synthetic k-mer DB of --db-gb GiB generated on the
+device.  One process per GPU; the DB is replicated, reads are
+sharded (weak scaling: per-GPU batch fixed); the only collective is the final
+all-reduce of the per-taxid tallies (RCCL).
+
+Prints ONE JSON line on rank 0 with `roofline` (HBM, algorithmic bytes per launch /
+HIP-event kernel time) and, at N=1, `cpu_baseline` (the CPU oracle on a bounded
+sample of the same reads, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BRANCHING = (3, 4, 4, 4, 4, 3)  # 768 species x 3 strains, 3328 nodes
+
+
+def sample_algorithmic_bytes(eng, reads, n_sample, k):
+    """Mean algorithmic bytes per read, SURVEY.md 8(d):
+    ceil(L/4)+ceil(L/8) + 64*D + sum over probed k-mers with a non-inline list of 64*ceil(2*len/64) + 16."""
+    from lmat_amd import synth
+    blob, off = reads.ascii(0, n_sample)
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        lut[ch] = i
+    total = 0.0
+    all_k, per_read = [], []
+    for i in range(n_sample):
+        seq = blob[int(off[i]):int(off[i + 1])]
+        L = seq.size
+        b = np.ceil(L / 4) + np.ceil(L / 8) + 16
+        codes = lut[seq]
+        if L >= k:
+            bad = codes == 255
+            c2 = np.where(bad, 0, codes)
+            km = synth.kmers_of(c2, k)
+            win_bad = np.convolve(bad.astype(np.int32), np.ones(k, dtype=np.int32), mode="valid") > 0
+            km = np.unique(km[~win_bad])
+            if km.size >= eng.params.min_kmer or True:
+                all_k.append(km)
+                per_read.append((i, km.size))
+                b += 64.0 * km.size
+        total += b
+    if all_k:
+        cat = np.concatenate(all_k)
+        counts, _ = eng.lookup(cat, stride=1)
+        multi = counts[counts > 1].astype(np.float64)
+        total += float(np.sum(64.0 * np.ceil(2.0 * multi / 64.0)))
+    return total / n_sample
+
+
+def cpu_baseline(eng, reads, n_sample, k, tmpdir, threads):
+    """CPU oracle (oracle/, a port of read_label's proc_line) on the first n_sample reads of this rank's
+    workload.  Its k-mer table holds exactly the taxid lists the GPU table returns for those reads' k-mers."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    from lmat_amd import synth
+    tax = synth.make_taxonomy(BRANCHING, specials=False)
+    p = synth.write_aux_files(tmpdir, tax)
+    orc = oracle_py.Oracle(p["tree"], p["depth"], p["rank"], p["idmap"])
+    orc.set_k(k)
+    orc.set_options(sdiff=eng.params.sdiff, hbias=eng.params.hbias, prn_all=eng.params.prn_all, min_kmer=eng.params.min_kmer)
+    blob, off = reads.ascii(0, n_sample)
+    kms = []
+    for i in range(n_sample):
+        km, _, _, _ = orc.extract(bytes(blob[int(off[i]):int(off[i + 1])]), k)
+        kms.append(km)
+    kms = np.unique(np.concatenate(kms))
+    counts, tids = eng.lookup(kms, stride=16)
+    orc.add_lists32(kms, counts, tids)
+    t0 = time.perf_counter()
+    orc.classify_mt(np.append(blob, np.uint8(0)), off, k, threads)
+    dt = time.perf_counter() - t0
+    orc.close()
+    return n_sample / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--db-gb", type=float, default=64.0, help="hash table size in GiB (BASELINE metric: 64)")
+    ap.add_argument("--batch", type=int, default=2_000_000, help="reads per step per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    T0 = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lmat_amd import Engine, Params
+    k = 20
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - T0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    eng = Engine(local_rank, Params.run_rl(prn_all=0))  # run_rl.sh flags, calls-only output
+    eng.synth_taxonomy(BRANCHING)
+    table_bytes = int(args.db_gb * (1 << 30)) // 64 * 64
+    n_species, S = 768, 3
+    pm = 1.0 - 0.99 ** k
+    G = int(0.8 * (table_bytes / 8) / (n_species * (1.0 + S * pm)))
+    t0 = time.perf_counter()
+    eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes)
+    t_build = time.perf_counter() - t0
+    log(f"db built: {eng.db_size} k-mers in {t_build:.2f}s, table {table_bytes / 2**30:.1f} GiB, G={G}")
+    n_steps_total = args.steps + args.warmup
+    n_reads = args.batch * n_steps_total
+    reads = eng.synth_reads(n_reads, (args.read_len,), seed=3003 + 7919 * rank)
+    log(f"{n_reads} reads generated ({reads.device_bytes / 2**20:.0f} MiB packed)")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # tallies exposed to torch for the RCCL all-reduce (no copy)
+    n_ids, nbytes = eng.counts_layout()
+
+    class _Buf:
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+    base = eng.counts_device_ptr()
+    t_cnt = torch.as_tensor(_Buf(base, n_ids, "<i8"), device=f"cuda:{local_rank}")
+    t_sc = torch.as_tensor(_Buf(base + 8 * n_ids, n_ids, "<f8"), device=f"cuda:{local_rank}")
+    t_nm = torch.as_tensor(_Buf(base + 16 * n_ids, 3, "<i8"), device=f"cuda:{local_rank}")
+
+    for w in range(args.warmup):
+        eng.classify_async(reads, w * args.batch, args.batch)
+    wms, wl = eng.sync()
+    log(f"warmup done: {wl} launches, {wms:.1f} ms kernel time")
+    eng.counts_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        eng.classify_async(reads, (args.warmup + s) * args.batch, args.batch)
+    kernel_ms, launches = eng.sync()
+    if dist is not None:  # merge step of read_label.cpp:1760-1800
+        dist.all_reduce(t_cnt)
+        dist.all_reduce(t_sc)
+        dist.all_reduce(t_nm)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    log(f"timed region {dt:.3f}s, kernel {kernel_ms:.1f} ms over {launches} launches")
+    total_reads = args.batch * args.steps * world
+    value = total_reads / dt
+    if rank == 0:
+        counts, nomatch = eng.counts()
+        called = sum(c for c, _ in counts.values())
+        mean_b = sample_algorithmic_bytes(eng, reads, 2000, k)
+        log(f"algorithmic bytes/read = {mean_b:.0f}")
+        avg_ms = kernel_ms / max(launches, 1)
+        achieved = mean_b * args.batch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "reads/s (150 bp) vs 64 GB k-mer DB", "value": value, "unit": "reads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.batch * args.steps} x {args.read_len} bp reads/GPU vs {args.db_gb:g} GiB "
+                                   f"k-mer hash ({eng.db_size} 20-mers, replicated per GPU), run_rl.sh flags -x 0 -j 30 -l 0 -b 1, calls-only",
+                       "reads_per_step_per_gpu": args.batch, "read_len": args.read_len, "db_gib": args.db_gb,
+                       "db_kmers": eng.db_size, "k": k, "parallelism": f"reads sharded x{world}, DB replicated",
+                       "db_build_s": round(t_build, 2), "reads_called": called, "nomatch": nomatch},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "classify_kernel<256,128>",
+                         "kernel_avg_ms": avg_ms, "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.batch},
+        }
+        if world == 1 and not args.no_cpu:
+            threads = os.cpu_count() or 1
+            with tempfile.TemporaryDirectory() as td:
+                rps, secs = cpu_baseline(eng, reads, args.cpu_sample, k, td, threads)
+            out["cpu_baseline"] = {"value": rps, "unit": "reads/s", "cores": threads, "kind": "port",
+                                   "sample": f"first {args.cpu_sample} reads of the same synthetic workload, CPU oracle "
+                                             f"(oracle/lmat_oracle.hpp, {threads} threads, {secs:.1f} s), k-mer table = "
+                                             "host hash map holding the GPU table's lists for those reads' k-mers"}
+        print(json.dumps(out))
+    reads.free()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

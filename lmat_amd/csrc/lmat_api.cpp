@@ -286,7 +286,7 @@ int lmat_synth_taxonomy(lmat_ctx* c, const uint32_t* br) {
     (void)ranks;
     HostTaxonomy& T = c->tax;
     T = HostTaxonomy();
-    std::vector<uint32_t> ids{1}, parent{1}, depth{0}, level_of{0};
+    std::vector<uint32_t> ids{1}, parent{0}, depth{0}, level_of{0};
     std::vector<uint32_t> level{0};  // indices into ids
     uint32_t dense = 0;
     for (int lv = 0; lv < 6; ++lv) {

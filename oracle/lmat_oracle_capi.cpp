@@ -1,6 +1,7 @@
 // lmat_oracle_capi.cpp -- C entry points of the CPU oracle for ctypes callers.
 // TEST INFRASTRUCTURE ONLY (see lmat_oracle.hpp header): used by tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker.
+#include <thread>
 #include "lmat_oracle.hpp"
 
 using namespace orc;
@@ -125,6 +126,45 @@ long orc_classify(orc_ctx* c, const char* blob, const uint64_t* off, long n, lon
     return (long)c->text.size();
 }
 const char* orc_text(orc_ctx* c) { return c->text.c_str(); }
+
+// bulk form of orc_add_list32: counts[i] ids at tids[i*stride ..]
+int orc_add_lists32(orc_ctx* c, const uint64_t* kmers, const uint32_t* counts, const uint32_t* tids, uint32_t stride,
+                    uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!counts[i]) continue;
+        if (counts[i] > stride) { c->err = "list longer than stride"; return -1; }
+        if (orc_add_list32(c, kmers[i], tids + i * stride, (int)counts[i]) != 0) return -1;
+    }
+    return 0;
+}
+
+// Throughput form for the CPU baseline: classifies the reads on nthreads host threads
+// (reads are independent, read_label.cpp:1742-1748) and discards the text.  Returns the
+// number of reads that produced a taxid call.
+long orc_classify_mt(orc_ctx* c, const char* blob, const uint64_t* off, long n, int k_size, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    std::vector<long> calls(nthreads, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) {
+        th.emplace_back([&, t]() {
+            Classifier cls(c->tax, c->db, c->opt);
+            Tallies tl;
+            std::ostringstream ofs;
+            for (long i = t; i < n; i += nthreads) {
+                std::string read(blob + off[i], blob + off[i + 1]);
+                cls.proc_line((int)read.length(), read, k_size, ofs, tl);
+                if (ofs.tellp() > (1 << 20)) { ofs.str(""); }
+            }
+            long s = 0;
+            for (auto& kv : tl.count) s += kv.second;
+            calls[t] = s;
+        });
+    }
+    for (auto& x : th) x.join();
+    long s = 0;
+    for (long v : calls) s += v;
+    return s;
+}
 
 // Whole-file run (FASTA/FASTQ parsing included), as the CLI does.
 long orc_run_file(orc_ctx* c, const char* query, int k_size, const char* rank_ids, char* fastsummary, long fs_cap,

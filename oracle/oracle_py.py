@@ -41,6 +41,9 @@ def _load():
     L.orc_extract.argtypes = [cp, i32, i32, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.orc_classify.restype = C.c_long
     L.orc_classify.argtypes = [vp, vp, vp, C.c_long, C.c_long, i32, vp, vp, vp, i32, C.POINTER(i32), vp]
+    L.orc_add_lists32.argtypes = [vp, vp, vp, vp, C.c_uint32, u64]
+    L.orc_classify_mt.restype = C.c_long
+    L.orc_classify_mt.argtypes = [vp, vp, vp, C.c_long, i32, i32]
     L.orc_text.restype = vp
     L.orc_text.argtypes = [vp]
     L.orc_run_file.restype = C.c_long
@@ -69,6 +72,18 @@ class Oracle:
         a = np.ascontiguousarray(tids, dtype=np.uint32)
         if self.L.orc_add_list32(self.h, int(kmer), a.ctypes.data, a.size) != 0:
             raise RuntimeError("oracle: " + self.L.orc_error(self.h).decode())
+
+    def add_lists32(self, kmers, counts, tids):
+        km = np.ascontiguousarray(kmers, dtype=np.uint64)
+        ct = np.ascontiguousarray(counts, dtype=np.uint32)
+        td = np.ascontiguousarray(tids, dtype=np.uint32)
+        if self.L.orc_add_lists32(self.h, km.ctypes.data, ct.ctypes.data, td.ctypes.data, td.shape[1], km.size) != 0:
+            raise RuntimeError("oracle: " + self.L.orc_error(self.h).decode())
+
+    def classify_mt(self, blob, off, k, nthreads):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        return self.L.orc_classify_mt(self.h, blob.ctypes.data, off.ctypes.data, off.size - 1, k, nthreads)
 
     @property
     def k(self):
