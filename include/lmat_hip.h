@@ -150,6 +150,11 @@ void* lmat_counts_device_ptr(lmat_ctx* ctx);
 int lmat_counts_get(lmat_ctx* ctx, uint32_t* tid32, uint64_t* count, double* score, uint32_t cap, uint32_t* n_nonzero,
                     uint64_t nomatch3[3]);
 
+/* ---- measurement aid ---------------------------------------------------------
+ * Random 64-byte bucket gather over the loaded table with the probe kernel's access shape;
+ * reports the HIP-event time and the bytes it read (the practical ceiling of the probe). */
+int lmat_gather_bench(lmat_ctx* ctx, uint64_t n_probes, uint64_t seed, float* ms, uint64_t* bytes);
+
 /* ---- record text -------------------------------------------------------------
  * The bytes read_label writes to a .out file for these results (prefix
  * read_label.cpp:1733-1738, body :844-848,894-937,1218,1233,1271).  Headers are

@@ -76,6 +76,7 @@ def load_library(path: str | None = None):
         "lmat_counts_layout": (i32, [vp, P(u32), P(u64)]),
         "lmat_counts_device_ptr": (vp, [vp]),
         "lmat_counts_get": (i32, [vp, vp, vp, vp, u32, P(u32), vp]),
+        "lmat_gather_bench": (i32, [vp, u64, u64, P(C.c_float), P(u64)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
     }
     for name, (res, args) in sig.items():
@@ -92,7 +93,8 @@ EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_
             "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_reads_upload",
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_results_fetch",
-            "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_format_out"]
+            "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
+            "lmat_format_out"]
 
 
 def _ptr(a):
@@ -235,6 +237,12 @@ class Engine:
         res = np.zeros(count, dtype=READ_RESULT_DTYPE)
         self._chk(self.lib.lmat_results_fetch(self.ctx, first, count, _ptr(res)))
         return res
+
+    def gather_bench(self, n_probes, seed=1):
+        """-> (ms, bytes) of a random 64-B bucket gather over the table (probe access shape)."""
+        ms, b = C.c_float(0), C.c_uint64(0)
+        self._chk(self.lib.lmat_gather_bench(self.ctx, int(n_probes), seed, C.byref(ms), C.byref(b)))
+        return float(ms.value), int(b.value)
 
     def format_out(self, res, cands, reads_ascii=None, first_index=0):
         """.out text for these results; reads_ascii = (blob, off) to echo the read, else 'X' (-a)."""

@@ -935,6 +935,28 @@ __device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* l
     }
 }
 
+// Random 64-byte bucket gather with the probe's access shape (8 lanes x 8 B per bucket, 8 wave-loads
+// in flight): the practical ceiling of K2 on this table, and a known byte count to calibrate
+// the FETCH_SIZE counter against.
+__global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __restrict__ slots, uint32_t nbuckets,
+                                                          uint64_t probes_per_wave, uint64_t seed,
+                                                          unsigned long long* sink) {
+    const int lane = threadIdx.x & 63, g = lane >> 3, sub = lane & 7;
+    unsigned long long acc = 0;
+    uint64_t ctr = (uint64_t)blockIdx.x * probes_per_wave;
+    for (uint64_t i = 0; i < probes_per_wave; i += 64) {
+        unsigned long long sl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t b = bucket_of(seed + ctr + i + j * 8 + g, nbuckets);
+            sl[j] = slots[(uint64_t)b * kSlotsPerBucket + sub];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += sl[j] >> 13;
+    }
+    if (acc == 0x123456789ull) atomicAdd(sink, acc);
+}
+
 template <int U, int T>
 __global__ __launch_bounds__(64) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -985,6 +1007,13 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
     if (!n) return;
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tb, kmers, n, counts, tids,
                        stride);
+}
+
+void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,
+                         unsigned long long* sink, hipStream_t stream) {
+    const int grid = 256 * 16;
+    const uint64_t per_wave = (n_probes / grid + 63) / 64 * 64;
+    gather_bench_kernel<<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
 }
 
 template <int U, int T>

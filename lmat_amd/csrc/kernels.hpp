@@ -38,6 +38,9 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
 // tcap_class: 0 = fast (T=128), 1 = large (T=1024).  Returns false if max_len exceeds every U class.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
 int classify_max_read_len();
+// issues ~n_probes random bucket reads (rounded up to 64 per wave x 4096 waves)
+void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,
+                         unsigned long long* sink, hipStream_t stream);
 
 // host-callable copies of the synthetic genome functions (tests / oracle cross-checks)
 uint32_t synth_strain_base_host(uint64_t seed, uint32_t species, uint32_t strain_global, uint64_t pos);

@@ -698,6 +698,28 @@ int lmat_counts_get(lmat_ctx* c, uint32_t* tid32, uint64_t* count, double* score
     return LMAT_OK;
 }
 
+int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, uint64_t* bytes) {
+    if (!c || !c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
+    hipSetDevice(c->device);
+    unsigned long long* sink = nullptr;
+    HIPCHK(c, hipMalloc((void**)&sink, 8));
+    HIPCHK(c, hipMemsetAsync(sink, 0, 8, c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    launch_gather_bench(c->dev.slots, c->dev.nbuckets, n_probes, seed, sink, c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float t = 0;
+    HIPCHK(c, hipEventElapsedTime(&t, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
+    if (ms) *ms = t;
+    const uint64_t per_wave = (n_probes / 4096 + 63) / 64 * 64;
+    if (bytes) *bytes = per_wave * 4096 * 64;
+    return LMAT_OK;
+}
+
 int64_t lmat_format_out(const lmat_ctx* c, const lmat_read_result* results, uint64_t n, const lmat_cand* cands,
                         const uint8_t* bases, const uint64_t* off, int prn_read, uint64_t first_index, char* buf,
                         uint64_t cap) {
