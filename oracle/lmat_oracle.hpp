@@ -736,6 +736,23 @@ struct Classifier {
         return std::make_pair(best_guess, mtype);
     }
 
+    // tally rule of proc_line, src/read_label.cpp:1248-1268
+    void tally_call(Tallies& tl, const std::pair<ufpair_t, Match>& m, int valid_kmers) const {
+        if (m.second == kNoMatchT) {
+            tl.nomatch[kNoDbHits] += 1;
+        } else if (m.first.second >= opt.min_score && valid_kmers >= opt.min_kmer) {
+            if (tl.count.find(m.first.first) == tl.count.end()) {
+                tl.count[m.first.first] = 1;
+                tl.score[m.first.first] = m.first.second;
+            } else {
+                tl.count[m.first.first] += 1;
+                tl.score[m.first.first] += m.first.second;
+            }
+        } else if (m.first.second < opt.min_score) {
+            tl.nomatch[kLowScore] += 1;
+        }
+    }
+
     // src/read_label.cpp:1211-1279
     void proc_line(int ri_len, const std::string& line, int k_size, std::ostream& ofs, Tallies& tl,
                    ReadTrace* tr = nullptr) const {
@@ -766,18 +783,8 @@ struct Classifier {
                 if (m.second == kNoMatchT && valid_kmers < opt.min_kmer) {
                     ofs << "-1 -1 -1" << "\t-1 -1\t" << valid_kmers << " " << opt.min_kmer << " ReadTooShort" << std::endl;
                     tl.nomatch[kReadTooShort] += 1;
-                } else if (m.second == kNoMatchT) {
-                    tl.nomatch[kNoDbHits] += 1;
-                } else if (m.first.second >= opt.min_score && valid_kmers >= opt.min_kmer) {
-                    if (tl.count.find(m.first.first) == tl.count.end()) {
-                        tl.count[m.first.first] = 1;
-                        tl.score[m.first.first] = m.first.second;
-                    } else {
-                        tl.count[m.first.first] += 1;
-                        tl.score[m.first.first] += m.first.second;
-                    }
-                } else if (m.first.second < opt.min_score) {
-                    tl.nomatch[kLowScore] += 1;
+                } else {
+                    tally_call(tl, m, valid_kmers);
                 }
             } else {
                 ofs << "-1 -1 " << valid_kmers << "\t-1 -1\t" << ri_len << " " << k_size << " NoDbHits" << std::endl;

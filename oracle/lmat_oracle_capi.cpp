@@ -166,6 +166,25 @@ long orc_classify_mt(orc_ctx* c, const char* blob, const uint64_t* off, long n, 
     return s;
 }
 
+// Summaries from a list of per-read calls (tid, score, is_nomatch), in read order: the tally rule of
+// proc_line (read_label.cpp:1248-1268) followed by the .fastsummary/.nomatchsum writers (:1801-1867).
+long orc_summaries_from_calls(orc_ctx* c, const uint32_t* tids, const float* scores, const int* nomatch, long n,
+                              int extra_short, int extra_nodb, char* fastsummary, long fs_cap, char* nomatchsum,
+                              long nm_cap) {
+    Classifier cls(c->tax, c->db, c->opt);
+    Tallies tl;
+    if (extra_short) tl.nomatch[kReadTooShort] = extra_short;
+    if (extra_nodb) tl.nomatch[kNoDbHits] = extra_nodb;
+    for (long i = 0; i < n; ++i)
+        cls.tally_call(tl, std::make_pair(std::make_pair(tids[i], scores[i]), nomatch[i] ? kNoMatchT : kDirectMatch),
+                       c->opt.min_kmer);
+    RunOutputs ro;
+    write_summaries(tl, "", ro);
+    snprintf(fastsummary, fs_cap, "%s", ro.fastsummary.c_str());
+    snprintf(nomatchsum, nm_cap, "%s", ro.nomatchsum.c_str());
+    return (long)tl.count.size();
+}
+
 // Whole-file run (FASTA/FASTQ parsing included), as the CLI does.
 long orc_run_file(orc_ctx* c, const char* query, int k_size, const char* rank_ids, char* fastsummary, long fs_cap,
                   char* nomatchsum, long nm_cap) {

@@ -46,6 +46,8 @@ def _load():
     L.orc_classify_mt.argtypes = [vp, vp, vp, C.c_long, i32, i32]
     L.orc_text.restype = vp
     L.orc_text.argtypes = [vp]
+    L.orc_summaries_from_calls.restype = C.c_long
+    L.orc_summaries_from_calls.argtypes = [vp, vp, vp, vp, C.c_long, i32, i32, vp, C.c_long, vp, C.c_long]
     L.orc_run_file.restype = C.c_long
     L.orc_run_file.argtypes = [vp, cp, i32, cp, vp, C.c_long, vp, C.c_long]
     return L
@@ -129,6 +131,16 @@ class Oracle:
         text = C.string_at(self.L.orc_text(self.h), ln).decode()
         n = nt.value
         return text, {int(t): (int(c), float(s)) for t, c, s in zip(tid[:n], cnt[:n], sc[:n])}, nm.tolist()
+
+    def summaries_from_calls(self, tids, scores, nomatch, extra_short=0, extra_nodb=0):
+        t = np.ascontiguousarray(tids, dtype=np.uint32)
+        s = np.ascontiguousarray(scores, dtype=np.float32)
+        m = np.ascontiguousarray(nomatch, dtype=np.int32)
+        fs = C.create_string_buffer(1 << 20)
+        ns = C.create_string_buffer(1 << 12)
+        self.L.orc_summaries_from_calls(self.h, t.ctypes.data, s.ctypes.data, m.ctypes.data, t.size, extra_short, extra_nodb,
+                                        fs, len(fs), ns, len(ns))
+        return fs.value.decode(), ns.value.decode()
 
     def run_file(self, query, k, rank_ids=None):
         fs = C.create_string_buffer(1 << 22)

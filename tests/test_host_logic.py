@@ -1,0 +1,138 @@
+"""CPU tests of host-side logic: C-ABI surface, std::sort replica, reader quirks, generator determinism."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import lmat_amd
+    from lmat_amd import capi
+    lib = lmat_amd.load_library()
+    hdr = open(os.path.join(ROOT, "include", "lmat_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(lmat_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(capi.EXPORTED) == declared
+
+
+def test_no_gpu_means_loud_failure():
+    import lmat_amd
+    import torch
+    if torch.cuda.is_available():
+        return
+    try:
+        lmat_amd.Engine()
+    except lmat_amd.LmatError as e:
+        assert e.code == -3
+    else:
+        raise AssertionError("Engine() must fail without a GPU (no CPU fallback)")
+
+
+def test_std_sort_replica_matches_libstdcxx(tmp_path):
+    """ss_sort (lmat_common.hpp) is the device's std::sort: same permutation as libstdc++ on random inputs,
+    including the non-strict-weak TCmp comparator (read_label.cpp:475-485) and n > 16 (introsort path)."""
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "lmat_common.hpp"
+struct E { float s; int d; int id; };
+struct TCmp { bool operator()(const E& a, const E& b) const {
+    if (fabs(a.s - b.s) < 0.001) return a.d < b.d; return a.s < b.s; } };
+struct DCmp { bool operator()(const E& a, const E& b) const { return a.d > b.d; } };
+template <class C> int run(int iters, unsigned seed, int maxn, C cmp) {
+    std::mt19937 g(seed);
+    for (int it = 0; it < iters; ++it) {
+        int n = 1 + g() % maxn;
+        std::vector<E> a(n);
+        for (int i = 0; i < n; ++i) { a[i].s = (g() % 40) * 0.0004f + (g() % 3) * 0.01f; a[i].d = g() % 6; a[i].id = i; }
+        std::vector<E> b = a;
+        std::sort(a.begin(), a.end(), cmp);
+        lmat::ss_sort(b.data(), n, cmp);
+        for (int i = 0; i < n; ++i) if (a[i].id != b[i].id) { printf("MISMATCH n=%d i=%d\n", n, i); return 1; }
+    }
+    return 0;
+}
+int main() {
+    if (run(20000, 1, 16, TCmp())) return 1;
+    if (run(20000, 2, 200, TCmp())) return 1;
+    if (run(5000, 3, 2000, DCmp())) return 1;
+    if (run(20000, 4, 40, DCmp())) return 1;
+    printf("OK\n");
+    return 0;
+}''')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "lmat_amd", "csrc"), str(src), "-o", str(exe)])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "OK"
+
+
+def _oracle(ds):
+    import oracle_py
+    o = oracle_py.Oracle(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    o.add_taxhisto(ds["db"])
+    o.set_options()
+    return o
+
+
+def test_fastq_header_lag_and_fasta_rules(small_dataset, tmp_path):
+    """Reader quirks restated from main() (read_label.cpp:1651-1713): FASTQ records carry the previous
+    record's header and the first is unknown_hdr:1 (Q2); FASTA lines of length <= 1 are dropped (Q3);
+    multi-line FASTA is concatenated."""
+    o = _oracle(small_dataset)
+    seqs = small_dataset["reads"][:6]
+    fq = tmp_path / "a.fq"
+    fq.write_text("".join(f"@h{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(seqs)))
+    o.set_options(fastq=1)
+    text, _, _ = o.run_file(str(fq), 20)
+    hdrs = [l.split("\t")[0] for l in text.splitlines()]
+    assert hdrs == ["unknown_hdr:1"] + [f"h{i}" for i in range(5)]
+    o.set_options(fastq=0)
+    fa = tmp_path / "a.fa"
+    s0, s1 = seqs[0], seqs[1]
+    fa.write_text(f">x0\n{s0[:70]}\n{s0[70:]}\n>x1\nA\n>x2\n{s1}\n")
+    text, _, nm = o.run_file(str(fa), 20)
+    lines = text.splitlines()
+    assert [l.split("\t")[0] for l in lines] == ["x0", "x2"]  # the 1-base record never becomes a read
+    assert lines[0].split("\t")[1] == s0
+    o.close()
+
+
+def test_silent_record_quirk(small_dataset):
+    """Q1: valid k-mers >= min but distinct k-mers < min -> 'hdr\\tread\\t' with no newline, tallied NoDbHits."""
+    o = _oracle(small_dataset)
+    unit = small_dataset["reads"][1][:25]
+    read = (unit * 6)[:150]
+    hit = small_dataset["reads"][1]
+    blob = np.frombuffer((read + hit).encode() + b"\0", dtype=np.uint8)
+    off = np.array([0, len(read), len(read) + len(hit)], dtype=np.uint64)
+    text, tally, nm = o.classify(blob, off, 20)
+    assert text.startswith(f"r0\t{read}\tr1\t{hit}\t")
+    assert nm[1] == 1
+    o.close()
+
+
+def test_generator_is_deterministic(tmp_path):
+    from lmat_amd import synth
+    a = synth.generate_dataset(str(tmp_path / "a"), (2, 2, 2, 2, 2, 2), 200, 20)
+    b = synth.generate_dataset(str(tmp_path / "b"), (2, 2, 2, 2, 2, 2), 200, 20)
+    for k in ("db", "fasta", "tree", "idmap"):
+        assert open(a[k], "rb").read() == open(b[k], "rb").read()
+
+
+def test_committed_dataset_matches_generator(tmp_path):
+    """tests/golden/ds is exactly what the generator emits today (fixtures stay reproducible)."""
+    from lmat_amd import synth
+    g = os.path.join(ROOT, "tests", "golden", "ds")
+    a = synth.generate_dataset(str(tmp_path / "a"), (2, 2, 2, 2, 3, 3), 300, 300, frac_short=0.03, lower_frac=0.05)
+    for f in ("th.bin", "reads.fa", "tax.dat", "map32to16.txt", "depth.dat", "rank.txt"):
+        assert open(os.path.join(g, f), "rb").read() == open(os.path.join(str(tmp_path / "a"), f), "rb").read(), f
