@@ -1,0 +1,329 @@
+// read_label_main.cpp -- `read_label`-compatible command line on top of liblmat_hip.so.
+//
+// Keeps the CLI contract bin/run_rl.sh relies on (argv built at bin/run_rl.sh:243; getopt string and
+// flag meanings src/read_label.cpp:1351-1442; required-argument check :1443-1453; outputs
+// <o><N>.out, <o>.<x>.<j>.fastsummary, <o>.<x>.<j>.nomatchsum :1642-1647,1836-1867; banner and
+// progress lines :1460-1462,1570-1573,1633,1707,1758,1843,1860,1869).  The per-read work
+// (proc_line, :1211-1279) runs on the GPU through the C ABI; this file only parses input, batches
+// reads, formats records and merges tallies (:1760-1800).
+//
+// Differences that are forced by the environment, all loud:
+//   * -d takes a tax_histo binary (make_db_table's input) or a text file listing several; PERM heap
+//     images cannot be opened without perm-je.
+//   * -n (null models), -s (permissive), -g/-m (run-time pruning) are not implemented yet: the
+//     program refuses them instead of ignoring them.
+//   * -t N is the number of output shards (<o>0.out .. <o>N-1.out) and of formatter threads; reads
+//     are dealt to shards in contiguous blocks (the reference deals them dynamically, so only the
+//     multiset of lines across shards is defined there; -t 1 gives the reference's -t 1 file).
+#include <getopt.h>
+#include <unistd.h>
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <set>
+#include <sstream>
+#include <thread>
+#include <vector>
+#include "../../include/lmat_hip.h"
+#include "fastx.hpp"
+#include "outfmt.hpp"
+
+#define LMAT_VERSION "1.2.4_2018a"
+
+using namespace lmat;
+
+static void usage(const char* exe) {
+    std::cout << "==============================================" << std::endl;
+    std::cout << "  Livermore  Metagenomics  Analysis  Toolkit  " << std::endl;
+    std::cout << "  read_label -- MI355X engine (liblmat_hip)    " << std::endl;
+    std::cout << "==============================================" << std::endl;
+    std::cout << std::endl << "Taxonomic classification module usage:" << std::endl;
+    std::cout << exe << " -d <tax_histo db file (list)> -i <query fasta file> -t <number of output shards>" << std::endl;
+    std::cout << "-o <output path> [-l <human bias>] -c <tax tree file> -e <depth file> -f <32to16 map> [-w <rank map>]" << std::endl;
+    std::cout << "[-x min score] [-j min kmers] [-z min found kmers] [-b sdiff] [-p] [-a] [-q] [-h:turn phiX screening off]" << std::endl;
+    std::cout << "[-V:print version and exit] [-H:print this usage help and exit]" << std::endl;
+}
+
+static bool is_list_file(const std::string& fn) {
+    FILE* f = fopen(fn.c_str(), "rb");
+    if (!f) return false;
+    unsigned char b[20];
+    size_t n = fread(b, 1, 20, f);
+    fclose(f);
+    if (n < 20) return true;
+    for (int i = 12; i < 20; ++i)
+        if (b[i] != 0xff) return true;
+    return false;
+}
+
+struct Batch {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off{0};
+    std::vector<std::string> hdrs;
+    size_t n() const { return hdrs.size(); }
+    void clear() { bases.clear(); off.assign(1, 0); hdrs.clear(); }
+};
+
+int main(int argc, char* argv[]) {
+    int c;
+    int n_threads = 0, k_size = -1;
+    float min_score = 0.0f;
+    int min_kmer = 35, min_fnd_kmer = 1;
+    lmat_params prm = {1.0f, 3.0f, 0.0f, 35, 1, 0, 1};
+    std::string rank_map_file, rank_ids, kmer_db_fn, query_fn, ofbase, tax_tree_fn, depth_file, id_bit_conv_fn, plasmid_file;
+    bool fastq = false, prn_read = true;
+    std::string unsupported;
+    while ((c = getopt(argc, argv, "u:ahn:j:b:ye:w:pk:c:v:k:i:d:l:t:r:sm:o:x:f:g:z:qVH")) != -1) {
+        switch (c) {
+            case 'h': prm.screen_phix = 0; break;
+            case 'r': plasmid_file = optarg; break;
+            case 'f': id_bit_conv_fn = optarg; break;
+            case 'j': min_kmer = atoi(optarg); break;
+            case 'z': min_fnd_kmer = atoi(optarg); break;
+            case 'u': rank_ids = optarg; break;
+            case 'x': min_score = atof(optarg); break;
+            case 'a': prn_read = false; break;
+            case 'w': rank_map_file = optarg; break;
+            case 's': unsupported += " -s"; break;
+            case 'n': unsupported += " -n"; break;
+            case 'b': prm.sdiff = atof(optarg); break;
+            case 'l': prm.hbias = atof(optarg); break;
+            case 'y': break;  // verbose dumps are not produced
+            case 'e': depth_file = optarg; break;
+            case 'q': fastq = true; break;
+            case 'p': prm.prn_all = 1; break;
+            case 'm': unsupported += " -m"; break;
+            case 't': n_threads = atoi(optarg); break;
+            case 'v': break;  // threshold: parsed and unused upstream too (proc_line's `threshold`)
+            case 'c': tax_tree_fn = optarg; break;
+            case 'k': k_size = atoi(optarg); break;
+            case 'g': unsupported += " -g"; break;
+            case 'i': query_fn = optarg; break;
+            case 'd': kmer_db_fn = optarg; break;
+            case 'o': ofbase = optarg; break;
+            case 'V': std::cout << "LMAT version " << LMAT_VERSION << std::endl; exit(0);
+            case 'H': usage(argv[0]); exit(0);
+            default: std::cerr << "WARNING! Unrecognized option " << (char)c << " to ignore." << std::endl;
+        }
+    }
+    if (depth_file == "") std::cerr << "ERROR! Missing depth_file" << std::endl;
+    if (ofbase == "") std::cerr << "ERROR! Missing ofbase" << std::endl;
+    if (n_threads == 0) std::cerr << "ERROR! Missing n_threads" << std::endl;
+    if (kmer_db_fn == "") std::cerr << "ERROR! Missing kmer_db_fn" << std::endl;
+    if (query_fn == "") std::cerr << "ERROR! Missing query_fn" << std::endl;
+    if (depth_file == "" || ofbase == "" || n_threads == 0 || kmer_db_fn == "" || query_fn == "") {
+        std::cerr << "Params: " << ofbase << " " << n_threads << " " << kmer_db_fn << " " << query_fn << " " << depth_file << std::endl;
+        usage(argv[0]);
+        return -1;
+    }
+    if (!unsupported.empty()) {
+        std::cerr << "ERROR! option(s)" << unsupported << " (null models / permissive match / run-time pruning) are not "
+                  << "implemented by the MI355X engine yet; refusing to run without them" << std::endl;
+        return -2;
+    }
+    if (id_bit_conv_fn.empty()) {
+        std::cerr << "ERROR! the 16-bit taxid map (-f) is required (TID_SIZE=16 database)" << std::endl;
+        return -1;
+    }
+    prm.min_score = min_score;
+    prm.min_kmer = min_kmer;
+    prm.min_fnd_kmer = min_fnd_kmer;
+
+    std::cout << "=== LMAT === read_label === ver. " << LMAT_VERSION << " ===" << std::endl;
+    int device = 0;
+    if (const char* d = getenv("LMAT_DEVICE")) device = atoi(d);
+    lmat_ctx* ctx = nullptr;
+    if (lmat_ctx_create(device, &prm, &ctx) != LMAT_OK) {
+        std::cerr << "ERROR! no usable HIP device (this build has no CPU path)" << std::endl;
+        return -1;
+    }
+    auto fail = [&](const char* what) {
+        std::cerr << "ERROR! " << what << ": " << lmat_last_error(ctx) << std::endl;
+        lmat_ctx_destroy(ctx);
+        return -1;
+    };
+    if (id_bit_conv_fn.length() > 0) std::cout << "Loading map file " << id_bit_conv_fn << "... ";
+    std::cout << "Reading taxonomy tree " << tax_tree_fn << std::endl;
+    std::cout << "Reading taxonomy depth " << depth_file << std::endl;
+    if (lmat_taxonomy_load_files(ctx, tax_tree_fn.c_str(), depth_file.c_str(), rank_map_file.empty() ? nullptr : rank_map_file.c_str(),
+                                 id_bit_conv_fn.c_str(), plasmid_file.empty() ? nullptr : plasmid_file.c_str()) != LMAT_OK)
+        return fail("taxonomy");
+    std::cout << "OK!" << std::endl;
+
+    std::cout << "Start kmer DB load..." << std::endl;
+    std::vector<std::string> files;
+    if (is_list_file(kmer_db_fn)) {
+        std::ifstream l(kmer_db_fn.c_str());
+        std::string f;
+        while (l >> f) files.push_back(f);
+    } else files.push_back(kmer_db_fn);
+    if (files.empty()) { std::cerr << "Error: unable to open kmer db [" << kmer_db_fn << "]" << std::endl; return -1; }
+    {
+        // k-mer length comes from the first file's header (KmerFileMetaData.cpp:44-94)
+        FILE* f = fopen(files[0].c_str(), "rb");
+        if (!f) { std::cerr << "Error: unable to open kmer db [" << files[0] << "]" << std::endl; return -1; }
+        uint32_t klen = 0;
+        fseek(f, 25, SEEK_SET);
+        if (fread(&klen, 4, 1, f) != 1) klen = 0;
+        fclose(f);
+        if (k_size < 1) k_size = (int)klen;
+        if (lmat_db_begin(ctx, (int)klen, 0, 0) != LMAT_OK) return fail("k-mer DB");
+    }
+    for (auto& f : files)
+        if (lmat_db_add_taxhisto(ctx, f.c_str()) != LMAT_OK) return fail("k-mer DB");
+    if (lmat_db_finalize(ctx) != LMAT_OK) return fail("k-mer DB");
+    std::cout << "Loaded k-mer DB into a " << (lmat_db_table_bytes(ctx) >> 20) << " MiB GPU hash. Num of k-mers: " << lmat_db_size(ctx)
+              << " of size " << k_size << std::endl;
+    if (k_size <= 0) { std::cerr << "ERROR! Unable to read database, k-mer size=" << k_size << std::endl; return -1; }
+
+    auto t_start = std::chrono::steady_clock::now();
+    std::ifstream qf;
+    std::istream* in = &std::cin;
+    if (query_fn != "-") {
+        qf.open(query_fn.c_str());
+        if (!qf) { std::cerr << "ERROR! Did not open for reading: " << query_fn << std::endl; exit(-1); }
+        in = &qf;
+    }
+    std::cout << "Classifing reads in parallel with " << n_threads << " processes in .out files..." << std::endl;
+    std::vector<std::ofstream> ofs(n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+        std::ostringstream nm;
+        nm << ofbase << t << ".out";
+        ofs[t].open(nm.str().c_str());
+    }
+
+    std::map<uint32_t, int> merge_count;
+    std::map<uint32_t, float> merge_score;
+    std::map<int, int> nomatch_merge;
+    FastxReader rd(*in, fastq);
+    const size_t kBatch = 1u << 20;
+    Batch b;
+    size_t read_count = 0;
+    std::vector<lmat_read_result> res;
+    std::vector<lmat_cand> cands;
+    bool more = true;
+    std::string read, hdr;
+    while (more) {
+        b.clear();
+        while (b.n() < kBatch) {
+            if (!rd.next(read, hdr)) { more = false; break; }
+            ++read_count;
+            if (hdr.empty() || hdr[0] == '\0') {
+                std::ostringstream o;
+                o << "unknown_hdr:" << read_count;
+                hdr = o.str();
+            }
+            b.hdrs.push_back(hdr);
+            b.bases.insert(b.bases.end(), read.begin(), read.end());
+            b.off.push_back(b.bases.size());
+        }
+        if (!more) std::cout << "Total reads loaded: " << read_count << std::endl;
+        const size_t n = b.n();
+        if (!n) break;
+        lmat_reads* dr = nullptr;
+        b.bases.push_back(0);
+        if (lmat_reads_upload(ctx, b.bases.data(), b.off.data(), n, &dr) != LMAT_OK) return fail("read upload");
+        res.resize(n);
+        uint64_t ncand = 0;
+        size_t cap = std::max<size_t>(64 * n, 4096);
+        for (;;) {  // grow the candidate buffer until the batch fits
+            cands.resize(cap);
+            int rc = lmat_classify(ctx, dr, 0, n, res.data(), cands.data(), cap, &ncand);
+            if (rc == LMAT_OK) break;
+            if (rc == LMAT_E_CAPACITY && strstr(lmat_last_error(ctx), "cand_cap") && cap < (size_t)1 << 31) { cap *= 4; continue; }
+            return fail("classify");
+        }
+        lmat_reads_free(ctx, dr);
+        // format: contiguous blocks per shard, one thread each
+        std::vector<std::string> text(n_threads);
+        std::vector<std::thread> th;
+        const size_t per = (n + n_threads - 1) / n_threads;
+        for (int t = 0; t < n_threads; ++t) {
+            th.emplace_back([&, t]() {
+                std::string& s = text[t];
+                const size_t lo = std::min(n, t * per), hi = std::min(n, lo + per);
+                s.reserve((hi - lo) * 256);
+                for (size_t i = lo; i < hi; ++i) {
+                    s += b.hdrs[i];
+                    s += '\t';
+                    if (prn_read) s.append((const char*)b.bases.data() + b.off[i], b.off[i + 1] - b.off[i]);
+                    else s += 'X';
+                    s += '\t';
+                    format_call(s, prm, k_size, res[i], cands.data());
+                }
+            });
+        }
+        for (auto& x : th) x.join();
+        for (int t = 0; t < n_threads; ++t) ofs[t] << text[t];
+        // tallies in read order (proc_line :1241-1276), float sums like a -t 1 run
+        for (size_t i = 0; i < n; ++i) {
+            const lmat_read_result& r = res[i];
+            if (r.status == LMAT_ST_SHORT_LEN || r.status == LMAT_ST_SHORT_VALID) nomatch_merge[0] += 1;
+            else if (r.status == LMAT_ST_NODBHITS || r.status == LMAT_ST_SILENT) nomatch_merge[1] += 1;
+            else if (r.status != LMAT_ST_PHIX && r.match_type == LMAT_MT_NOMATCH) nomatch_merge[1] += 1;
+            else if (r.call_score >= min_score) {
+                if (merge_count.find(r.call_tid) == merge_count.end()) { merge_count[r.call_tid] = 1; merge_score[r.call_tid] = r.call_score; }
+                else { merge_count[r.call_tid] += 1; merge_score[r.call_tid] += r.call_score; }
+            } else if (r.call_score < min_score) nomatch_merge[2] += 1;
+        }
+    }
+    for (auto& o : ofs) o.close();
+    std::cout << "Finished classifing reads, doing final steps sequentially..." << std::endl;
+
+    // names for the called taxids from the -u file (:1812-1835)
+    std::set<uint32_t> cand_tid;
+    std::vector<std::pair<uint32_t, float>> sort_val(merge_score.begin(), merge_score.end());
+    for (auto& p : sort_val) cand_tid.insert(p.first);
+    std::map<uint32_t, std::string> save_id;
+    if (!rank_ids.empty()) {
+        std::ifstream ts(rank_ids.c_str());
+        std::string proc;
+        while (std::getline(ts, proc)) {
+            std::vector<char> buff(proc.begin(), proc.end());
+            buff.push_back('\0');
+            char* val = strtok(buff.data(), "=,");
+            while (val != NULL) {
+                if (strcmp(val, "taxid") == 0) {
+                    val = strtok(NULL, "=,");
+                    if (!val) break;
+                    uint32_t cid = (uint32_t)strtoul(val, nullptr, 10);
+                    if (cand_tid.count(cid)) {
+                        size_t pos = proc.rfind('\t');
+                        save_id.insert(std::make_pair(cid, proc.substr(pos + 1)));
+                    }
+                    break;
+                }
+                val = strtok(NULL, "=,");
+            }
+        }
+    }
+    std::string sbase;
+    { std::string t = ofbase; t += '.'; put_float(t, min_score); t += '.'; put_int(t, min_kmer); sbase = t; }
+    {
+        std::ofstream sum_ofs((sbase + ".fastsummary").c_str());
+        if (!sum_ofs) { std::cerr << "ERROR! Could not open for writing " << sbase << ".fastsummary" << std::endl; return -1; }
+        std::cout << "Writing FastSummary file in " << sbase << ".fastsummary" << std::endl;
+        std::sort(sort_val.begin(), sort_val.end(),
+                  [](const std::pair<uint32_t, float>& a, const std::pair<uint32_t, float>& b) { return a.second > b.second; });
+        for (auto& p : sort_val) {
+            std::string s;
+            put_float(s, p.second); s += '\t'; put_int(s, merge_count[p.first]); s += '\t'; put_int(s, p.first); s += '\t';
+            s += save_id[p.first];
+            sum_ofs << s << std::endl;
+        }
+    }
+    {
+        std::ofstream nom_ofs((sbase + ".nomatchsum").c_str());
+        if (!nom_ofs) { std::cerr << "ERROR! Could not open for writing " << sbase << ".nomatchsum" << std::endl; return -1; }
+        std::cout << "Writing NoMatchSum file in " << sbase << ".nomatchsum" << std::endl;
+        static const char* names[3] = {"ReadTooShort", "NoDbHits", "LowScore"};
+        for (auto& p : nomatch_merge) nom_ofs << names[p.first] << "\t" << p.second << std::endl;
+    }
+    lmat_ctx_destroy(ctx);
+    double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::cout << "DONE! Total query time: " << el << " sec = " << el / 60 << " min" << std::endl;
+    return 0;
+}
