@@ -583,7 +583,8 @@ static int rerun_overflow(lmat_ctx* c, const lmat_reads* reads, uint64_t first, 
     uint32_t cur[2];
     HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
     if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read registers more than 1024 taxids");
-    if (cur[1] & kErrCandOverflow) return LMAT_E_CAPACITY;
+    if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
+    if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
     for (uint32_t r : idx)
         HIPCHK(c, hipMemcpy(&host[r - first], c->d_results + (r - first), sizeof(lmat_read_result), hipMemcpyDeviceToHost));
     return LMAT_OK;

@@ -1,0 +1,232 @@
+"""GPU parity, wider cases: reference-pinned lookups, config-1 size, mixed read lengths (U=512 kernel),
+parameter variants, taxid-table overflow re-run, async path, and a full-size sample check (config[1])."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DS = os.path.join(G, "ds")
+
+
+def _blob(reads):
+    bs = [r.encode() for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    return np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8), off
+
+
+def _engine(ds, params=None):
+    from lmat_amd import Engine, Params
+    e = Engine(0, params or Params.run_rl())
+    e.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    e.build_db(ds["db"], k=20)
+    return e
+
+
+def _oracle(ds, **opts):
+    import oracle_py
+    o = oracle_py.Oracle(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    o.add_taxhisto(ds["db"])
+    o.set_options(**opts)
+    return o
+
+
+def _compare(eng, orc, reads, first_index=0, cand_per_read=256):
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    res, cands = eng.classify(dr, cand_cap=max(cand_per_read * len(reads), 4096))
+    got = eng.format_out(res, cands, (blob, off), first_index)
+    want, tally, nm = orc.classify(blob, off, 20, first_index)
+    dr.free()
+    if got != want:
+        g, w = got.split("\n"), want.split("\n")
+        bad = [(i, a, b) for i, (a, b) in enumerate(zip(g, w)) if a != b]
+        raise AssertionError(f"{len(bad)} records differ; first: {bad[0]}")
+    return res, tally, nm
+
+
+def test_gpu_lookup_matches_reference_sorteddb():
+    """The GPU hash returns, for every golden k-mer, what the REFERENCE's SortedDb + TaxNodeStat returned."""
+    ds = {k: os.path.join(DS, v) for k, v in dict(tree="tax.dat", depth="depth.dat", rank="rank.txt",
+                                                  idmap="map32to16.txt", db="th.bin").items()}
+    eng = _engine(ds)
+    kms, want = [], []
+    for line in open(os.path.join(G, "ref_lookup.txt")):
+        f = line.split()
+        kms.append(int(f[0]))
+        want.append([int(x) for x in f[2:]])
+    counts, tids = eng.lookup(np.array(kms, dtype=np.uint64), stride=32)
+    for i, w in enumerate(want):
+        assert counts[i] == len(w)
+        assert tids[i, :len(w)].tolist() == w
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def config1(tmp_path_factory):
+    """BASELINE config 1: 10 k reads vs a ~1 M k-mer (10 MB) DB; read lengths mixed 75-300 so the
+    512-k-mer kernel class runs too."""
+    from lmat_amd import synth
+    d = tmp_path_factory.mktemp("cfg1")
+    info = synth.generate_dataset(str(d), (2, 2, 2, 2, 3, 3), 13400, 10000, L=(75, 100, 125, 150, 200, 250, 300),
+                                  frac_short=0.01, lower_frac=0.02)
+    info["reads"] = [l.rstrip("\n") for l in open(info["fasta"]) if not l.startswith(">")]
+    return info
+
+
+def test_config1_text_parity(config1):
+    assert 0.8e6 < config1["n_kmers"] < 1.3e6
+    eng = _engine(config1)
+    orc = _oracle(config1)
+    eng.counts_reset()
+    res, tally, nm = _compare(eng, orc, config1["reads"])
+    counts, nomatch = eng.counts()
+    assert nomatch == nm
+    assert {t: c for t, (c, s) in counts.items()} == {t: c for t, (c, s) in tally.items()}
+    st = np.bincount(res["status"], minlength=6)
+    assert st[0] > 5000 and st[4] > 300  # calls and NoDbHits both well represented
+    kinds = np.bincount(res["match_type"][res["status"] == 0], minlength=5)
+    assert kinds[0] > 100 and kinds[1] > 100  # DirectMatch and MultiMatch
+    orc.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("variant", ["no_p", "hbias3", "phix_off", "strict"])
+def test_parameter_variants(config1, variant):
+    from lmat_amd import Params
+    p = Params.run_rl()
+    o = dict(sdiff=1.0, hbias=0.0, prn_all=1, screen_phix=1, min_score=0.0, min_kmer=30, min_fnd_kmer=1)
+    if variant == "no_p":
+        p.prn_all, o["prn_all"] = 0, 0
+    elif variant == "hbias3":
+        p.hbias, o["hbias"] = 3.0, 3.0
+    elif variant == "phix_off":
+        p.screen_phix, o["screen_phix"] = 0, 0
+    else:
+        p.sdiff, p.min_kmer, p.min_score, p.min_fnd_kmer = 0.25, 35, 0.3, 3
+        o.update(sdiff=0.25, min_kmer=35, min_score=0.3, min_fnd_kmer=3)
+    eng = _engine(config1, p)
+    orc = _oracle(config1, **o)
+    eng.counts_reset()
+    res, tally, nm = _compare(eng, orc, config1["reads"][:3000])
+    counts, nomatch = eng.counts()
+    assert nomatch == nm and {t: c for t, (c, s) in counts.items()} == {t: c for t, (c, s) in tally.items()}
+    orc.close()
+    eng.close()
+
+
+def test_special_taxids_are_exercised(config1):
+    """The dataset must actually reach the human / PhiX / plasmid branches the parity tests claim to cover."""
+    orc = _oracle(config1)
+    blob, off = _blob(config1["reads"])
+    text, tally, nm = orc.classify(blob, off, 20)
+    assert 9606 in tally and tally[9606][0] > 10          # human call (with 63221 folded in)
+    assert 32630 in tally                                  # PhiX short-circuit
+    assert any(10000000 <= t < 11000000 for t in tally)    # plasmid override
+    orc.close()
+
+
+def test_taxid_table_overflow_rerun(tmp_path):
+    """A k-mer whose list keeps > 128 taxids overflows the fast kernel's table; the engine re-runs the read
+    with the 1024-entry kernel on the GPU and still matches the oracle.  > 1024 is a loud capacity error."""
+    from lmat_amd import synth, LmatError
+    tax = synth.make_taxonomy((3, 4, 4, 4, 4, 3), specials=False)
+    p = synth.write_aux_files(str(tmp_path), tax)
+    leaves = tax.leaves[:6]
+    tax.leaves = leaves
+    genomes = synth.make_genomes(tax, 400, 2002)
+    kmers, lists = synth.build_kmer_table(tax, genomes, 20, extra_lists=False)
+    all_strains = [t for t in tax.ids if tax.rank[t] == "strain"]
+    reads = synth.make_reads(tax, genomes, 40, 150, 3003, err=0.0, frac_random=0.0, frac_n=0.0, frac_lowc=0.0)
+    orc_tmp = __import__("oracle_py").Oracle(p["tree"], p["depth"], p["rank"], p["idmap"])
+    km0 = orc_tmp.extract(reads[0][1].encode(), 20)[0]
+    km1 = orc_tmp.extract(reads[1][1].encode(), 20)[0]
+    orc_tmp.close()
+    idx = {int(k): i for i, k in enumerate(kmers.tolist())}
+    for j, km in enumerate(km0[:3].tolist()):
+        lists[idx[km]] = all_strains[100 * j:100 * j + 300]
+    p["db"] = os.path.join(str(tmp_path), "th.bin")
+    synth.write_taxhisto(p["db"], kmers, lists, 20)
+    eng = _engine(p)
+    orc = _oracle(p)
+    res, _, _ = _compare(eng, orc, [r for _, r in reads], cand_per_read=2048)
+    assert res["n_cand"].max() > 128
+    eng.close()
+    orc.close()
+    # > 1024 kept taxids: capacity error, not a wrong answer
+    lists[idx[int(km1[0])]] = all_strains[:1500]
+    synth.write_taxhisto(p["db"], kmers, lists, 20)
+    eng = _engine(p)
+    blob, off = _blob([r for _, r in reads])
+    dr = eng.upload_reads((blob, off))
+    with pytest.raises(LmatError) as ei:
+        eng.classify(dr)
+    assert ei.value.code == -4
+    eng.close()
+
+
+def test_async_and_calls_only_agree_with_full_output(config1):
+    from lmat_amd import Params
+    eng = _engine(config1)
+    reads = config1["reads"][:4000]
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    res, _ = eng.classify(dr)
+    eng.set_params(Params.run_rl(prn_all=0))
+    eng.classify_async(dr, 0, len(reads))
+    ms, launches = eng.sync()
+    res2 = eng.fetch_results(0, len(reads))
+    for f in ("status", "match_type", "cand_kmer_cnt", "valid_kmers", "call_tid", "bin_sel"):
+        assert (res[f] == res2[f]).all(), f
+    assert (res["call_score"].view(np.uint32) == res2["call_score"].view(np.uint32)).all()
+    assert (res["stdev"].view(np.uint32) == res2["stdev"].view(np.uint32)).all()
+    assert launches == 1 and ms > 0
+    dr.free()
+    eng.close()
+
+
+def test_full_size_sample_parity(tmp_path):
+    """BASELINE config[1] (1 M reads vs an 8 GB DB; LMAT_TEST_DB_GB overrides): the whole batch runs on the GPU;
+    a 20 k-read sample is re-derived by the CPU oracle from the GPU table's own lookups and must match byte for
+    byte; size-independent properties are checked on all reads."""
+    from lmat_amd import Engine, Params, synth
+    import oracle_py
+    gb = float(os.environ.get("LMAT_TEST_DB_GB", "8"))
+    n_reads = int(os.environ.get("LMAT_TEST_READS", "1000000"))
+    br = (3, 4, 4, 4, 4, 3)
+    eng = Engine(0, Params.run_rl())
+    eng.synth_taxonomy(br)
+    table_bytes = int(gb * (1 << 30))
+    Glen = int(0.8 * (table_bytes / 8) / (768 * (1.0 + 3 * (1 - 0.99 ** 20))))
+    eng.synth_db(Glen, k=20, seed=2002, table_bytes=table_bytes)
+    assert eng.db_size > 0.7 * table_bytes / 8
+    reads = eng.synth_reads(n_reads, (150,), seed=3003)
+    eng.counts_reset()
+    res, cands = eng.classify(reads, cand_cap=40 * n_reads)
+    counts, nomatch = eng.counts()
+    st = np.bincount(res["status"], minlength=6)
+    assert st.sum() == n_reads and st[0] > 0.8 * n_reads
+    assert sum(c for c, _ in counts.values()) + sum(nomatch) == n_reads
+    assert (res["valid_kmers"][res["status"] == 0] >= 30).all()
+    # genome-sampled reads without N: every k-mer is valid
+    assert (res["valid_kmers"] == 131).mean() > 0.97
+    # sample parity through the oracle
+    ns = 20000
+    tax = synth.make_taxonomy(br, specials=False)
+    p = synth.write_aux_files(str(tmp_path), tax)
+    orc = oracle_py.Oracle(p["tree"], p["depth"], p["rank"], p["idmap"])
+    orc.set_k(20)
+    orc.set_options()
+    blob, off = reads.ascii(0, ns)
+    kms = np.unique(np.concatenate([orc.extract(bytes(blob[int(off[i]):int(off[i + 1])]), 20)[0] for i in range(ns)]))
+    cnts, tids = eng.lookup(kms, stride=8)
+    assert (cnts > 0).mean() > 0.5 and cnts.max() <= 4
+    orc.add_lists32(kms, cnts, tids)
+    want, _, _ = orc.classify(np.append(blob, np.uint8(0)), off, 20)
+    got = eng.format_out(res[:ns], cands, (np.append(blob, np.uint8(0)), off))
+    assert got == want
+    orc.close()
+    reads.free()
+    eng.close()
