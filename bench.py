@@ -168,10 +168,8 @@ def main():
     for s in range(args.steps):
         eng.classify_async(reads, (args.warmup + s) * args.batch, args.batch)
     kernel_ms, launches = eng.sync()
-    if dist is not None:  # merge step of read_label.cpp:1760-1800
-        dist.all_reduce(t_cnt)
-        dist.all_reduce(t_sc)
-        dist.all_reduce(t_nm)
+    from lmat_amd.shard import allreduce_tallies
+    allreduce_tallies(t_cnt, t_sc, t_nm, dist)  # merge step of read_label.cpp:1760-1800
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
