@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblmat_hip.so")
+LIB_PATH = os.environ.get("LMAT_LIB") or os.path.join(_HERE, "liblmat_hip.so")  # LMAT_LIB: A/B builds when profiling
 
 
 class LmatError(RuntimeError):

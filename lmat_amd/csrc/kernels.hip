@@ -21,6 +21,19 @@ namespace lmat {
         __builtin_amdgcn_wave_barrier();                     \
     } while (0)
 
+// Pointers that arrive inside a by-value struct are "generic" to the compiler, which then emits flat_load
+// (counted on lgkmcnt as well, so every LDS wait also waits for HBM).  The classify kernel therefore
+// re-types every device pointer into address space 1 (global) up front.
+#define GAS __attribute__((address_space(1)))
+#define G_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define G_OR(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+__device__ __forceinline__ void store_result(GAS uint64_t* dst, const lmat_read_result& r) {
+    static_assert(sizeof(lmat_read_result) == 40, "result record is 5 x 8 bytes");
+    uint64_t w[5];
+    __builtin_memcpy(w, &r, 40);
+    dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3]; dst[4] = w[4];
+}
+
 __device__ __forceinline__ uint64_t lt_mask(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 __device__ __forceinline__ uint32_t hash32(uint64_t x) {
@@ -285,25 +298,32 @@ __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmer
 //   U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in
 //   registered taxids.  Regions are reused across phases (see classify_one).
 // ------------------------------------------------------------------------------------------
-struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351)
+struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351), 16 bytes
     uint16_t tid;
     uint16_t flag;  // bit0: member of no_good
     float score;
+    uint16_t dep, tin, tout, pad;
 };
 
-template <int U, int T>
+// U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in registered
+// taxids, E = capacity in kept-list elements summed over the read's distinct payloads.
+// Regions are reused across phases (see classify_one).
+template <int U, int T, int E>
 struct WL {
     static constexpr int H = 2 * U;    // k-mer / payload hash slots (power of two)
     static constexpr int TH = 4 * T;   // taxid hash slots: <= T registered + <= T unregistered species keys
     static constexpr int LIN = T + 72; // lineage scratch entries
     static constexpr int RD_WORDS = (U + 96) / 16 + (U + 96) / 32 + 4;
-    static constexpr int R1_HASH = 8 * H + 4 * H;                  // u64 hv[H], u32 haux[H]
-    static constexpr int R1_TID = 2 * T * 6 + 4 * T + 4 * TH + 4 * TH;  // reg,cnt,leaf,stamp,dep,ord | score | hent | best
+    static constexpr int R1_HASH = 8 * H + 4 * H;                      // u64 hv[H], u32 haux[H]
+    static constexpr int R1_TID = 12 * T + 4 * T + 4 * T + T + 4 * TH + 4 * TH;
     static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
-    static constexpr int R2_K = 8 * U + 4 * U;                     // ukmer, ubucket
-    static constexpr int R2_D = 4 * U + 4 * U + 8 * LIN;           // dpay, dmult, lineage
-    static constexpr int R2 = R2_K > R2_D ? R2_K : R2_D;
-    static constexpr int R3 = 4 * U;                               // upay
+    static constexpr int R2_K = 8 * U + 4 * U;                         // ukmer, ubucket
+    static constexpr int R2_D = 4 * U + 2 * U + 2 * U + 2 * U + U;     // dpay, dmult, dn, dstart, dfl
+    static constexpr int R2_L = 16 * LIN;                              // lineage (K4, after the d-arrays die)
+    static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
+    static constexpr int R3_P = 4 * U;                                 // upay
+    static constexpr int R3_E = 16 * E;                                // element staging
+    static constexpr int R3 = R3_P > R3_E ? R3_P : R3_E;
     static constexpr int OFF_RD = 0;
     static constexpr int OFF_R1 = ((RD_WORDS * 4 + 15) / 16) * 16;
     static constexpr int OFF_R2 = OFF_R1 + ((R1 + 15) / 16) * 16;
@@ -334,7 +354,8 @@ __device__ __forceinline__ uint32_t lds_find(const unsigned long long* hv, int h
     return h;
 }
 
-// taxid hash entry: low 16 bits = taxid index (0 = empty), high 16 = registration slot or 0xFFFF
+// taxid hash entry: low 16 bits = taxid index (0 = empty); high 16 bits = registration slot (< 0x8000),
+// 0x8000|lane while a chunk decides who registers it, 0xFFFF = known key, not registered
 __device__ __forceinline__ uint32_t tid_hash(uint32_t t, int thmask) { return ((t * 0x9E3779B1u) >> 12) & thmask; }
 __device__ __forceinline__ uint32_t tid_find_or_claim(unsigned int* hent, int thmask, uint32_t t) {
     uint32_t h = tid_hash(t, thmask);
@@ -357,20 +378,20 @@ __device__ __forceinline__ int tid_find(const unsigned int* hent, int thmask, ui
         h = (h + 1) & thmask;
     }
 }
-// registration slot of taxid t, or -1 when t is not registered
 __device__ __forceinline__ int tid_slot(const unsigned int* hent, int thmask, uint32_t t) {
     const int h = tid_find(hent, thmask, t);
     if (h < 0) return -1;
     const uint32_t s = hent[h] >> 16;
-    return s == 0xFFFFu ? -1 : (int)s;
+    return s >= 0x8000u ? -1 : (int)s;
+}
+// u16 counters packed two per dword so LDS atomics can add to them (sums stay below 65536)
+__device__ __forceinline__ void add_u16(uint16_t* arr, uint32_t idx, uint32_t v) {
+    atomicAdd((unsigned int*)arr + (idx >> 1), (idx & 1) ? (v << 16) : v);
 }
 
-// isAncestor (read_label.cpp:138-150): a is on b's path to root (b itself excluded).
-__device__ __forceinline__ bool is_ancestor(const DeviceTables& tb, uint32_t a, uint32_t b) {
-    if (b == 0) return false;
-    const uint32_t la = tb.path_len[a], lb = tb.path_len[b];
-    if (lb <= la) return false;
-    return tb.paths[tb.path_off[b] + (lb - la - 1)] == a;
+// isAncestor (read_label.cpp:138-150) on Euler-tour intervals: a is a proper ancestor of b
+__device__ __forceinline__ bool anc_iv(uint32_t tin_a, uint32_t tout_a, uint32_t tin_b, uint32_t tout_b) {
+    return tin_a < tin_b && tout_b <= tout_a;
 }
 
 struct TCmpDev {  // TCmp, read_label.cpp:475-485
@@ -383,20 +404,24 @@ struct TCmpDev {  // TCmp, read_label.cpp:475-485
     }
 };
 struct CmpDepthDev {  // CmpDepth, read_label.cpp:159-167
-    const uint16_t* fdepth;
-    __device__ bool operator()(const LinEnt& a, const LinEnt& b) const { return (int)fdepth[a.tid] > (int)fdepth[b.tid]; }
+    __device__ bool operator()(const LinEnt& a, const LinEnt& b) const { return (int)a.dep > (int)b.dep; }
 };
 
-// K4, executed by lane 0.  cnt[]/reg[] are final, registration order = slot order.
-template <int U, int T>
-__device__ void decide_read(const ClassifyArgs& A, lmat_read_result& res, const uint16_t* reg, const uint16_t* cnt,
-                            float* score, const uint16_t* dep, uint16_t* ord, const unsigned int* hent, LinEnt* lin,
-                            int nT, uint32_t cand, lmat_cand* cand_out, uint32_t* n_cand_out, uint32_t* call_idx_out,
-                            uint32_t* errflags) {
-    const KernelParams& P = A.prm;
-    const DeviceTables& tb = A.tb;
-    constexpr int THM = WL<U, T>::TH - 1;
-    // --- scores and running sums in registration order, read_label.cpp:748-764,803-837
+// K4 state that lives in lane 0's registers between the two sequential parts
+struct K4State {
+    float top_score, diff_thresh;
+    int lidx, nlin, lowest, highest;
+    unsigned highest_depth;
+    int plasmid_slot;  // slot of the saved top-hit plasmid or -1
+    bool done;         // PhiX short-circuit taken
+};
+
+// K4 part 1 (lane 0): scores, running sums, PhiX screen, mean/stdev, human bias, TCmp sort, lineage
+// building loop of findReadLabelVer2.  read_label.cpp:748-764, 803-893, 295-325.
+template <int LIN>
+__device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& S, const uint16_t* cnt, float* score,
+                         const uint16_t* dep, const uint8_t* sflags, const uint16_t* tin, const uint16_t* tout,
+                         const uint16_t* reg, uint16_t* ord, LinEnt* lin, int nT, uint32_t cand) {
     bool fnd_phix = false, has_human = false;
     float log_sum = 0.0f, pos_log_sum = 0.0f, top_score = 0.0f, phix_score = 0.0f;
     unsigned sig_hits = 0, pos_sig_hits = 0;
@@ -404,7 +429,7 @@ __device__ void decide_read(const ClassifyArgs& A, lmat_read_result& res, const 
     for (int s = 0; s < nT; ++s) {
         const float sc = (float)cnt[s] / fcand;
         score[s] = sc;
-        const uint8_t fl = tb.flags[reg[s]];
+        const uint8_t fl = sflags[s];
         if (fl & kFlagHuman) has_human = true;
         log_sum += sc;
         sig_hits++;
@@ -413,16 +438,16 @@ __device__ void decide_read(const ClassifyArgs& A, lmat_read_result& res, const 
         if (s == 0 || sc > top_score) top_score = sc;
     }
     res.cand_kmer_cnt = (uint16_t)cand;
-    *n_cand_out = 0;
+    S.done = false;
+    S.top_score = top_score;
     if (P.screen_phix && phix_score >= top_score && fnd_phix) {  // :841-848
         res.status = LMAT_ST_PHIX;
         res.match_type = LMAT_MT_DIRECT;
         res.call_tid = 32630;
         res.call_score = phix_score;
-        *call_idx_out = A.phix_call_idx;
+        S.done = true;
         return;
     }
-    // --- mean / stdev, :850-881
     unsigned use_sig_hits;
     float log_avg;
     if (pos_sig_hits > 3) { use_sig_hits = pos_sig_hits; log_avg = pos_log_sum / (float)pos_sig_hits; }
@@ -437,94 +462,81 @@ __device__ void decide_read(const ClassifyArgs& A, lmat_read_result& res, const 
     res.status = LMAT_ST_CALL;
     res.log_avg = log_avg;
     res.stdev = stdev1;
-    // --- human bias, sort by TCmp, :883-893
-    if (has_human) {
+    if (has_human) {  // :883-891
         for (int s = 0; s < nT; ++s)
-            if (tb.flags[reg[s]] & kFlagHuman) score[s] += (P.hbias * stdev1);
+            if (sflags[s] & kFlagHuman) score[s] += (P.hbias * stdev1);
     }
     for (int s = 0; s < nT; ++s) ord[s] = (uint16_t)s;
-    ss_sort(ord, nT, TCmpDev{score, dep});
-    const float diff_thresh = stdev1 * P.sdiff;  // :895
-
-    // --- findReadLabelVer2, :284-419
-    uint8_t match = LMAT_MT_NOMATCH;
-    uint32_t save_plasmid = 0;
-    bool plasmid_top = false;
+    ss_sort(ord, nT, TCmpDev{score, dep});  // :892-893
+    S.diff_thresh = stdev1 * P.sdiff;       // :895
+    // findReadLabelVer2 :287-325
+    S.plasmid_slot = -1;
     unsigned lowest_depth = 0, highest_depth = 0;
-    int lowest = -1, highest = -1;  // slots
-    int lidx = -1;
+    int lowest = -1, highest = -1, lidx = -1, nlin = 0;
     bool lin_done = false;
-    int nlin = 0;
     for (int i = nT - 1; i >= 0; --i) {
         const int s = ord[i];
-        const uint32_t t = reg[s];
-        if (score[s] >= top_score && (tb.flags[t] & kFlagPlasmid)) { plasmid_top = true; save_plasmid = t; }
+        if (score[s] >= top_score && (sflags[s] & kFlagPlasmid)) S.plasmid_slot = s;
         if (!lin_done) {
             bool add = true;  // addToCandLineage :225-262
             const unsigned cd = dep[s];
+            const uint32_t ti = tin[s], to = tout[s];
             for (int j = 0; j < nlin; ++j) {
-                const uint32_t lt = lin[j].tid;
-                const unsigned chk = tb.fdepth[lt];
-                if (chk > cd && !is_ancestor(tb, t, lt)) { add = false; break; }
-                else if (chk < cd && !is_ancestor(tb, lt, t)) { add = false; break; }
+                const unsigned chk = lin[j].dep;
+                if (chk > cd && !anc_iv(ti, to, lin[j].tin, lin[j].tout)) { add = false; break; }
+                else if (chk < cd && !anc_iv(lin[j].tin, lin[j].tout, ti, to)) { add = false; break; }
                 else if (chk == cd) { add = false; break; }
             }
             if (!add) {
                 lidx = i;
                 lin_done = true;
             } else {
-                lin[nlin].tid = (uint16_t)t; lin[nlin].flag = 0; lin[nlin].score = score[s];
-                ++nlin;
+                LinEnt e;
+                e.tid = reg[s]; e.flag = 0; e.score = score[s]; e.dep = (uint16_t)cd; e.tin = (uint16_t)ti; e.tout = (uint16_t)to; e.pad = 0;
+                lin[nlin++] = e;
                 if (cd > lowest_depth || i == nT - 1) { lowest = s; lowest_depth = cd; }
                 if (cd < highest_depth || i == nT - 1) { highest = s; highest_depth = cd; }
             }
         }
         if (lin_done && score[s] < top_score) break;
     }
-    // ancestors of the shallowest accepted node, :326-343 (all_cand_set holds pre-bias scores)
-    const uint32_t high_tid = highest >= 0 ? reg[highest] : 0;
-    const bool have_add = highest_depth != 0 && high_tid != 0;
-    if (have_add) {
-        const int anc_len = tb.path_len[high_tid];
-        const uint32_t off = tb.path_off[high_tid];
-        for (int j = 0; j < anc_len; ++j) {
-            if (nlin >= WL<U, T>::LIN) { atomicOr(errflags, (uint32_t)kErrLineageTrunc); break; }
-            const uint32_t a = tb.paths[off + j];
-            const int s = tid_slot(hent, THM, a);
-            lin[nlin].tid = (uint16_t)a; lin[nlin].flag = 0;
-            lin[nlin].score = s >= 0 ? (float)cnt[s] / fcand : -10000.0f;
-            ++nlin;
-        }
-    }
-    // without -p, MultiMatch prints cand_lin in list order (:917-927): save it before sorting
+    S.lidx = lidx; S.nlin = nlin; S.lowest = lowest; S.highest = highest; S.highest_depth = highest_depth;
+}
+
+// K4 part 2 (lane 0): lineage sort, competitor scan, call, candidate list.  read_label.cpp:344-419, 898-937.
+__device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_read_result& res, const K4State& S,
+                         const float* score, const uint16_t* tin, const uint16_t* tout, const uint16_t* reg,
+                         const uint16_t* ord, const unsigned int* hent, int thmask, LinEnt* lin, int nlin, int nT,
+                         bool have_add, uint32_t high_tin, uint32_t high_tout, GAS lmat_cand* cand_out,
+                         uint32_t* n_cand_out, uint32_t* call_idx_out) {
     const int nlin_total = nlin;
-    if (!P.prn_all && cand_out) {
-        for (int j = 0; j < nlin; ++j) { cand_out[j].tid = tb.tid32[lin[j].tid]; cand_out[j].score = lin[j].score; }
+    if (!P.prn_all && cand_out) {  // without -p, MultiMatch prints cand_lin in list order (:917-927)
+        for (int j = 0; j < nlin; ++j) { cand_out[j].tid = tid32[lin[j].tid]; cand_out[j].score = lin[j].score; }
     }
-    ss_sort(lin, nlin, CmpDepthDev{tb.fdepth});  // :344-351
-    // competitors, :355-362 with cmpCompLineage :264-282
+    ss_sort(lin, nlin, CmpDepthDev{});  // :344-351
     bool any_no_good = false;
-    for (int i = lidx; i >= 0; --i) {
+    for (int i = S.lidx; i >= 0; --i) {  // :355-362, cmpCompLineage :264-282
         const int s = ord[i];
-        const uint32_t t = reg[s];
-        if (have_add && is_ancestor(tb, t, high_tid)) continue;  // member of add_set
+        const uint32_t ti = tin[s], to = tout[s];
+        if (have_add && anc_iv(ti, to, high_tin, high_tout)) continue;  // member of add_set
         bool keep_going = true;
         const float cs = score[s];
         for (int j = 0; j < nlin; ++j) {
-            if (is_ancestor(tb, lin[j].tid, t)) break;
+            if (anc_iv(lin[j].tin, lin[j].tout, ti, to)) break;
             const float ls = lin[j].score;
-            if (ls != -10000.0f && (ls - cs) > diff_thresh) { keep_going = false; break; }
-            if ((ls - cs) <= diff_thresh) { lin[j].flag |= 1; any_no_good = true; }
+            if (ls != -10000.0f && (ls - cs) > S.diff_thresh) { keep_going = false; break; }
+            if ((ls - cs) <= S.diff_thresh) { lin[j].flag |= 1; any_no_good = true; }
         }
         if (!keep_going) break;
     }
-    uint32_t call_tid = 0;
+    uint8_t match = LMAT_MT_NOMATCH;
+    uint32_t call_tid = 0, call_tin = 0xFFFF, call_tout = 0xFFFF;
     float call_score = 0;
     if (nlin == 0 && !any_no_good) {
         match = LMAT_MT_NOMATCH;
     } else if (nlin > 0 && !any_no_good) {
-        call_tid = reg[lowest];
-        call_score = score[lowest];
+        call_tid = reg[S.lowest]; call_tin = tin[S.lowest]; call_tout = tout[S.lowest];
+        call_score = score[S.lowest];
         match = LMAT_MT_DIRECT;
     } else {
         float max_val = -10000.0f;
@@ -534,21 +546,22 @@ __device__ void decide_read(const ClassifyArgs& A, lmat_read_result& res, const 
             if (!(lin[j].flag & 1)) { root_idx = j; break; }
         }
         if (root_idx < 0) {
-            // LCA_ERROR: construct_labels leaves best_guess at (0,0) (:931-936)
-            call_tid = 0; call_score = 0; match = LMAT_MT_LCA_ERROR;
+            match = LMAT_MT_LCA_ERROR;  // construct_labels leaves best_guess at (0,0), :931-936
         } else {
             match = LMAT_MT_MULTI;
             const uint32_t lca = lin[root_idx].tid;
-            if (tid_slot(hent, THM, lca) >= 0) {
+            if (tid_slot(hent, thmask, lca) >= 0) {
                 if (max_val < lin[root_idx].score) { match = LMAT_MT_PARTIAL; max_val = lin[root_idx].score; }
             }
-            call_tid = lca;
+            call_tid = lca; call_tin = lin[root_idx].tin; call_tout = lin[root_idx].tout;
             call_score = max_val;
         }
     }
-    if (plasmid_top && match != LMAT_MT_LCA_ERROR && is_ancestor(tb, call_tid, save_plasmid)) call_tid = save_plasmid;
+    if (S.plasmid_slot >= 0 && match != LMAT_MT_LCA_ERROR && match != LMAT_MT_NOMATCH &&
+        anc_iv(call_tin, call_tout, tin[S.plasmid_slot], tout[S.plasmid_slot]))
+        call_tid = reg[S.plasmid_slot];  // :410-416
     res.match_type = match;
-    res.call_tid = call_tid ? tb.tid32[call_tid] : 0;
+    res.call_tid = call_tid ? tid32[call_tid] : 0;
     res.call_score = call_score;
     *call_idx_out = call_tid;
     uint32_t ncand = 0;
@@ -556,7 +569,7 @@ __device__ void decide_read(const ClassifyArgs& A, lmat_read_result& res, const 
         if (cand_out) {
             for (int i = nT - 1; i >= 0; --i) {
                 const int s = ord[i];
-                if (score[s] >= 0) { cand_out[ncand].tid = tb.tid32[reg[s]]; cand_out[ncand].score = score[s]; ++ncand; }
+                if (score[s] >= 0) { cand_out[ncand].tid = tid32[reg[s]]; cand_out[ncand].score = score[s]; ++ncand; }
             }
         }
     } else if ((match == LMAT_MT_MULTI || match == LMAT_MT_PARTIAL) && cand_out) {
@@ -571,51 +584,78 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
     lo |= nl;
 }
 
-template <int U, int T>
-__device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane) {
-    using L = WL<U, T>;
+template <int U, int T, int E>
+__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane) {
+    using L = WL<U, T, E>;
+    constexpr int THM = L::TH - 1;
     uint32_t* rd = (uint32_t*)(lds + L::OFF_RD);
-    // hash phase views of R1
+    // R1, hash phases
     unsigned long long* hv = (unsigned long long*)(lds + L::OFF_R1);
     unsigned int* haux = (unsigned int*)(lds + L::OFF_R1 + 8 * L::H);
-    // taxid phase views of R1
+    // R1, taxid phase
     uint16_t* reg = (uint16_t*)(lds + L::OFF_R1);
-    uint16_t* cnt = reg + T;
-    uint16_t* leaf = cnt + T;
-    uint16_t* stamp = leaf + T;
-    uint16_t* dep = stamp + T;
+    uint16_t* dep = reg + T;
     uint16_t* ord = dep + T;
-    float* score = (float*)(ord + T);
-    unsigned int* hent = (unsigned int*)(score + T);
+    uint16_t* tin = ord + T;
+    uint16_t* tout = tin + T;
+    uint16_t* stamp = tout + T;
+    uint16_t* cnt = stamp + T;
+    uint16_t* leaf = cnt + T;
+    float* score = (float*)(leaf + T);
+    uint8_t* sflags = (uint8_t*)(score + T);
+    unsigned int* hent = (unsigned int*)(sflags + T);
     unsigned int* best = hent + L::TH;
-    // R2: k-mer phase, then distinct payloads + lineage scratch
+    // R2: k-mers, then per-distinct-payload arrays, then the lineage scratch
     unsigned long long* ukmer = (unsigned long long*)(lds + L::OFF_R2);
     uint32_t* ubucket = (uint32_t*)(lds + L::OFF_R2 + 8 * U);
     uint32_t* dpay = (uint32_t*)(lds + L::OFF_R2);
-    uint32_t* dmult = (uint32_t*)(lds + L::OFF_R2 + 4 * U);
-    LinEnt* lin = (LinEnt*)(lds + L::OFF_R2 + 8 * U);
+    uint16_t* dmult = (uint16_t*)(lds + L::OFF_R2 + 4 * U);
+    uint16_t* dn = dmult + U;
+    uint16_t* dstart = dn + U;
+    uint8_t* dfl = (uint8_t*)(dstart + U);
+    LinEnt* lin = (LinEnt*)(lds + L::OFF_R2);
+    // R3: payload per distinct k-mer, then the staged kept-list elements
     uint32_t* upay = (uint32_t*)(lds + L::OFF_R3);
+    uint32_t* el_poff = (uint32_t*)(lds + L::OFF_R3);
+    uint16_t* el_t = (uint16_t*)(el_poff + E);   // kept id, registration order
+    uint16_t* el_ta = el_t + E;                  // kept id, ascending order (closure order)
+    uint16_t* el_d = el_ta + E;                  // owning distinct-payload index
+    uint16_t* el_sp = el_d + E;                  // species_of[ta]
+    uint16_t* el_plen = el_sp + E;               // path_len[ta]
+    uint8_t* el_fl = (uint8_t*)(el_plen + E);    // flags[ta]
 
     const DeviceTables& tb = A.tb;
     const int k = tb.k;
-    const uint32_t* rec = A.words + A.rec_off[r];
+    const GAS uint64_t* g_slots = (const GAS uint64_t*)tb.slots;
+    const GAS uint16_t* g_arena = (const GAS uint16_t*)tb.arena;
+    const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
+    const GAS uint16_t* g_fdepth = (const GAS uint16_t*)tb.fdepth;
+    const GAS uint8_t* g_flags = (const GAS uint8_t*)tb.flags;
+    const GAS uint16_t* g_species_of = (const GAS uint16_t*)tb.species_of;
+    const GAS uint32_t* g_path_off = (const GAS uint32_t*)tb.path_off;
+    const GAS uint16_t* g_path_len = (const GAS uint16_t*)tb.path_len;
+    const GAS uint16_t* g_paths = (const GAS uint16_t*)tb.paths;
+    const GAS uint16_t* g_tin = (const GAS uint16_t*)tb.tin;
+    const GAS uint16_t* g_tout = (const GAS uint16_t*)tb.tout;
+    GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    const GAS uint32_t* rec = (const GAS uint32_t*)A.words + ((const GAS uint64_t*)A.rec_off)[r];
     const uint32_t len = rec[0];
     lmat_read_result res;
     res.status = LMAT_ST_NODBHITS; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = 0;
     res.read_len = (int)len; res.log_avg = 0; res.stdev = 0; res.call_tid = 0; res.call_score = 0;
     res.cand_off = 0; res.n_cand = 0; res.bin_sel = 0;
-    lmat_read_result* out = A.results + (r - A.result_base);
-    unsigned long long* tally_count = (unsigned long long*)A.counts;
-    double* tally_score = (double*)(tally_count + tb.n_ids);
-    unsigned long long* tally_nomatch = (unsigned long long*)(tally_score + tb.n_ids);
+    GAS uint64_t* out = (GAS uint64_t*)(A.results + (r - A.result_base));
+    GAS unsigned long long* tally_count = (GAS unsigned long long*)A.counts;
+    GAS double* tally_score = (GAS double*)(tally_count + tb.n_ids);
+    GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + tb.n_ids);
 
     if ((int)len < k) {  // proc_line :1217-1223
-        if (lane == 0) { res.status = LMAT_ST_SHORT_LEN; *out = res; atomicAdd(&tally_nomatch[0], 1ull); }
+        if (lane == 0) { res.status = LMAT_ST_SHORT_LEN; store_result(out, res); G_ADD(&tally_nomatch[0], 1ull); }
         return;
     }
     const uint32_t P = len - k + 1;
     if (P > (uint32_t)U) {  // the host sizes U from the batch's longest read
-        if (lane == 0) { res.status = 255; *out = res; atomicOr(&A.cursor[1], (uint32_t)kErrReadTooLong); }
+        if (lane == 0) { res.status = 255; store_result(out, res); G_OR(&g_cursor[1], (uint32_t)kErrReadTooLong); }
         return;
     }
     // ---- packed record -> LDS (coalesced), zero tail so windows past the end are invalid
@@ -681,9 +721,10 @@ __device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* l
         res.bin_sel = (int)(gc_pcnt / 10.0f);
     }
     if (valid_kmers < A.prm.min_kmer) {  // proc_line :1232-1238
-        if (lane == 0) { res.status = LMAT_ST_SHORT_VALID; *out = res; atomicAdd(&tally_nomatch[0], 1ull); }
+        if (lane == 0) { res.status = LMAT_ST_SHORT_VALID; store_result(out, res); G_ADD(&tally_nomatch[0], 1ull); }
         return;
     }
+    if (A.prm.stop_after == 1) { if (lane == 0) { res.status = 250; store_result(out, res); } return; }
     // ---- K1 pass 2: compact first occurrences in position order
     uint32_t nuniq = 0;
     for (uint32_t p0 = 0; p0 < P; p0 += 64) {
@@ -704,11 +745,12 @@ __device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* l
         nuniq += popc64(bm);
     }
     WSYNC();
+    if (A.prm.stop_after == 2) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nuniq; store_result(out, res); } return; }
     // ---- K2: probe.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets;
     //      8 loads are issued back to back before the first is consumed.
     {
         const int g = lane >> 3, sub = lane & 7;
-        const uint64_t* __restrict__ slots = tb.slots;
+        const GAS uint64_t* slots = g_slots;
         for (uint32_t base = 0; base < nuniq; base += 64) {
             unsigned long long sl[8];
             uint32_t bk[8];
@@ -742,6 +784,7 @@ __device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* l
         }
     }
     WSYNC();
+    if (A.prm.stop_after == 3) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = upay[0]; store_result(out, res); } return; }
     // ---- K3a: distinct payloads in first-occurrence order with multiplicities.  Identical payload
     //      means identical taxid list, hence identical contribution at every such position.
     for (int i = lane; i < L::H; i += 64) { hv[i] = kEmpty64; haux[i] = 0; }
@@ -770,116 +813,206 @@ __device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* l
         if (owner) {
             const uint32_t rk = ndist + popc64(bm & lt_mask(lane));
             dpay[rk] = pay;
-            dmult[rk] = mult;
+            dmult[rk] = (uint16_t)mult;
         }
         ndist += popc64(bm);
     }
     WSYNC();
-    // ---- K3b: taxid tables (overlay the hash region)
+    if (A.prm.stop_after == 4) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = ndist; store_result(out, res); } return; }
+    if (ndist == 0) {  // taxid_lst empty: NoDbHits record, proc_line :1270-1277
+        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); G_ADD(&tally_nomatch[1], 1ull); }
+        return;
+    }
+    // ---- K3b stage 1: list headers of all distinct payloads in one round of loads; element offsets by scan
+    const GAS uint16_t* arena = g_arena;
+    uint32_t nel = 0, cand = nuniq, fnd = 0;
+    for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
+        const uint32_t d = d0 + lane;
+        uint32_t n = 0, fl = 0, m = 0;
+        if (d < ndist) {
+            const uint32_t pay = dpay[d];
+            m = dmult[d];
+            n = 1;
+            if (pay >= kListBase) {
+                const uint32_t hdr = *(const GAS uint32_t*)(arena + 2 * (pay - kListBase));  // [flags][n_kept]
+                fl = hdr & 0xFFFFu;
+                n = hdr >> 16;
+            }
+        }
+        // inclusive scan of n over the wave
+        uint32_t incl = n;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (d < ndist) {
+            dn[d] = (uint16_t)n;
+            dfl[d] = (uint8_t)fl;
+            dstart[d] = (uint16_t)(nel + incl - n);
+        }
+        // label_vec.first < 0 positions leave the candidate count (quirk Q4); positions with a
+        // non-empty set count as found (construct_labels :722-725)
+        uint32_t negm = (fl & kListNegFirst) ? m : 0, fm = n ? m : 0;
+        for (int o = 32; o > 0; o >>= 1) { negm += __shfl_xor(negm, o); fm += __shfl_xor(fm, o); }
+        cand -= negm;
+        fnd += fm;
+        nel += __shfl(incl, 63);
+    }
+    bool overflow = nel > (uint32_t)E;
+    if (overflow) {
+        if (lane == 0) {
+            res.status = 255;
+            store_result(out, res);
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
+            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+        }
+        return;
+    }
+    WSYNC();
+    // owner index of every element (the d-lane writes its run; runs are short)
+    for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
+        const uint32_t d = d0 + lane;
+        if (d < ndist) {
+            const uint32_t s0 = dstart[d], n = dn[d];
+            for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (uint16_t)d;
+        }
+    }
     for (int i = lane; i < L::TH; i += 64) { hent[i] = 0; best[i] = 0; }
     WSYNC();
-    uint32_t nT = 0, cand = nuniq, fnd = 0;
-    bool overflow = false;
-    const uint16_t* __restrict__ arena = tb.arena;
-    // phase 1 registration (read_label.cpp:1104-1122): first-lookup position order, then the
-    // depth-sorted order inside a k-mer's kept list
-    for (uint32_t d = 0; d < ndist && !overflow; ++d) {
-        const uint32_t pay = dpay[d], m = dmult[d];
-        uint32_t n = 1, eoff = 0;
-        if (pay >= kListBase) {
-            eoff = 2 * (pay - kListBase);
-            n = arena[eoff + 1];
-            if (arena[eoff] & kListNegFirst) cand -= m;  // label_vec.first < 0 (quirk Q4)
-        }
-        if (n) fnd += m;
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            const bool act = j < n;
-            const uint32_t t = act ? (pay < kListBase ? pay : arena[eoff + kListHdr + j]) : 0;
-            uint32_t h = 0;
-            bool isnew = false;
-            if (act) { h = tid_find_or_claim(hent, L::TH - 1, t); isnew = (hent[h] >> 16) == 0xFFFFu; }
-            const uint64_t nm_ = __ballot(isnew);
-            const uint32_t newcnt = popc64(nm_);
-            if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
-            if (isnew) {
-                const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
-                hent[h] = t | (s << 16);
-                reg[s] = (uint16_t)t; cnt[s] = 0; leaf[s] = 0; stamp[s] = 0xFFFF;
+    // ---- K3b stage 2: the elements and the taxonomy facts of the ascending-order copy, two rounds of loads
+    for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        if (e < nel) {
+            const uint32_t d = el_d[e], pay = dpay[d], n = dn[d], j = e - dstart[d];
+            uint32_t t = pay, ta = pay;
+            if (pay >= kListBase) {
+                const uint32_t eoff = 2 * (pay - kListBase) + kListHdr;
+                t = arena[eoff + j];
+                ta = arena[eoff + n + j];
             }
-            nT += newcnt;
-            WSYNC();
-            if (act) leaf[hent[h] >> 16] += (uint16_t)m;
-            WSYNC();
-        }
-    }
-    if (overflow) {
-        if (lane == 0) { res.status = 255; *out = res; atomicOr(&A.cursor[1], (uint32_t)kErrTidOverflow); }
-        return;
-    }
-    if (nT == 0) {  // taxid_lst empty: NoDbHits record, proc_line :1270-1277
-        if (lane == 0) { res.status = LMAT_ST_NODBHITS; *out = res; atomicAdd(&tally_nomatch[1], 1ull); }
-        return;
-    }
-    // representative strain per species (read_label.cpp:1144-1177): max leaf count, ties -> smallest taxid
-    const uint32_t nT1 = nT;
-    for (uint32_t s0 = 0; s0 < nT1; s0 += 64) {
-        const uint32_t s = s0 + lane;
-        if (s < nT1) {
-            const uint32_t t = reg[s];
-            if (tb.flags[t] & kFlagStrain) {
-                const uint32_t sp = tb.species_of[t];
-                if (sp) {
-                    const uint32_t h = tid_find_or_claim(hent, L::TH - 1, sp);
-                    atomicMax(&best[h], ((uint32_t)leaf[s] << 16) | (0xFFFFu - t));
-                }
-            }
+            el_t[e] = (uint16_t)t;
+            el_ta[e] = (uint16_t)ta;
+            el_fl[e] = g_flags[ta];
+            el_sp[e] = g_species_of[ta];
+            el_plen[e] = g_path_len[ta];
+            el_poff[e] = g_path_off[ta];
         }
     }
     WSYNC();
-    // phase 2 (read_label.cpp:1178-1203 + 701-764): per-position sets = kept ids + ancestors of the
-    // eligible ones; positions ascending == distinct payloads in first-occurrence order
-    for (uint32_t d = 0; d < ndist && !overflow; ++d) {
-        const uint32_t pay = dpay[d], m = dmult[d];
-        uint32_t n = 1, eoff = 0, fl = 0;
-        if (pay >= kListBase) { eoff = 2 * (pay - kListBase); fl = arena[eoff]; n = arena[eoff + 1]; }
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {  // (a) the kept ids themselves
-            const uint32_t j = j0 + lane;
-            if (j < n) {
-                const uint32_t t = pay < kListBase ? pay : arena[eoff + kListHdr + j];
-                const uint32_t s = hent[tid_find(hent, L::TH - 1, t)] >> 16;
-                cnt[s] += (uint16_t)m;
-                stamp[s] = (uint16_t)d;
-            }
+    // ---- phase 1 registration (read_label.cpp:1104-1122): first-lookup position order, then the depth-sorted
+    //      order inside a k-mer's kept list == element order.  Within a chunk the lowest lane holding a new
+    //      taxid registers it (atomicMin on the entry), so order is kept with several lists per chunk.
+    uint32_t nT = 0;
+    for (uint32_t e0 = 0; e0 < nel && !overflow; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool act = e < nel;
+        const uint32_t t = act ? el_t[e] : 0;
+        uint32_t h = 0;
+        if (act) {
+            h = tid_find_or_claim(hent, THM, t);
+            atomicMin(&hent[h], t | ((0x8000u | (uint32_t)lane) << 16));
         }
         WSYNC();
-        if (fl & kListNegFirst) continue;  // closure only where first >= 0 (:1179)
-        for (uint32_t j = 0; j < n && !overflow; ++j) {  // (b) members ascending by taxid
-            const uint32_t u = pay < kListBase ? pay : arena[eoff + kListHdr + n + j];
-            bool eligible = !(tb.flags[u] & kFlagStrain);  // rank != "strain" (:1184)
-            if (!eligible) {
-                const uint32_t sp = tb.species_of[u];
-                if (sp) {
-                    const int h = tid_find(hent, L::TH - 1, sp);
-                    eligible = h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - u);
-                }
+        const bool isnew = act && (hent[h] >> 16) == (0x8000u | (uint32_t)lane);
+        const uint64_t nm_ = __ballot(isnew);
+        const uint32_t newcnt = popc64(nm_);
+        if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
+        if (isnew) {
+            const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+            hent[h] = t | (s << 16);
+            reg[s] = (uint16_t)t; stamp[s] = 0xFFFF;
+        }
+        nT += newcnt;
+        WSYNC();
+    }
+    if (overflow) {
+        if (lane == 0) {
+            res.status = 255;
+            store_result(out, res);
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
+            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+        }
+        return;
+    }
+    // cnt/leaf are packed u16 pairs updated with dword atomics: clear them for all slots that can be used
+    for (uint32_t i = lane; i < (uint32_t)T; i += 64) ((unsigned int*)cnt)[i] = 0;  // covers cnt[T] and leaf[T]
+    WSYNC();
+    // leaf_track (:1112-1116) and the kept ids' own position counts (:701-721), all elements at once
+    for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        if (e < nel) {
+            const uint32_t s = hent[tid_find(hent, THM, el_t[e])] >> 16;
+            const uint32_t m = dmult[el_d[e]];
+            add_u16(leaf, s, m);
+            add_u16(cnt, s, m);
+        }
+    }
+    WSYNC();
+    if (A.prm.stop_after == 5) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nT; store_result(out, res); } return; }
+    // representative strain per species (read_label.cpp:1144-1177): max leaf count, ties -> smallest taxid
+    for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        if (e < nel && (el_fl[e] & kFlagStrain) && el_sp[e]) {
+            const uint32_t u = el_ta[e];
+            const uint32_t lf = leaf[hent[tid_find(hent, THM, u)] >> 16];
+            const uint32_t h = tid_find_or_claim(hent, THM, el_sp[e]);
+            atomicMax(&best[h], (lf << 16) | (0xFFFFu - u));
+        }
+    }
+    WSYNC();
+    // ---- phase 2 (read_label.cpp:1178-1203): per position, ancestors of the eligible kept ids, visited in
+    //      ascending taxid order; positions ascending == distinct payloads in first-occurrence order.
+    //      Everything but the path elements is already in LDS; the next chain is prefetched.
+    {
+        auto eligible = [&](uint32_t e) -> bool {
+            if (dfl[el_d[e]] & kListNegFirst) return false;  // closure only where first >= 0 (:1179)
+            if (!(el_fl[e] & kFlagStrain)) return true;      // rank != "strain" (:1184)
+            const uint32_t sp = el_sp[e];
+            if (!sp) return false;
+            const int h = tid_find(hent, THM, sp);
+            return h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - (uint32_t)el_ta[e]);
+        };
+        // next eligible element at or after e (uniform scan)
+        auto next_elig = [&](uint32_t e) -> uint32_t {
+            while (e < nel) {
+                const uint32_t x = e + lane;
+                const uint64_t m = __ballot(x < nel && eligible(x));
+                if (m) return e + (uint32_t)__builtin_ctzll(m);
+                e += 64;
             }
-            if (!eligible) continue;
-            const uint32_t plen = tb.path_len[u], poff = tb.path_off[u];
+            return nel;
+        };
+        uint32_t e = next_elig(0);
+        uint32_t a_next = 0;
+        if (e < nel) a_next = (uint32_t)lane < (uint32_t)el_plen[e] ? g_paths[el_poff[e] + lane] : 0u;
+        int cur_d = -1;
+        while (e < nel && !overflow) {
+            const uint32_t d = el_d[e], m = dmult[d], plen = el_plen[e], poff = el_poff[e];
+            if ((int)d != cur_d) {  // entering a new position set: its kept ids are members already
+                cur_d = (int)d;
+                const uint32_t s0 = dstart[d], n = dn[d];
+                for (uint32_t j = lane; j < n; j += 64) stamp[hent[tid_find(hent, THM, el_t[s0 + j])] >> 16] = (uint16_t)d;
+                WSYNC();
+            }
+            uint32_t a_cur = a_next;
+            const uint32_t e2 = next_elig(e + 1);
+            if (e2 < nel) a_next = (uint32_t)lane < (uint32_t)el_plen[e2] ? g_paths[el_poff[e2] + lane] : 0u;
             for (uint32_t c0 = 0; c0 < plen; c0 += 64) {
                 const uint32_t c = c0 + lane;
                 const bool act = c < plen;
-                const uint32_t a = act ? tb.paths[poff + c] : 0;
+                const uint32_t a = c0 == 0 ? a_cur : (act ? g_paths[poff + c] : 0u);
                 uint32_t h = 0;
-                bool unreg = false;
-                if (act) { h = tid_find_or_claim(hent, L::TH - 1, a); unreg = (hent[h] >> 16) == 0xFFFFu; }
+                if (act) {
+                    h = tid_find_or_claim(hent, THM, a);
+                }
+                const bool unreg = act && (hent[h] >> 16) == 0xFFFFu;
                 const uint64_t nm_ = __ballot(unreg);
                 const uint32_t newcnt = popc64(nm_);
                 if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
                 if (unreg) {
                     const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
                     hent[h] = a | (s << 16);
-                    reg[s] = (uint16_t)a; cnt[s] = 0; leaf[s] = 0; stamp[s] = 0xFFFF;
+                    reg[s] = (uint16_t)a; stamp[s] = 0xFFFF;
                 }
                 nT += newcnt;
                 WSYNC();
@@ -889,48 +1022,111 @@ __device__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* l
                 }
                 WSYNC();
             }
+            e = e2;
         }
     }
     if (overflow) {
-        if (lane == 0) { res.status = 255; *out = res; atomicOr(&A.cursor[1], (uint32_t)kErrTidOverflow); }
+        if (lane == 0) {
+            res.status = 255;
+            store_result(out, res);
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
+            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+        }
         return;
     }
-    for (uint32_t s = lane; s < nT; s += 64) dep[s] = tb.fdepth[reg[s]];
-    WSYNC();
+    if (A.prm.stop_after == 6) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nT; store_result(out, res); } return; }
     cand &= 0xFFFF;  // uint16_t cand_kmer_cnt (:699)
     // ---- construct_labels early exits (:727-733): nothing is written (quirk Q1), tallied NoDbHits
     if ((int)fnd < A.prm.min_fnd_kmer || (int)cand < A.prm.min_kmer) {
         if (lane == 0) {
-            res.status = LMAT_ST_SILENT;
+            res.status = nT ? LMAT_ST_SILENT : LMAT_ST_NODBHITS;
             res.cand_kmer_cnt = (uint16_t)cand;
-            *out = res;
-            atomicAdd(&tally_nomatch[1], 1ull);
+            store_result(out, res);
+            G_ADD(&tally_nomatch[1], 1ull);
         }
         return;
     }
-    // ---- K4 on lane 0
-    if (lane == 0) {
-        uint32_t ncand = 0, call_idx = 0, coff = 0;
-        lmat_cand* cout_ = nullptr;
-        if (A.cands) {
-            const uint32_t reserve = A.prm.prn_all ? nT : (uint32_t)L::LIN;
-            coff = atomicAdd(&A.cursor[0], reserve);
-            if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = A.cands + coff;
-            else atomicOr(&A.cursor[1], (uint32_t)kErrCandOverflow);
+    if (nT == 0) {  // hits whose kept lists are all empty: taxid_lst empty, proc_line :1270-1277
+        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); G_ADD(&tally_nomatch[1], 1ull); }
+        return;
+    }
+    // ---- K4 staging: per-slot taxonomy facts in one round of loads
+    for (uint32_t s = lane; s < nT; s += 64) {
+        const uint32_t t = reg[s];
+        dep[s] = g_fdepth[t];
+        sflags[s] = g_flags[t];
+        tin[s] = g_tin[t];
+        tout[s] = g_tout[t];
+    }
+    WSYNC();
+    // ---- K4 part 1 on lane 0 (LDS only)
+    K4State S;
+    S.done = false; S.nlin = 0; S.highest = -1; S.highest_depth = 0; S.lidx = -1; S.lowest = -1; S.plasmid_slot = -1;
+    S.top_score = 0; S.diff_thresh = 0;
+    if (lane == 0) k4_part1<L::LIN>(A.prm, res, S, cnt, score, dep, sflags, tin, tout, reg, ord, lin, (int)nT, cand);
+    const int done = __builtin_amdgcn_readfirstlane((int)S.done);
+    int nlin = __builtin_amdgcn_readfirstlane(S.nlin);
+    const int highest = __builtin_amdgcn_readfirstlane(S.highest);
+    const unsigned highest_depth = (unsigned)__builtin_amdgcn_readfirstlane((int)S.highest_depth);
+    WSYNC();
+    uint32_t call_idx = 0, ncand = 0, coff = 0;
+    bool have_add = false;
+    uint32_t high_tin = 0xFFFF, high_tout = 0xFFFF;
+    if (!done) {
+        // ancestors of the shallowest accepted node join the lineage with their pre-bias scores or -10000
+        // (:326-343); one lane per ancestor
+        const uint32_t high_tid = highest >= 0 ? reg[highest] : 0;
+        have_add = highest_depth != 0 && high_tid != 0;
+        if (have_add) {
+            high_tin = tin[highest];
+            high_tout = tout[highest];
+            const uint32_t alen = g_path_len[high_tid], aoff = g_path_off[high_tid];
+            const float fcand = (float)cand;
+            uint32_t room = (uint32_t)L::LIN - (uint32_t)nlin;
+            if (alen > room) { if (lane == 0) G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); }
+            const uint32_t take = alen < room ? alen : room;
+            for (uint32_t j0 = 0; j0 < take; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                if (j < take) {
+                    const uint32_t a = g_paths[aoff + j];
+                    const int s = tid_slot(hent, THM, a);
+                    LinEnt en;
+                    en.tid = (uint16_t)a; en.flag = 0; en.pad = 0;
+                    en.score = s >= 0 ? (float)cnt[s] / fcand : -10000.0f;
+                    en.dep = g_fdepth[a]; en.tin = g_tin[a]; en.tout = g_tout[a];
+                    lin[nlin + j] = en;
+                }
+            }
+            nlin += (int)take;
         }
-        decide_read<U, T>(A, res, reg, cnt, score, dep, ord, hent, lin, (int)nT, cand, cout_, &ncand, &call_idx,
-                          &A.cursor[1]);
+        WSYNC();
+    }
+    // ---- K4 part 2 on lane 0
+    if (lane == 0) {
+        GAS lmat_cand* cout_ = nullptr;
+        if (!done) {
+            if (A.cands) {
+                const uint32_t reserve = A.prm.prn_all ? nT : (uint32_t)L::LIN;
+                coff = G_ADD(&g_cursor[0], reserve);
+                if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
+                else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
+            }
+            k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, hent, THM, lin, nlin, (int)nT, have_add, high_tin,
+                     high_tout, cout_, &ncand, &call_idx);
+        } else {
+            call_idx = A.phix_call_idx;
+        }
         res.cand_off = coff;
         res.n_cand = ncand;
-        *out = res;
+        store_result(out, res);
         // tallies, proc_line :1241-1268
         if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {
-            atomicAdd(&tally_nomatch[1], 1ull);
+            G_ADD(&tally_nomatch[1], 1ull);
         } else if (res.call_score >= A.prm.min_score) {
-            atomicAdd(&tally_count[call_idx], 1ull);
-            atomicAdd(&tally_score[call_idx], (double)res.call_score);
+            G_ADD(&tally_count[call_idx], 1ull);
+            G_ADD(&tally_score[call_idx], (double)res.call_score);
         } else if (res.call_score < A.prm.min_score) {
-            atomicAdd(&tally_nomatch[2], 1ull);
+            G_ADD(&tally_nomatch[2], 1ull);
         }
     }
 }
@@ -957,13 +1153,14 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
     if (acc == 0x123456789ull) atomicAdd(sink, acc);
 }
 
-template <int U, int T>
+template <int U, int T, int E>
 __global__ __launch_bounds__(64) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    for (uint64_t it = blockIdx.x; it < A.count; it += gridDim.x) {
-        const uint64_t r = A.index ? (uint64_t)A.index[it] : A.first + it;
-        classify_one<U, T>(A, r, smem, lane);
+    const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
+    for (uint64_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint64_t r = A.index ? (uint64_t)((const GAS uint32_t*)A.index)[it] : A.first + it;
+        classify_one<U, T, E>(A, r, smem, lane);
         WSYNC();
     }
 }
@@ -1016,21 +1213,22 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
     gather_bench_kernel<<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
 }
 
-template <int U, int T>
+template <int U, int T, int E>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        constexpr int lds_bytes0 = WL<U, T>::BYTES;
-        hipFuncSetAttribute((const void*)classify_kernel<U, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
+        constexpr int lds_bytes0 = WL<U, T, E>::BYTES;
+        hipFuncSetAttribute((const void*)classify_kernel<U, T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
         attr_set = true;
     }
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
-    const int per_cu = 160 * 1024 / WL<U, T>::BYTES;
+    const int per_cu = 160 * 1024 / WL<U, T, E>::BYTES;
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * 2;
-    if ((uint64_t)grid > a.count) grid = (int)a.count;
+    if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)a.count;
+    if (a.count_ptr && grid > 512) grid = 512;
     if (grid < 1) grid = 1;
-    constexpr int lds_bytes = WL<U, T>::BYTES;
-    classify_kernel<U, T><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
+    constexpr int lds_bytes = WL<U, T, E>::BYTES;
+    classify_kernel<U, T, E><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
 
 int classify_max_read_len() { return 2048 + 19; }
@@ -1039,11 +1237,11 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
     if (P <= 256) {
-        if (tcap_class == 0) launch_classify_t<256, 128>(a, stream); else launch_classify_t<256, 1024>(a, stream);
+        if (tcap_class == 0) launch_classify_t<256, 128, 128>(a, stream); else launch_classify_t<256, 1024, 4096>(a, stream);
     } else if (P <= 512) {
-        if (tcap_class == 0) launch_classify_t<512, 128>(a, stream); else launch_classify_t<512, 1024>(a, stream);
+        if (tcap_class == 0) launch_classify_t<512, 128, 128>(a, stream); else launch_classify_t<512, 1024, 4096>(a, stream);
     } else if (P <= 2048) {
-        launch_classify_t<2048, 1024>(a, stream);
+        launch_classify_t<2048, 1024, 4096>(a, stream);
     } else {
         return false;
     }

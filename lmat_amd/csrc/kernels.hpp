@@ -18,6 +18,8 @@ struct ClassifyArgs {
     uint32_t* cursor;          // [0] candidate bump cursor, [1] error flags
     void* counts;              // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint32_t phix_call_idx;    // internal index of 32630
+    uint32_t* ovf_list;        // fast kernel: reads whose tables overflowed are appended here (count in cursor[2])
+    const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
 };
 
 enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8 };

@@ -38,6 +38,8 @@ int upload_taxonomy(lmat_ctx* c) {
     if ((rc = dev_upload(c, &c->dev.path_len, T.path_len))) return rc;
     if ((rc = dev_upload(c, &c->dev.paths, T.paths))) return rc;
     if ((rc = dev_upload(c, &c->dev.conv, T.conv))) return rc;
+    if ((rc = dev_upload(c, &c->dev.tin, T.tin))) return rc;
+    if ((rc = dev_upload(c, &c->dev.tout, T.tout))) return rc;
     c->dev.n_ids = T.n + 1;
     // tallies: u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     if (c->d_counts) { hipFree(c->d_counts); c->d_counts = nullptr; }
@@ -52,6 +54,8 @@ static KernelParams kparams(const lmat_params& p) {
     KernelParams k;
     k.sdiff = p.sdiff; k.hbias = p.hbias; k.min_score = p.min_score;
     k.min_kmer = p.min_kmer; k.min_fnd_kmer = p.min_fnd_kmer; k.prn_all = p.prn_all; k.screen_phix = p.screen_phix;
+    const char* sa = getenv("LMAT_STOP_AFTER");
+    k.stop_after = sa ? atoi(sa) : 0;
     return k;
 }
 
@@ -80,8 +84,8 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     hipDeviceSynchronize();
     for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
-                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.conv, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx};
+                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
+                    c->d_counts, c->d_synth_strain_idx, c->d_ovf};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -324,6 +328,7 @@ int lmat_synth_taxonomy(lmat_ctx* c, const uint32_t* br) {
         if (level_of[i] == 6) T.species_of[ix] = (uint16_t)(parent[i] + 1);
     }
     T.loaded = true;
+    build_euler_intervals(T);
     for (int i = 0; i < 6; ++i) c->synth_branching[i] = br[i];
     c->synth_strains_per_species = br[5];
     c->synth_n_species = (uint32_t)level.size() / br[5];
@@ -505,6 +510,12 @@ static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
         HIPCHK(c, hipMalloc((void**)&c->d_results, count * sizeof(lmat_read_result)));
         c->results_cap = count;
     }
+    if (count > c->ovf_cap) {
+        if (c->d_ovf) hipFree(c->d_ovf);
+        c->d_ovf = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_ovf, count * sizeof(uint32_t)));
+        c->ovf_cap = count;
+    }
     if (cand_cap > c->cands_cap) {
         if (c->d_cands) hipFree(c->d_cands);
         c->d_cands = nullptr;
@@ -532,6 +543,8 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.counts = c->d_counts;
     auto it = c->tax.index_of.find(32630);
     a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
+    a.ovf_list = c->d_ovf;
+    a.count_ptr = nullptr;
     return a;
 }
 
@@ -543,7 +556,8 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     hipSetDevice(c->device);
     int rc = ensure_results(c, count, want_cands ? cand_cap : 0);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+    if (reads->n > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "read set above 2^32 reads");
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 12, c->stream));
     ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
@@ -553,40 +567,19 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     }
     if (!launch_classify(a, reads->max_len, 0, c->stream))
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+    {   // second launch on the same stream: reads that overflowed the fast kernel's LDS tables, listed on the device
+        ClassifyArgs b = a;
+        b.index = c->d_ovf;
+        b.count_ptr = c->d_cursor + 2;
+        b.ovf_list = nullptr;
+        b.count = 0;
+        launch_classify(b, reads->max_len, 1, c->stream);
+    }
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
         c->pending_events.push_back(std::make_pair(e0, e1));
     }
     HIPCHK(c, hipGetLastError());
-    return LMAT_OK;
-}
-
-// re-run reads whose taxid table overflowed the fast kernel's capacity with the large-capacity kernel
-static int rerun_overflow(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, bool want_cands,
-                          uint64_t cand_cap, std::vector<lmat_read_result>& host) {
-    std::vector<uint32_t> idx;
-    for (uint64_t i = 0; i < count; ++i)
-        if (host[i].status == 255) idx.push_back((uint32_t)(first + i));
-    if (idx.empty()) return LMAT_OK;
-    if (first + count > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "overflow re-run needs read indices below 2^32");
-    uint32_t* d_idx = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_idx, idx.size() * 4));
-    HIPCHK(c, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
-    uint32_t zero = 0;
-    HIPCHK(c, hipMemcpyAsync(c->d_cursor + 1, &zero, 4, hipMemcpyHostToDevice, c->stream));
-    ClassifyArgs a = make_args(c, reads, first, idx.size(), want_cands, cand_cap);
-    a.index = d_idx;
-    a.result_base = first;
-    launch_classify(a, reads->max_len, 1, c->stream);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(d_idx);
-    uint32_t cur[2];
-    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
-    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read registers more than 1024 taxids");
-    if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
-    if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
-    for (uint32_t r : idx)
-        HIPCHK(c, hipMemcpy(&host[r - first], c->d_results + (r - first), sizeof(lmat_read_result), hipMemcpyDeviceToHost));
     return LMAT_OK;
 }
 
@@ -606,11 +599,8 @@ int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t
         if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
         std::vector<lmat_read_result> host(count);
         HIPCHK(c, hipMemcpy(host.data(), c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
-        if (cur[1] & kErrTidOverflow) {
-            rc = rerun_overflow(c, reads, first, count, want, cand_cap, host);
-            if (rc) return rc;
-            HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
-        }
+        if (cur[1] & kErrTidOverflow)
+            return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
         memcpy(results, host.data(), count * sizeof(lmat_read_result));
         if (want) {
             const uint64_t used = std::min<uint64_t>(cur[0], cand_cap);
@@ -646,7 +636,7 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     uint32_t cur[2];
     HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
-    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "taxid table overflow in async classify (use lmat_classify)");
+    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
     return LMAT_OK;
 }
 

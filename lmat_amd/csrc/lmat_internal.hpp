@@ -23,6 +23,7 @@ struct HostTaxonomy {
     std::vector<uint32_t> path_off;   // [n+1] into paths
     std::vector<uint16_t> path_len;   // [n+1] number of ancestors (tree depth)
     std::vector<uint16_t> paths;      // ancestors parent..root as internal indices (TaxTree.hpp:60-91)
+    std::vector<uint16_t> tin, tout;  // [n+1] Euler-tour interval: a is a proper ancestor of b iff tin[a] < tin[b] && tout[b] <= tout[a]
     std::unordered_map<uint32_t, uint16_t> index_of;  // tid32 -> internal
     std::unordered_map<uint32_t, uint16_t> br;        // 32 -> 16 (make_db_table.cpp:259-273)
     std::vector<uint32_t> conv;                       // [65536] 16 -> 32 (read_label.cpp:1593-1598), 0 = unmapped
@@ -41,6 +42,8 @@ struct DeviceTables {
     uint32_t* path_off = nullptr;
     uint16_t* path_len = nullptr;
     uint16_t* paths = nullptr;
+    uint16_t* tin = nullptr;
+    uint16_t* tout = nullptr;
     uint32_t* conv = nullptr;  // [65536] 16 -> 32, lookup API only
     uint32_t n_ids = 0;
     int k = 0;
@@ -49,6 +52,7 @@ struct DeviceTables {
 struct KernelParams {
     float sdiff, hbias, min_score;
     int min_kmer, min_fnd_kmer, prn_all, screen_phix;
+    int stop_after;  // debug/profiling only (env LMAT_STOP_AFTER): 0 = full path, n = return after phase n
 };
 
 struct DbBuilder {
@@ -95,7 +99,9 @@ struct lmat_ctx {
     uint64_t results_cap = 0;
     lmat_cand* d_cands = nullptr;
     uint64_t cands_cap = 0;
-    uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags
+    uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags, [2] overflow-list length
+    uint32_t* d_ovf = nullptr;     // reads to re-run with the large-capacity kernel
+    uint64_t ovf_cap = 0;
     void* d_counts = nullptr;      // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint64_t counts_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -109,6 +115,7 @@ int set_err(lmat_ctx* c, int code, const std::string& msg);
 int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, const char* rank_fn,
                         const char* idmap_fn, const char* plasmid_fn);
 int upload_taxonomy(lmat_ctx* c);
+void build_euler_intervals(HostTaxonomy& T);
 // compute the arena record of one raw list; returns false (err set) on invalid ids
 bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec);
 }  // namespace lmat

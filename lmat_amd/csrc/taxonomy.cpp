@@ -177,7 +177,45 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
     auto h = T.index_of.find(9606);
     T.human_idx = h == T.index_of.end() ? 0 : h->second;
     T.loaded = true;
+    if (T.n > 65534) return set_err(c, LMAT_E_CAPACITY, "taxonomy closure above 65534 ids");
+    build_euler_intervals(T);
     return upload_taxonomy(c);
+}
+
+// Euler-tour intervals over the forest defined by paths[]: isAncestor (read_label.cpp:138-150, "a is on
+// b's getPathToRoot") becomes tin[a] < tin[b] && tout[b] <= tout[a] without touching memory per level.
+// Ids that are not tree nodes (empty path, nobody's ancestor) get the empty interval (0xFFFF, 0xFFFF).
+void build_euler_intervals(HostTaxonomy& T) {
+    const uint32_t n = T.n;
+    T.tin.assign(n + 1, 0xFFFF);
+    T.tout.assign(n + 1, 0xFFFF);
+    std::vector<std::vector<uint16_t>> children(n + 1);
+    std::vector<uint8_t> is_child(n + 1, 0), has_child(n + 1, 0);
+    for (uint32_t i = 1; i <= n; ++i)
+        if (T.path_len[i]) {
+            const uint16_t par = T.paths[T.path_off[i]];
+            children[par].push_back((uint16_t)i);
+            is_child[i] = 1;
+            has_child[par] = 1;
+        }
+    uint32_t clock = 0;
+    std::vector<std::pair<uint16_t, size_t>> st;
+    for (uint32_t r = 1; r <= n; ++r) {
+        if (is_child[r] || !has_child[r]) continue;  // roots that own a subtree
+        st.push_back(std::make_pair((uint16_t)r, (size_t)0));
+        T.tin[r] = (uint16_t)clock++;
+        while (!st.empty()) {
+            auto& top = st.back();
+            if (top.second < children[top.first].size()) {
+                const uint16_t ch = children[top.first][top.second++];
+                T.tin[ch] = (uint16_t)clock++;
+                st.push_back(std::make_pair(ch, (size_t)0));
+            } else {
+                T.tout[top.first] = (uint16_t)(clock - 1);
+                st.pop_back();
+            }
+        }
+    }
 }
 
 // One raw DB list -> arena record.  Restates the per-k-mer part of retrieve_kmer_labels
