@@ -506,7 +506,7 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
 // K4 part 2 (lane 0): lineage sort, competitor scan, call, candidate list.  read_label.cpp:344-419, 898-937.
 __device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_read_result& res, const K4State& S,
                          const float* score, const uint16_t* tin, const uint16_t* tout, const uint16_t* reg,
-                         const uint16_t* ord, const unsigned int* hent, int thmask, LinEnt* lin, int nlin, int nT,
+                         const uint16_t* ord, LinEnt* lin, int nlin, int nT,
                          bool have_add, uint32_t high_tin, uint32_t high_tout, GAS lmat_cand* cand_out,
                          uint32_t* n_cand_out, uint32_t* call_idx_out) {
     const int nlin_total = nlin;
@@ -550,7 +550,9 @@ __device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_
         } else {
             match = LMAT_MT_MULTI;
             const uint32_t lca = lin[root_idx].tid;
-            if (tid_slot(hent, thmask, lca) >= 0) {
+            bool lca_is_cand = false;  // all_cand_set.find(lca_tid) :400
+            for (int s = 0; s < nT; ++s) lca_is_cand |= reg[s] == lca;
+            if (lca_is_cand) {
                 if (max_val < lin[root_idx].score) { match = LMAT_MT_PARTIAL; max_val = lin[root_idx].score; }
             }
             call_tid = lca; call_tin = lin[root_idx].tin; call_tout = lin[root_idx].tout;
@@ -584,7 +586,7 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
     lo |= nl;
 }
 
-template <int U, int T, int E>
+template <int U, int T, int E, bool INK4>
 __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane) {
     using L = WL<U, T, E>;
     constexpr int THM = L::TH - 1;
@@ -1050,6 +1052,26 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); G_ADD(&tally_nomatch[1], 1ull); }
         return;
     }
+    if (!INK4) {
+        // hand the read to k4_kernel (one lane per read): registration-ordered (taxid, count) table + cand
+        if (nT > (uint32_t)kK4T) {
+            if (lane == 0) {
+                res.status = 255;
+                store_result(out, res);
+                ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;
+            }
+            return;
+        }
+        GAS uint32_t* krec = (GAS uint32_t*)A.k4buf + (r - A.result_base) * kK4RecWords;
+        if (lane < (int)nT) krec[2 + lane] = (uint32_t)reg[lane] | ((uint32_t)cnt[lane] << 16);
+        if (lane == 0) {
+            krec[0] = nT | (cand << 16);
+            res.status = 254;  // pending K4
+            res.cand_kmer_cnt = (uint16_t)cand;
+            store_result(out, res);
+        }
+        return;
+    }
     // ---- K4 staging: per-slot taxonomy facts in one round of loads
     for (uint32_t s = lane; s < nT; s += 64) {
         const uint32_t t = reg[s];
@@ -1111,7 +1133,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
                 else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
             }
-            k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, hent, THM, lin, nlin, (int)nT, have_add, high_tin,
+            k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
                      high_tout, cout_, &ncand, &call_idx);
         } else {
             call_idx = A.phix_call_idx;
@@ -1120,6 +1142,100 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         res.n_cand = ncand;
         store_result(out, res);
         // tallies, proc_line :1241-1268
+        if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {
+            G_ADD(&tally_nomatch[1], 1ull);
+        } else if (res.call_score >= A.prm.min_score) {
+            G_ADD(&tally_count[call_idx], 1ull);
+            G_ADD(&tally_score[call_idx], (double)res.call_score);
+        } else if (res.call_score < A.prm.min_score) {
+            G_ADD(&tally_nomatch[2], 1ull);
+        }
+    }
+}
+
+// K4 as its own kernel: one lane per read (64 reads per wave), per-read tables in private memory.
+// Runs the same k4_part1 / k4_part2 as the in-kernel lane-0 path of the large-capacity kernel.
+__global__ __launch_bounds__(64) void k4_kernel(ClassifyArgs A) {
+    const DeviceTables& tb = A.tb;
+    const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
+    const GAS uint16_t* g_fdepth = (const GAS uint16_t*)tb.fdepth;
+    const GAS uint8_t* g_flags = (const GAS uint8_t*)tb.flags;
+    const GAS uint32_t* g_path_off = (const GAS uint32_t*)tb.path_off;
+    const GAS uint16_t* g_path_len = (const GAS uint16_t*)tb.path_len;
+    const GAS uint16_t* g_paths = (const GAS uint16_t*)tb.paths;
+    const GAS uint16_t* g_tin = (const GAS uint16_t*)tb.tin;
+    const GAS uint16_t* g_tout = (const GAS uint16_t*)tb.tout;
+    GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    GAS unsigned long long* tally_count = (GAS unsigned long long*)A.counts;
+    GAS double* tally_score = (GAS double*)(tally_count + tb.n_ids);
+    GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + tb.n_ids);
+    constexpr int LIN = kK4T + 72;
+    const uint64_t stride = (uint64_t)gridDim.x * 64;
+    for (uint64_t it = (uint64_t)blockIdx.x * 64 + threadIdx.x; it < A.count; it += stride) {
+        const GAS uint32_t* krec = (const GAS uint32_t*)A.k4buf + it * kK4RecWords;
+        GAS uint64_t* out = (GAS uint64_t*)(A.results + it);
+        lmat_read_result res;
+        {
+            uint64_t w[5];
+            w[0] = out[0]; w[1] = out[1]; w[2] = out[2]; w[3] = out[3]; w[4] = out[4];
+            __builtin_memcpy(&res, w, 40);
+        }
+        if (res.status != 254) continue;
+        const uint32_t hdr = krec[0];
+        const int nT = (int)(hdr & 0xFFFFu);
+        const uint32_t cand = hdr >> 16;
+        uint16_t reg[kK4T], cnt[kK4T], dep[kK4T], tin[kK4T], tout[kK4T], ord[kK4T];
+        uint8_t sflags[kK4T];
+        float score[kK4T];
+        LinEnt lin[LIN];
+        for (int s = 0; s < nT; ++s) {
+            const uint32_t w = krec[2 + s];
+            const uint32_t t = w & 0xFFFFu;
+            reg[s] = (uint16_t)t;
+            cnt[s] = (uint16_t)(w >> 16);
+            dep[s] = g_fdepth[t];
+            sflags[s] = g_flags[t];
+            tin[s] = g_tin[t];
+            tout[s] = g_tout[t];
+        }
+        K4State S;
+        k4_part1<LIN>(A.prm, res, S, cnt, score, dep, sflags, tin, tout, reg, ord, lin, nT, cand);
+        uint32_t call_idx = A.phix_call_idx, ncand = 0, coff = 0;
+        if (!S.done) {
+            int nlin = S.nlin;
+            const uint32_t high_tid = S.highest >= 0 ? reg[S.highest] : 0;
+            const bool have_add = S.highest_depth != 0 && high_tid != 0;
+            uint32_t high_tin = 0xFFFF, high_tout = 0xFFFF;
+            if (have_add) {  // ancestors of the shallowest accepted node (:326-343)
+                high_tin = tin[S.highest];
+                high_tout = tout[S.highest];
+                const uint32_t alen = g_path_len[high_tid], aoff = g_path_off[high_tid];
+                const float fcand = (float)cand;
+                for (uint32_t j = 0; j < alen; ++j) {
+                    if (nlin >= LIN) { G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); break; }
+                    const uint32_t a = g_paths[aoff + j];
+                    int sl = -1;
+                    for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
+                    LinEnt en;
+                    en.tid = (uint16_t)a; en.flag = 0; en.pad = 0;
+                    en.score = sl >= 0 ? (float)cnt[sl] / fcand : -10000.0f;
+                    en.dep = g_fdepth[a]; en.tin = g_tin[a]; en.tout = g_tout[a];
+                    lin[nlin++] = en;
+                }
+            }
+            GAS lmat_cand* cout_ = nullptr;
+            if (A.cands) {
+                const uint32_t reserve = A.prm.prn_all ? (uint32_t)nT : (uint32_t)LIN;
+                coff = G_ADD(&g_cursor[0], reserve);
+                if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
+                else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
+            }
+            k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, cout_,
+                     &ncand, &call_idx);
+        }
+        res.cand_off = coff;
+        res.n_cand = ncand;
+        store_result(out, res);
         if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {
             G_ADD(&tally_nomatch[1], 1ull);
         } else if (res.call_score >= A.prm.min_score) {
@@ -1153,14 +1269,14 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
     if (acc == 0x123456789ull) atomicAdd(sink, acc);
 }
 
-template <int U, int T, int E>
+template <int U, int T, int E, bool INK4>
 __global__ __launch_bounds__(64) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
     for (uint64_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint64_t r = A.index ? (uint64_t)((const GAS uint32_t*)A.index)[it] : A.first + it;
-        classify_one<U, T, E>(A, r, smem, lane);
+        classify_one<U, T, E, INK4>(A, r, smem, lane);
         WSYNC();
     }
 }
@@ -1213,12 +1329,19 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
     gather_bench_kernel<<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
 }
 
-template <int U, int T, int E>
+void launch_k4(const ClassifyArgs& a, hipStream_t stream) {
+    uint64_t blocks = (a.count + 63) / 64;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    k4_kernel<<<dim3((unsigned)blocks), dim3(64), 0, stream>>>(a);
+}
+
+template <int U, int T, int E, bool INK4>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         constexpr int lds_bytes0 = WL<U, T, E>::BYTES;
-        hipFuncSetAttribute((const void*)classify_kernel<U, T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
+        hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
         attr_set = true;
     }
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
@@ -1228,7 +1351,7 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     if (a.count_ptr && grid > 512) grid = 512;
     if (grid < 1) grid = 1;
     constexpr int lds_bytes = WL<U, T, E>::BYTES;
-    classify_kernel<U, T, E><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
+    classify_kernel<U, T, E, INK4><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
 
 int classify_max_read_len() { return 2048 + 19; }
@@ -1237,11 +1360,11 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
     if (P <= 256) {
-        if (tcap_class == 0) launch_classify_t<256, 128, 128>(a, stream); else launch_classify_t<256, 1024, 4096>(a, stream);
+        if (tcap_class == 0) launch_classify_t<256, 128, 128, false>(a, stream); else launch_classify_t<256, 1024, 4096, true>(a, stream);
     } else if (P <= 512) {
-        if (tcap_class == 0) launch_classify_t<512, 128, 128>(a, stream); else launch_classify_t<512, 1024, 4096>(a, stream);
+        if (tcap_class == 0) launch_classify_t<512, 128, 128, false>(a, stream); else launch_classify_t<512, 1024, 4096, true>(a, stream);
     } else if (P <= 2048) {
-        launch_classify_t<2048, 1024, 4096>(a, stream);
+        launch_classify_t<2048, 1024, 4096, true>(a, stream);
     } else {
         return false;
     }

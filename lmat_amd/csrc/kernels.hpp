@@ -20,7 +20,12 @@ struct ClassifyArgs {
     uint32_t phix_call_idx;    // internal index of 32630
     uint32_t* ovf_list;        // fast kernel: reads whose tables overflowed are appended here (count in cursor[2])
     const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
+    uint32_t* k4buf;           // per-read records handed from the fast classify kernel to k4_kernel
 };
+
+// record handed to k4_kernel: word0 = nT | cand << 16, word1 reserved, then K4T words reg | cnt << 16
+static const int kK4T = 32;
+static const int kK4RecWords = 2 + kK4T;
 
 enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8 };
 
@@ -39,6 +44,7 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
                    uint32_t stride, hipStream_t stream);
 // tcap_class: 0 = fast (T=128), 1 = large (T=1024).  Returns false if max_len exceeds every U class.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
+void launch_k4(const ClassifyArgs& a, hipStream_t stream);
 int classify_max_read_len();
 // issues ~n_probes random bucket reads (rounded up to 64 per wave x 4096 waves)
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,

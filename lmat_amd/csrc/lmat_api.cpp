@@ -85,7 +85,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx, c->d_ovf};
+                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -512,7 +512,10 @@ static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
     }
     if (count > c->ovf_cap) {
         if (c->d_ovf) hipFree(c->d_ovf);
+        if (c->d_k4buf) hipFree(c->d_k4buf);
         c->d_ovf = nullptr;
+        c->d_k4buf = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_k4buf, count * (uint64_t)kK4RecWords * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_ovf, count * sizeof(uint32_t)));
         c->ovf_cap = count;
     }
@@ -545,6 +548,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
     a.ovf_list = c->d_ovf;
     a.count_ptr = nullptr;
+    a.k4buf = c->d_k4buf;
     return a;
 }
 
@@ -567,7 +571,8 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     }
     if (!launch_classify(a, reads->max_len, 0, c->stream))
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
-    {   // second launch on the same stream: reads that overflowed the fast kernel's LDS tables, listed on the device
+    if (a.prm.stop_after == 0) launch_k4(a, c->stream);  // score + LCA decision, one lane per read
+    {   // last launch on the same stream: reads that overflowed the fast kernel's LDS tables, listed on the device
         ClassifyArgs b = a;
         b.index = c->d_ovf;
         b.count_ptr = c->d_cursor + 2;

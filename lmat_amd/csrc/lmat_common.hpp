@@ -150,8 +150,13 @@ LM_HD void ss_heapsort(T* a, int first, int last, Cmp& cmp) {
 template <class T, class Cmp>
 LM_HD void ss_sort(T* a, int n, Cmp cmp) {
     if (n <= 0) return;
+    if (n <= 16) {  // introsort loop is a no-op below the threshold: straight to the final insertion sort
+        ss_insertion_sort(a, 0, n, cmp);
+        return;
+    }
     // introsort loop, recursion on the right part made explicit with a small stack
-    int stack_first[64], stack_last[64], stack_depth[64];
+    // pending right-hand ranges: at most one per recursion level, depth <= 2*floor(log2 n) <= 32 for n < 65536
+    int stack_first[34], stack_last[34], stack_depth[34];
     int sp = 0;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) ++lg;
@@ -190,7 +195,7 @@ LM_HD void ss_sort(T* a, int n, Cmp cmp) {
             const int cut = lo;
             // reference recurses on [cut,last) first, then loops on [first,cut)
             // (order of processing disjoint ranges does not change the result)
-            if (sp < 64) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
+            if (sp < 34) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
             last = cut;
         }
     }

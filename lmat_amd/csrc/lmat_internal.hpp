@@ -101,6 +101,7 @@ struct lmat_ctx {
     uint64_t cands_cap = 0;
     uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags, [2] overflow-list length
     uint32_t* d_ovf = nullptr;     // reads to re-run with the large-capacity kernel
+    uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to k4_kernel
     uint64_t ovf_cap = 0;
     void* d_counts = nullptr;      // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint64_t counts_bytes = 0;
