@@ -308,18 +308,21 @@ struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351), 1
 // U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in registered
 // taxids, E = capacity in kept-list elements summed over the read's distinct payloads.
 // Regions are reused across phases (see classify_one).
-template <int U, int T, int E>
+constexpr int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+template <int U, int T, int E, bool INK4>
 struct WL {
-    static constexpr int H = 2 * U;    // k-mer / payload hash slots (power of two)
+    static constexpr int H = pow2_ceil(U * 3 / 2);  // k-mer / payload hash slots
     static constexpr int TH = 4 * T;   // taxid hash slots: <= T registered + <= T unregistered species keys
-    static constexpr int LIN = T + 72; // lineage scratch entries
+    static constexpr int LIN = T + 72; // lineage scratch entries (in-kernel K4 only)
     static constexpr int RD_WORDS = (U + 96) / 16 + (U + 96) / 32 + 4;
-    static constexpr int R1_HASH = 8 * H + 4 * H;                      // u64 hv[H], u32 haux[H]
-    static constexpr int R1_TID = 12 * T + 4 * T + 4 * T + T + 4 * TH + 4 * TH;
+    static constexpr int R1_HASH = 8 * H;                              // u64 hv[H]
+    // reg, stamp, cnt, leaf (u16) | hent, best (u32) | in-kernel K4: dep, ord, tin, tout (u16), score (f32), sflags (u8)
+    static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T : 0);
     static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
     static constexpr int R2_K = 8 * U + 4 * U;                         // ukmer, ubucket
     static constexpr int R2_D = 4 * U + 2 * U + 2 * U + 2 * U + U;     // dpay, dmult, dn, dstart, dfl
-    static constexpr int R2_L = 16 * LIN;                              // lineage (K4, after the d-arrays die)
+    static constexpr int R2_L = INK4 ? 16 * LIN : 0;                   // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
     static constexpr int R3_E = 16 * E;                                // element staging
@@ -588,25 +591,25 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
 
 template <int U, int T, int E, bool INK4>
 __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane) {
-    using L = WL<U, T, E>;
+    using L = WL<U, T, E, INK4>;
     constexpr int THM = L::TH - 1;
     uint32_t* rd = (uint32_t*)(lds + L::OFF_RD);
     // R1, hash phases
     unsigned long long* hv = (unsigned long long*)(lds + L::OFF_R1);
-    unsigned int* haux = (unsigned int*)(lds + L::OFF_R1 + 8 * L::H);
     // R1, taxid phase
     uint16_t* reg = (uint16_t*)(lds + L::OFF_R1);
-    uint16_t* dep = reg + T;
+    uint16_t* stamp = reg + T;
+    uint16_t* cnt = stamp + T;
+    uint16_t* leaf = cnt + T;
+    unsigned int* hent = (unsigned int*)(leaf + T);
+    unsigned int* best = hent + L::TH;
+    // in-kernel K4 only (large-capacity kernel)
+    uint16_t* dep = (uint16_t*)(best + L::TH);
     uint16_t* ord = dep + T;
     uint16_t* tin = ord + T;
     uint16_t* tout = tin + T;
-    uint16_t* stamp = tout + T;
-    uint16_t* cnt = stamp + T;
-    uint16_t* leaf = cnt + T;
-    float* score = (float*)(leaf + T);
+    float* score = (float*)(tout + T);
     uint8_t* sflags = (uint8_t*)(score + T);
-    unsigned int* hent = (unsigned int*)(sflags + T);
-    unsigned int* best = hent + L::TH;
     // R2: k-mers, then per-distinct-payload arrays, then the lineage scratch
     unsigned long long* ukmer = (unsigned long long*)(lds + L::OFF_R2);
     uint32_t* ubucket = (uint32_t*)(lds + L::OFF_R2 + 8 * U);
@@ -753,22 +756,22 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     {
         const int g = lane >> 3, sub = lane & 7;
         const GAS uint64_t* slots = g_slots;
-        for (uint32_t base = 0; base < nuniq; base += 64) {
-            unsigned long long sl[8];
-            uint32_t bk[8];
+        constexpr int NL = U / 8 < 16 ? U / 8 : 16;  // wave-loads in flight per group (128 k-mers)
+        for (uint32_t base = 0; base < nuniq; base += NL * 8) {
+            unsigned long long sl[NL];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NL; ++i) {
                 const uint32_t idx = base + i * 8 + g;
-                bk[i] = idx < nuniq ? ubucket[idx] : 0u;
-                sl[i] = idx < nuniq ? slots[(uint64_t)bk[i] * kSlotsPerBucket + sub] : 0ull;
+                sl[i] = idx < nuniq ? slots[(uint64_t)ubucket[idx] * kSlotsPerBucket + sub] : 0ull;
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NL; ++i) {
+                if (base + i * 8 >= nuniq) break;
                 const uint32_t idx = base + i * 8 + g;
                 const bool act = idx < nuniq;
                 const uint64_t km = act ? ukmer[idx] : 0;
                 unsigned long long s = sl[i];
-                uint32_t b = bk[i];
+                uint32_t b = act ? ubucket[idx] : 0u;
                 bool pending = act;
                 while (__ballot(pending)) {
                     const bool match = pending && s != 0 && (s >> kPayloadBits) == km;
@@ -789,15 +792,12 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     if (A.prm.stop_after == 3) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = upay[0]; store_result(out, res); } return; }
     // ---- K3a: distinct payloads in first-occurrence order with multiplicities.  Identical payload
     //      means identical taxid list, hence identical contribution at every such position.
-    for (int i = lane; i < L::H; i += 64) { hv[i] = kEmpty64; haux[i] = 0; }
+    for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
     WSYNC();
     for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {
         const uint32_t i = i0 + lane;
         const uint32_t pay = i < nuniq ? upay[i] : 0;
-        if (pay) {
-            const uint32_t h = lds_min_insert(hv, L::H - 1, pay, i);
-            atomicAdd(&haux[h], 1u);
-        }
+        if (pay) lds_min_insert(hv, L::H - 1, pay, i);
     }
     WSYNC();
     uint32_t ndist = 0;
@@ -805,19 +805,26 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint32_t i = i0 + lane;
         const uint32_t pay = i < nuniq ? upay[i] : 0;
         bool owner = false;
-        uint32_t mult = 0;
+        uint32_t h = 0;
         if (pay) {
-            const uint32_t h = lds_find(hv, L::H - 1, pay);
+            h = lds_find(hv, L::H - 1, pay);
             owner = (uint32_t)(hv[h] & 0xFFFF) == i;
-            mult = haux[h];
         }
         const uint64_t bm = __ballot(owner);
+        WSYNC();
         if (owner) {
             const uint32_t rk = ndist + popc64(bm & lt_mask(lane));
             dpay[rk] = pay;
-            dmult[rk] = (uint16_t)mult;
+            hv[h] = ((unsigned long long)pay << 16) | (0x8000u | rk);  // first index -> rank (bit 15 marks it)
         }
         ndist += popc64(bm);
+    }
+    for (uint32_t d = lane; d < (ndist + 1) / 2; d += 64) ((unsigned int*)dmult)[d] = 0;
+    WSYNC();
+    for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // multiplicity = number of distinct k-mers carrying the payload
+        const uint32_t i = i0 + lane;
+        const uint32_t pay = i < nuniq ? upay[i] : 0;
+        if (pay) add_u16(dmult, (uint32_t)(hv[lds_find(hv, L::H - 1, pay)] & 0x7FFFu), 1u);
     }
     WSYNC();
     if (A.prm.stop_after == 4) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = ndist; store_result(out, res); } return; }
@@ -1340,17 +1347,17 @@ template <int U, int T, int E, bool INK4>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        constexpr int lds_bytes0 = WL<U, T, E>::BYTES;
+        constexpr int lds_bytes0 = WL<U, T, E, INK4>::BYTES;
         hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
         attr_set = true;
     }
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
-    const int per_cu = 160 * 1024 / WL<U, T, E>::BYTES;
+    const int per_cu = 160 * 1024 / WL<U, T, E, INK4>::BYTES;
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * 2;
     if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)a.count;
     if (a.count_ptr && grid > 512) grid = 512;
     if (grid < 1) grid = 1;
-    constexpr int lds_bytes = WL<U, T, E>::BYTES;
+    constexpr int lds_bytes = WL<U, T, E, INK4>::BYTES;
     classify_kernel<U, T, E, INK4><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
 
@@ -1359,10 +1366,12 @@ int classify_max_read_len() { return 2048 + 19; }
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream) {
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
-    if (P <= 256) {
-        if (tcap_class == 0) launch_classify_t<256, 128, 128, false>(a, stream); else launch_classify_t<256, 1024, 4096, true>(a, stream);
+    if (P <= 160 && tcap_class == 0) {
+        launch_classify_t<160, 64, 128, false>(a, stream);
+    } else if (P <= 256) {
+        if (tcap_class == 0) launch_classify_t<256, 64, 128, false>(a, stream); else launch_classify_t<256, 1024, 4096, true>(a, stream);
     } else if (P <= 512) {
-        if (tcap_class == 0) launch_classify_t<512, 128, 128, false>(a, stream); else launch_classify_t<512, 1024, 4096, true>(a, stream);
+        if (tcap_class == 0) launch_classify_t<512, 64, 128, false>(a, stream); else launch_classify_t<512, 1024, 4096, true>(a, stream);
     } else if (P <= 2048) {
         launch_classify_t<2048, 1024, 4096, true>(a, stream);
     } else {

@@ -24,7 +24,7 @@ struct ClassifyArgs {
 };
 
 // record handed to k4_kernel: word0 = nT | cand << 16, word1 reserved, then K4T words reg | cnt << 16
-static const int kK4T = 32;
+static const int kK4T = 64;
 static const int kK4RecWords = 2 + kK4T;
 
 enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8 };

@@ -638,8 +638,9 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     if (kernel_launches) *kernel_launches = c->kernel_launches;
     c->kernel_ms_total = 0;
     c->kernel_launches = 0;
-    uint32_t cur[2];
-    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    uint32_t cur[3];
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 12, hipMemcpyDeviceToHost));
+    if (getenv("LMAT_DEBUG")) fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags %u, reads re-run by the large kernel %u\n", cur[0], cur[1], cur[2]);
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
     if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
     return LMAT_OK;
