@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 
 // K4 as its own kernel: one lane per read (64 reads per wave), per-read tables in private memory.
 // Runs the same k4_part1 / k4_part2 as the in-kernel lane-0 path of the large-capacity kernel.
-__global__ __launch_bounds__(64) void k4_kernel(ClassifyArgs A) {
+__global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     const DeviceTables& tb = A.tb;
     const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
     const GAS uint16_t* g_fdepth = (const GAS uint16_t*)tb.fdepth;
