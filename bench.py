@@ -82,16 +82,23 @@ def cpu_baseline(eng, reads, n_sample, k, tmpdir, threads):
     counts, tids = eng.lookup(kms, stride=16)
     orc.add_lists32(kms, counts, tids)
     b0 = np.append(blob, np.uint8(0))
-    t0 = time.perf_counter()
-    orc.classify_mt(b0, off, k, threads)
-    dt1 = time.perf_counter() - t0
+    # the oracle allocates heavily (STL node containers, as the reference does): pick the thread count
+    # that actually gives the highest rate on this host instead of assuming all hardware threads help
+    best = None
+    for t in sorted({threads, max(threads // 2, 1), max(threads // 4, 1), max(threads // 8, 1)}):
+        t0 = time.perf_counter()
+        orc.classify_mt(b0, off, k, t)
+        d = time.perf_counter() - t0
+        if best is None or d < best[1]:
+            best = (t, d)
+    threads, dt1 = best
     reps = int(min(max(12.0 / max(dt1, 1e-3), 1), 400))  # aim at ~12 s of CPU work
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.classify_mt(b0, off, k, threads)
     dt = time.perf_counter() - t0
     orc.close()
-    return n_sample * reps / dt, dt, reps
+    return n_sample * reps / dt, dt, reps, threads
 
 
 def main():
@@ -168,6 +175,7 @@ def main():
     for s in range(args.steps):
         eng.classify_async(reads, (args.warmup + s) * args.batch, args.batch)
     kernel_ms, launches = eng.sync()
+    classify_ms, decide_ms, _ = eng.last_timing()
     from lmat_amd.shard import allreduce_tallies
     allreduce_tallies(t_cnt, t_sc, t_nm, dist)  # merge step of read_label.cpp:1760-1800
     barrier()
@@ -177,7 +185,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    log(f"timed region {dt:.3f}s, kernel {kernel_ms:.1f} ms over {launches} launches")
+    log(f"timed region {dt:.3f}s, kernels {kernel_ms:.1f} ms over {launches} launches (classify {classify_ms:.1f} + decide {decide_ms:.1f})")
     total_reads = args.batch * args.steps * world
     value = total_reads / dt
     if rank == 0:
@@ -185,7 +193,7 @@ def main():
         called = sum(c for c, _ in counts.values())
         mean_b = sample_algorithmic_bytes(eng, reads, 2000, k)
         log(f"algorithmic bytes/read = {mean_b:.0f}")
-        avg_ms = kernel_ms / max(launches, 1)
+        avg_ms = classify_ms / max(launches, 1)  # dominant kernel only: classify_kernel (HBM-bound probe inside)
         achieved = mean_b * args.batch / (avg_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -207,14 +215,14 @@ def main():
                        "db_kmers": eng.db_size, "k": k, "parallelism": f"reads sharded x{world}, DB replicated",
                        "db_build_s": round(t_build, 2), "reads_called": called, "nomatch": nomatch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "classify_kernel<256,128>",
-                         "kernel_avg_ms": avg_ms, "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.batch,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "classify_kernel<160,64,128,false>",
+                         "kernel_avg_ms": avg_ms, "k4_kernel_avg_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.batch,
                          "random_64B_gather_ceiling_GBs": gather_gbs},
         }
         if world == 1 and not args.no_cpu:
             threads = os.cpu_count() or 1
             with tempfile.TemporaryDirectory() as td:
-                rps, secs, reps = cpu_baseline(eng, reads, args.cpu_sample, k, td, threads)
+                rps, secs, reps, threads = cpu_baseline(eng, reads, args.cpu_sample, k, td, threads)
             out["cpu_baseline"] = {"value": rps, "unit": "reads/s", "cores": threads, "kind": "port",
                                    "sample": f"first {args.cpu_sample} reads of the same synthetic workload x {reps} passes, CPU "
                                              f"oracle (oracle/lmat_oracle.hpp, {threads} threads, {secs:.1f} s), k-mer table = "

@@ -133,10 +133,14 @@ int lmat_classify(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64
                   lmat_cand* cands, uint64_t cand_cap, uint64_t* n_cands);
 
 /* Same kernels, results left in device memory (throughput runs).  Asynchronous on
- * the context's stream; lmat_sync waits.  kernel_ms (may be NULL) = HIP-event time
- * of the classify kernel, valid after lmat_sync. */
+ * the context's stream; lmat_sync waits.  kernel_ms_total (may be NULL) = HIP-event time of
+ * all kernels of those launches; lmat_last_timing splits it per kernel. */
 int lmat_classify_async(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count);
 int lmat_sync(lmat_ctx* ctx, float* kernel_ms_total, uint64_t* kernel_launches);
+/* HIP-event times accumulated by the launches the last lmat_sync waited for, split per kernel:
+ * classify_ms = classify_kernel (extract + probe + registration/closure, the HBM-bound kernel),
+ * decide_ms = k4_kernel (score + LCA decision) + the large-capacity re-run. */
+int lmat_last_timing(const lmat_ctx* ctx, float* classify_ms, float* decide_ms, uint64_t* launches);
 int lmat_results_fetch(lmat_ctx* ctx, uint64_t first, uint64_t count, lmat_read_result* results);
 
 /* ---- tallies (merge step read_label.cpp:1760-1800) --------------------------

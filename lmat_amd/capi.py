@@ -71,6 +71,7 @@ def load_library(path: str | None = None):
         "lmat_classify": (i32, [vp, vp, u64, u64, vp, vp, u64, P(u64)]),
         "lmat_classify_async": (i32, [vp, vp, u64, u64]),
         "lmat_sync": (i32, [vp, P(C.c_float), P(u64)]),
+        "lmat_last_timing": (i32, [vp, P(C.c_float), P(C.c_float), P(u64)]),
         "lmat_results_fetch": (i32, [vp, u64, u64, vp]),
         "lmat_counts_reset": (i32, [vp]),
         "lmat_counts_layout": (i32, [vp, P(u32), P(u64)]),
@@ -92,7 +93,7 @@ EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_
             "lmat_db_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
             "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_reads_upload",
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
-            "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_results_fetch",
+            "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_format_out"]
 
@@ -232,6 +233,12 @@ class Engine:
         ms, nl = C.c_float(0), C.c_uint64(0)
         self._chk(self.lib.lmat_sync(self.ctx, C.byref(ms), C.byref(nl)))
         return float(ms.value), int(nl.value)
+
+    def last_timing(self):
+        """-> (classify_kernel ms, k4_kernel + re-run ms, launches) of the launches the last sync() waited for."""
+        a, b, n = C.c_float(0), C.c_float(0), C.c_uint64(0)
+        self._chk(self.lib.lmat_last_timing(self.ctx, C.byref(a), C.byref(b), C.byref(n)))
+        return float(a.value), float(b.value), int(n.value)
 
     def fetch_results(self, first, count):
         res = np.zeros(count, dtype=READ_RESULT_DTYPE)

@@ -756,7 +756,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     {
         const int g = lane >> 3, sub = lane & 7;
         const GAS uint64_t* slots = g_slots;
-        constexpr int NL = U / 8 < 16 ? U / 8 : 16;  // wave-loads in flight per group (128 k-mers)
+        constexpr int NL = U / 8 < 17 ? U / 8 : 17;  // wave-loads in flight per group: 136 k-mers, a whole 150 bp read
         for (uint32_t base = 0; base < nuniq; base += NL * 8) {
             unsigned long long sl[NL];
 #pragma unroll

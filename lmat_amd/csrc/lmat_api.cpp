@@ -83,6 +83,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
                     c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf};
@@ -563,14 +564,21 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     if (reads->n > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "read set above 2^32 reads");
     HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 12, c->stream));
     ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     if (timed) {
         HIPCHK(c, hipEventCreate(&e0));
         HIPCHK(c, hipEventCreate(&e1));
+        HIPCHK(c, hipEventCreate(&e2));
+        HIPCHK(c, hipEventCreate(&e3));
         HIPCHK(c, hipEventRecord(e0, c->stream));
     }
     if (!launch_classify(a, reads->max_len, 0, c->stream))
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+    if (timed) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipEventRecord(e2, c->stream));
+        c->pending_events.push_back(std::make_pair(e0, e1));
+    }
     if (a.prm.stop_after == 0) launch_k4(a, c->stream);  // score + LCA decision, one lane per read
     {   // last launch on the same stream: reads that overflowed the fast kernel's LDS tables, listed on the device
         ClassifyArgs b = a;
@@ -581,8 +589,8 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         launch_classify(b, reads->max_len, 1, c->stream);
     }
     if (timed) {
-        HIPCHK(c, hipEventRecord(e1, c->stream));
-        c->pending_events.push_back(std::make_pair(e0, e1));
+        HIPCHK(c, hipEventRecord(e3, c->stream));
+        c->pending_events2.push_back(std::make_pair(e2, e3));
     }
     HIPCHK(c, hipGetLastError());
     return LMAT_OK;
@@ -634,15 +642,34 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
         hipEventDestroy(e.second);
     }
     c->pending_events.clear();
-    if (kernel_ms_total) *kernel_ms_total = c->kernel_ms_total;
+    for (auto& e : c->pending_events2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) c->kernel2_ms_total += ms;
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    c->pending_events2.clear();
+    if (kernel_ms_total) *kernel_ms_total = c->kernel_ms_total + c->kernel2_ms_total;
     if (kernel_launches) *kernel_launches = c->kernel_launches;
+    c->last_classify_ms = c->kernel_ms_total;
+    c->last_decide_ms = c->kernel2_ms_total;
+    c->last_launches = c->kernel_launches;
     c->kernel_ms_total = 0;
+    c->kernel2_ms_total = 0;
     c->kernel_launches = 0;
     uint32_t cur[3];
     HIPCHK(c, hipMemcpy(cur, c->d_cursor, 12, hipMemcpyDeviceToHost));
     if (getenv("LMAT_DEBUG")) fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags %u, reads re-run by the large kernel %u\n", cur[0], cur[1], cur[2]);
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
     if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
+    return LMAT_OK;
+}
+
+int lmat_last_timing(const lmat_ctx* c, float* classify_ms, float* decide_ms, uint64_t* launches) {
+    if (!c) return LMAT_E_ARG;
+    if (classify_ms) *classify_ms = c->last_classify_ms;
+    if (decide_ms) *decide_ms = c->last_decide_ms;
+    if (launches) *launches = c->last_launches;
     return LMAT_OK;
 }
 

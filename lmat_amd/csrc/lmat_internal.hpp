@@ -106,8 +106,10 @@ struct lmat_ctx {
     void* d_counts = nullptr;      // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint64_t counts_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
-    float kernel_ms_total = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;   // around the classify kernel
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events2;  // around k4_kernel + large-capacity re-run
+    float kernel_ms_total = 0, kernel2_ms_total = 0, last_classify_ms = 0, last_decide_ms = 0;
+    uint64_t last_launches = 0;
     uint64_t kernel_launches = 0;
 };
 
