@@ -10,6 +10,15 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts: compile the engine (hipcc cross-compiles without a GPU) and the
+    # oracle once per session; the tests themselves never fall back to anything if this fails
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "lmat_amd", "liblmat_hip.so")) or \
+            not os.path.exists(os.path.join(ROOT, "lmat_amd", "csrc", "read_label")):
+        subprocess.call(["make", "-C", os.path.join(ROOT, "lmat_amd", "csrc"), "all"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liblmat_oracle.so")):
+        subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "lmat_oracle", "liblmat_oracle.so"],
+                        stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
