@@ -590,7 +590,8 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
 }
 
 template <int U, int T, int E, bool INK4>
-__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane) {
+__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane,
+                                             const uint32_t* wcur, uint32_t (&nmacc)[2]) {
     using L = WL<U, T, E, INK4>;
     constexpr int THM = L::TH - 1;
     uint32_t* rd = (uint32_t*)(lds + L::OFF_RD);
@@ -643,8 +644,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     const GAS uint16_t* g_tin = (const GAS uint16_t*)tb.tin;
     const GAS uint16_t* g_tout = (const GAS uint16_t*)tb.tout;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
-    const GAS uint32_t* rec = (const GAS uint32_t*)A.words + ((const GAS uint64_t*)A.rec_off)[r];
-    const uint32_t len = rec[0];
+    // record words were prefetched by the caller: lane l holds word l + 64*j in wcur[j] (word 0 = length)
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)wcur[0]);
     lmat_read_result res;
     res.status = LMAT_ST_NODBHITS; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = 0;
     res.read_len = (int)len; res.log_avg = 0; res.stdev = 0; res.call_tid = 0; res.call_score = 0;
@@ -655,7 +656,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + tb.n_ids);
 
     if ((int)len < k) {  // proc_line :1217-1223
-        if (lane == 0) { res.status = LMAT_ST_SHORT_LEN; store_result(out, res); G_ADD(&tally_nomatch[0], 1ull); }
+        if (lane == 0) { res.status = LMAT_ST_SHORT_LEN; store_result(out, res); nmacc[0]++; }
         return;
     }
     const uint32_t P = len - k + 1;
@@ -665,7 +666,11 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
     // ---- packed record -> LDS (coalesced), zero tail so windows past the end are invalid
     const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
-    for (uint32_t w = lane; w < (uint32_t)L::RD_WORDS; w += 64) rd[w] = w < nb + nm ? rec[1 + w] : 0u;
+#pragma unroll
+    for (int j = 0; j < (L::RD_WORDS + 1 + 63) / 64; ++j) {
+        const uint32_t w = (uint32_t)lane + 64u * j;  // record word index; rd[] starts at word 1
+        if (w >= 1 && w - 1 < (uint32_t)L::RD_WORDS) rd[w - 1] = (w - 1 < nb + nm) ? wcur[j] : 0u;
+    }
     for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
     WSYNC();
     const uint32_t* codes = rd;
@@ -692,16 +697,28 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         return ok;
     };
 
-    // ---- K1 pass 1: valid k-mers, first-occurrence hash, GC accounting
+    // ---- K1 pass 1: valid k-mers, first-occurrence hash, GC accounting.  For U <= 512 the canonical
+    //      k-mers and their hash slots stay in registers for pass 2 (chunk loop fully unrolled).
+    constexpr int CH = (U + 32 + 63) / 64;   // 64-base chunks of the longest read of this class
+    constexpr bool CACHE = U <= 512;
+    constexpr int KC = CACHE ? CH : 1;
+    uint64_t kreg[KC];
+    uint32_t hreg[KC];
+    uint64_t okm[KC];
     int valid_kmers = 0, gc = 0, tot = 0;
     uint64_t prevV = 0;
-    for (uint32_t p0 = 0; p0 < len; p0 += 64) {
+#pragma unroll
+    for (int c = 0; c < (CACHE ? CH : 1); ++c) {
+        if (CACHE) { kreg[c] = 0; hreg[c] = 0; okm[c] = 0; }
+    }
+    auto pass1_chunk = [&](uint32_t p0, uint64_t& km_out, uint32_t& h_out, uint64_t& V_out) {
         const uint32_t p = p0 + lane;
         uint64_t km = 0;
         const bool ok = (p < P) && window(p, km);
         const uint64_t V = __ballot(ok);
         valid_kmers += popc64(V);
-        if (ok) lds_min_insert(hv, L::H - 1, km, p);
+        uint32_t h = 0;
+        if (ok) h = lds_min_insert(hv, L::H - 1, km, p);
         // bases covered by at least one valid k-mer (read_label.cpp:987-1008): base b is covered
         // iff some window start in [b-k+1, b] is valid
         uint64_t lo = prevV, hi = V;
@@ -717,6 +734,16 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         gc += popc64(__ballot(covered && isgc));
         tot += popc64(hi);
         prevV = V;
+        km_out = km; h_out = h; V_out = V;
+    };
+    if (CACHE) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((uint32_t)c * 64 >= len) break;
+            pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], okm[c]);
+        }
+    } else {
+        for (uint32_t p0 = 0; p0 < len; p0 += 64) { uint64_t a; uint32_t b; uint64_t v; pass1_chunk(p0, a, b, v); }
     }
     WSYNC();
     res.valid_kmers = valid_kmers;
@@ -726,20 +753,15 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         res.bin_sel = (int)(gc_pcnt / 10.0f);
     }
     if (valid_kmers < A.prm.min_kmer) {  // proc_line :1232-1238
-        if (lane == 0) { res.status = LMAT_ST_SHORT_VALID; store_result(out, res); G_ADD(&tally_nomatch[0], 1ull); }
+        if (lane == 0) { res.status = LMAT_ST_SHORT_VALID; store_result(out, res); nmacc[0]++; }
         return;
     }
     if (A.prm.stop_after == 1) { if (lane == 0) { res.status = 250; store_result(out, res); } return; }
     // ---- K1 pass 2: compact first occurrences in position order
     uint32_t nuniq = 0;
-    for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+    auto pass2_chunk = [&](uint32_t p0, uint64_t km, uint32_t h, bool ok) {
         const uint32_t p = p0 + lane;
-        uint64_t km = 0;
-        bool first = false;
-        if (p < P && window(p, km)) {
-            const uint32_t h = lds_find(hv, L::H - 1, km);
-            first = (uint32_t)(hv[h] & 0xFFFF) == p;
-        }
+        const bool first = ok && (uint32_t)(hv[h] & 0xFFFF) == p;
         const uint64_t bm = __ballot(first);
         if (first) {
             const uint32_t rk = nuniq + popc64(bm & lt_mask(lane));
@@ -748,15 +770,32 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             upay[rk] = 0;
         }
         nuniq += popc64(bm);
+    };
+    if (CACHE) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((uint32_t)c * 64 >= P) break;
+            pass2_chunk((uint32_t)c * 64, kreg[c], hreg[c], (okm[c] >> lane) & 1ull);
+        }
+    } else {
+        for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            uint64_t km = 0;
+            uint32_t h = 0;
+            const bool ok = p < P && window(p, km);
+            if (ok) h = lds_find(hv, L::H - 1, km);
+            pass2_chunk(p0, km, h, ok);
+        }
     }
     WSYNC();
     if (A.prm.stop_after == 2) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nuniq; store_result(out, res); } return; }
-    // ---- K2: probe.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets;
-    //      8 loads are issued back to back before the first is consumed.
+    // ---- K2: probe.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets; all wave-loads
+    //      of a group (a whole 150 bp read) are issued before the first is consumed.  A bucket that is full
+    //      and does not hold the key (rare at load 0.8) is followed up in a second, slower pass.
     {
         const int g = lane >> 3, sub = lane & 7;
         const GAS uint64_t* slots = g_slots;
-        constexpr int NL = U / 8 < 17 ? U / 8 : 17;  // wave-loads in flight per group: 136 k-mers, a whole 150 bp read
+        constexpr int NL = U / 8 < 17 ? U / 8 : 17;
         for (uint32_t base = 0; base < nuniq; base += NL * 8) {
             unsigned long long sl[NL];
 #pragma unroll
@@ -764,25 +803,38 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 const uint32_t idx = base + i * 8 + g;
                 sl[i] = idx < nuniq ? slots[(uint64_t)ubucket[idx] * kSlotsPerBucket + sub] : 0ull;
             }
+            uint32_t pend = 0;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 if (base + i * 8 >= nuniq) break;
                 const uint32_t idx = base + i * 8 + g;
                 const bool act = idx < nuniq;
                 const uint64_t km = act ? ukmer[idx] : 0;
-                unsigned long long s = sl[i];
-                uint32_t b = act ? ubucket[idx] : 0u;
-                bool pending = act;
-                while (__ballot(pending)) {
-                    const bool match = pending && s != 0 && (s >> kPayloadBits) == km;
-                    const bool empty = pending && s == 0;
-                    const uint64_t mm = __ballot(match), em = __ballot(empty);
-                    if (match) upay[idx] = (uint32_t)(s & kPayloadMask);
-                    const uint32_t gm = (uint32_t)(mm >> (g * 8)) & 0xFF, ge = (uint32_t)(em >> (g * 8)) & 0xFF;
-                    if (gm || ge) pending = false;
-                    if (pending) {  // bucket full, key absent: linear probe to the next bucket
-                        b = b + 1 == tb.nbuckets ? 0 : b + 1;
-                        s = slots[(uint64_t)b * kSlotsPerBucket + sub];
+                const unsigned long long s = sl[i];
+                const bool match = act && s != 0 && (s >> kPayloadBits) == km;
+                const bool empty = act && s == 0;
+                const uint64_t me = __ballot(match || empty);
+                if (match) upay[idx] = (uint32_t)(s & kPayloadMask);
+                if (act && ((uint32_t)(me >> (g * 8)) & 0xFF) == 0) pend |= 1u << i;
+            }
+            if (__ballot(pend != 0)) {
+                for (int i = 0; i < NL; ++i) {
+                    bool pending = (pend >> i) & 1u;
+                    if (!__ballot(pending)) continue;
+                    const uint32_t idx = base + i * 8 + g;
+                    const uint64_t km = pending ? ukmer[idx] : 0;
+                    uint32_t b = pending ? ubucket[idx] : 0u;
+                    while (__ballot(pending)) {
+                        unsigned long long s = 0;
+                        if (pending) {
+                            b = b + 1 == tb.nbuckets ? 0 : b + 1;
+                            s = slots[(uint64_t)b * kSlotsPerBucket + sub];
+                        }
+                        const bool match = pending && s != 0 && (s >> kPayloadBits) == km;
+                        const bool empty = pending && s == 0;
+                        const uint64_t me = __ballot(match || empty);
+                        if (match) upay[idx] = (uint32_t)(s & kPayloadMask);
+                        if (((uint32_t)(me >> (g * 8)) & 0xFF) != 0) pending = false;
                     }
                 }
             }
@@ -829,7 +881,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     WSYNC();
     if (A.prm.stop_after == 4) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = ndist; store_result(out, res); } return; }
     if (ndist == 0) {  // taxid_lst empty: NoDbHits record, proc_line :1270-1277
-        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); G_ADD(&tally_nomatch[1], 1ull); }
+        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); nmacc[1]++; }
         return;
     }
     // ---- K3b stage 1: list headers of all distinct payloads in one round of loads; element offsets by scan
@@ -1051,12 +1103,12 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             res.status = nT ? LMAT_ST_SILENT : LMAT_ST_NODBHITS;
             res.cand_kmer_cnt = (uint16_t)cand;
             store_result(out, res);
-            G_ADD(&tally_nomatch[1], 1ull);
+            nmacc[1]++;
         }
         return;
     }
     if (nT == 0) {  // hits whose kept lists are all empty: taxid_lst empty, proc_line :1270-1277
-        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); G_ADD(&tally_nomatch[1], 1ull); }
+        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); nmacc[1]++; }
         return;
     }
     if (!INK4) {
@@ -1276,15 +1328,69 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
     if (acc == 0x123456789ull) atomicAdd(sink, acc);
 }
 
+// Variant of the gather microbenchmark with the classify kernel's probe structure: bucket indices staged in
+// LDS, `burst` wave-loads issued back to back, then consumed, `pad_lds` bytes of LDS per wave to set occupancy.
+__global__ __launch_bounds__(64) void gather_bench2_kernel(const uint64_t* __restrict__ slots_, uint32_t nbuckets,
+                                                           uint32_t bursts_per_wave, uint32_t burst, uint64_t seed,
+                                                           unsigned long long* sink) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* lb = (uint32_t*)smem;
+    const GAS uint64_t* slots = (const GAS uint64_t*)slots_;
+    const int lane = threadIdx.x & 63, g = lane >> 3, sub = lane & 7;
+    unsigned long long acc = 0;
+    uint64_t ctr = ((uint64_t)blockIdx.x * bursts_per_wave) * 256;
+    for (uint32_t it = 0; it < bursts_per_wave; ++it) {
+        for (uint32_t i = lane; i < burst * 8; i += 64) lb[i] = bucket_of(seed + ctr + i, nbuckets);
+        ctr += 256;
+        WSYNC();
+        unsigned long long sl[24];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            sl[j] = (uint32_t)j < burst ? slots[(uint64_t)lb[j * 8 + g] * kSlotsPerBucket + sub] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 24; ++j) acc += sl[j] >> 13;
+        WSYNC();
+    }
+    if (acc == 0x123456789ull) atomicAdd(sink, acc);
+}
+
 template <int U, int T, int E, bool INK4>
-__global__ __launch_bounds__(64) void classify_kernel(ClassifyArgs A) {
+__global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
-    for (uint64_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const uint64_t r = A.index ? (uint64_t)((const GAS uint32_t*)A.index)[it] : A.first + it;
-        classify_one<U, T, E, INK4>(A, r, smem, lane);
+    const GAS uint32_t* index = (const GAS uint32_t*)A.index;
+    const GAS uint64_t* rec_off = (const GAS uint64_t*)A.rec_off;
+    const GAS uint32_t* words = (const GAS uint32_t*)A.words;
+    auto r_of = [&](uint64_t it) -> uint64_t { return index ? (uint64_t)index[it] : A.first + it; };
+    // Software pipeline over the reads of this wave: the record offset is fetched two reads ahead and the
+    // record words one read ahead, so a read never starts with a chain of dependent HBM round trips.
+    constexpr int NW = (WL<U, T, E, INK4>::RD_WORDS + 1 + 63) / 64;
+    const uint64_t G = gridDim.x;
+    uint64_t it = blockIdx.x;
+    if (it >= count) return;
+    uint32_t wcur[NW], wnext[NW];
+    uint32_t nmacc[2] = {0, 0};
+    const uint64_t off0 = rec_off[r_of(it)];
+    uint64_t off1 = it + G < count ? rec_off[r_of(it + G)] : 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) wcur[j] = words[off0 + lane + 64 * j];  // may run past the record: the buffer is padded
+    while (it < count) {
+        const uint64_t off2 = it + 2 * G < count ? rec_off[r_of(it + 2 * G)] : 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) wnext[j] = it + G < count ? words[off1 + lane + 64 * j] : 0u;
+        classify_one<U, T, E, INK4>(A, r_of(it), smem, lane, wcur, nmacc);
         WSYNC();
+#pragma unroll
+        for (int j = 0; j < NW; ++j) wcur[j] = wnext[j];
+        off1 = off2;
+        it += G;
+    }
+    if (lane == 0) {  // ReadTooShort / NoDbHits counts of this wave's reads, one atomic each
+        GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)A.counts + 2 * (uint64_t)A.tb.n_ids;
+        if (nmacc[0]) G_ADD(&tally_nomatch[0], (unsigned long long)nmacc[0]);
+        if (nmacc[1]) G_ADD(&tally_nomatch[1], (unsigned long long)nmacc[1]);
     }
 }
 
@@ -1327,6 +1433,12 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
     if (!n) return;
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tb, kmers, n, counts, tids,
                        stride);
+}
+
+void launch_gather_bench2(const uint64_t* slots, uint32_t nbuckets, uint32_t grid, uint32_t bursts_per_wave, uint32_t burst,
+                          uint32_t lds_bytes, uint64_t seed, unsigned long long* sink, hipStream_t stream) {
+    hipFuncSetAttribute((const void*)gather_bench2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    gather_bench2_kernel<<<dim3(grid), dim3(64), lds_bytes, stream>>>(slots, nbuckets, bursts_per_wave, burst, seed, sink);
 }
 
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,

@@ -406,7 +406,7 @@ static int reads_alloc(lmat_ctx* c, const std::vector<uint64_t>& rec_off, uint32
     r->n = rec_off.size() - 1;
     r->n_words = rec_off.back();
     r->max_len = max_len;
-    if (hipMalloc((void**)&r->words, std::max<uint64_t>(r->n_words, 1) * 4 + 64) != hipSuccess ||
+    if (hipMalloc((void**)&r->words, std::max<uint64_t>(r->n_words, 1) * 4 + 4096) != hipSuccess ||  // kernels read whole-record tiles: pad
         hipMalloc((void**)&r->rec_off, rec_off.size() * 8) != hipSuccess) {
         if (r->words) hipFree(r->words);
         delete r;
@@ -741,6 +741,28 @@ int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, 
     if (ms) *ms = t;
     const uint64_t per_wave = (n_probes / 4096 + 63) / 64 * 64;
     if (bytes) *bytes = per_wave * 4096 * 64;
+    return LMAT_OK;
+}
+
+// experiment hook (not in the public header): burst-structured gather
+extern "C" int lmat_gather_bench2(lmat_ctx* c, uint32_t grid, uint32_t bursts_per_wave, uint32_t burst, uint32_t lds_bytes,
+                                  float* ms, uint64_t* bytes) {
+    if (!c || !c->db_ready || burst > 24) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    unsigned long long* sink = nullptr;
+    HIPCHK(c, hipMalloc((void**)&sink, 8));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    launch_gather_bench2(c->dev.slots, c->dev.nbuckets, grid, bursts_per_wave, burst, lds_bytes, 99, sink, c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float t = 0;
+    HIPCHK(c, hipEventElapsedTime(&t, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
+    if (ms) *ms = t;
+    if (bytes) *bytes = (uint64_t)grid * bursts_per_wave * burst * 8 * 64;
     return LMAT_OK;
 }
 
