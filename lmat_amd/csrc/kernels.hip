@@ -11,6 +11,7 @@
 //   K3 registration/closure/count src/read_label.cpp:1104-1204, 692-764
 //   K4 score + decision           src/read_label.cpp:803-941, 284-419, 225-282
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "kernels.hpp"
 
 namespace lmat {
@@ -789,55 +790,69 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
     WSYNC();
     if (A.prm.stop_after == 2) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nuniq; store_result(out, res); } return; }
-    // ---- K2: probe.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets; all wave-loads
-    //      of a group (a whole 150 bp read) are issued before the first is consumed.  A bucket that is full
-    //      and does not hold the key (rare at load 0.8) is followed up in a second, slower pass.
+    // ---- K2: probe in rounds.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets; all
+    //      wave-loads of a group (a whole 150 bp read) are issued before the first is consumed.  K-mers whose
+    //      bucket is full and does not hold the key (31 % of buckets are full at load 0.8) go on a pending
+    //      list and are probed together, one bucket further, in the next round.
     {
         const int g = lane >> 3, sub = lane & 7;
         const GAS uint64_t* slots = g_slots;
         constexpr int NL = U / 8 < 17 ? U / 8 : 17;
-        for (uint32_t base = 0; base < nuniq; base += NL * 8) {
-            unsigned long long sl[NL];
+        uint16_t* plist = (uint16_t*)hv;                               // two lists of U entries; the k-mer hash is dead
+        unsigned int* pcnt = (unsigned int*)((uint16_t*)hv + 2 * U);   // [2] lengths of the two lists
+        // one pass over a list of np k-mer indices (identity list in round 0), NLX wave-loads in flight
+        auto probe_pass = [&](auto nlx_tag, auto ident_tag, uint32_t np, const uint16_t* pcur, uint16_t* pnext,
+                              unsigned int* ncnt) {
+            constexpr int NLX = decltype(nlx_tag)::value;
+            constexpr bool IDENT = decltype(ident_tag)::value;
+            for (uint32_t base = 0; base < np; base += NLX * 8) {
+                unsigned long long sl[NLX];
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const uint32_t idx = base + i * 8 + g;
-                sl[i] = idx < nuniq ? slots[(uint64_t)ubucket[idx] * kSlotsPerBucket + sub] : 0ull;
-            }
-            uint32_t pend = 0;
+                for (int i = 0; i < NLX; ++i) {
+                    const uint32_t li = base + i * 8 + g;
+                    unsigned long long v = 0;
+                    if (li < np) {
+                        const uint32_t idx = IDENT ? li : (uint32_t)pcur[li];
+                        v = slots[(uint64_t)ubucket[idx] * kSlotsPerBucket + sub];
+                    }
+                    sl[i] = v;
+                }
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                if (base + i * 8 >= nuniq) break;
-                const uint32_t idx = base + i * 8 + g;
-                const bool act = idx < nuniq;
-                const uint64_t km = act ? ukmer[idx] : 0;
-                const unsigned long long s = sl[i];
-                const bool match = act && s != 0 && (s >> kPayloadBits) == km;
-                const bool empty = act && s == 0;
-                const uint64_t me = __ballot(match || empty);
-                if (match) upay[idx] = (uint32_t)(s & kPayloadMask);
-                if (act && ((uint32_t)(me >> (g * 8)) & 0xFF) == 0) pend |= 1u << i;
-            }
-            if (__ballot(pend != 0)) {
-                for (int i = 0; i < NL; ++i) {
-                    bool pending = (pend >> i) & 1u;
-                    if (!__ballot(pending)) continue;
-                    const uint32_t idx = base + i * 8 + g;
-                    const uint64_t km = pending ? ukmer[idx] : 0;
-                    uint32_t b = pending ? ubucket[idx] : 0u;
-                    while (__ballot(pending)) {
-                        unsigned long long s = 0;
-                        if (pending) {
-                            b = b + 1 == tb.nbuckets ? 0 : b + 1;
-                            s = slots[(uint64_t)b * kSlotsPerBucket + sub];
-                        }
-                        const bool match = pending && s != 0 && (s >> kPayloadBits) == km;
-                        const bool empty = pending && s == 0;
-                        const uint64_t me = __ballot(match || empty);
-                        if (match) upay[idx] = (uint32_t)(s & kPayloadMask);
-                        if (((uint32_t)(me >> (g * 8)) & 0xFF) != 0) pending = false;
+                for (int i = 0; i < NLX; ++i) {
+                    if (base + i * 8 >= np) break;
+                    const uint32_t li = base + i * 8 + g;
+                    const bool act = li < np;
+                    const uint32_t idx = act ? (IDENT ? li : (uint32_t)pcur[li]) : 0u;
+                    const uint64_t km = act ? ukmer[idx] : 0;
+                    const unsigned long long sv = sl[i];
+                    const bool match = act && sv != 0 && (sv >> kPayloadBits) == km;
+                    const bool empty = act && sv == 0;
+                    const uint64_t me = __ballot(match || empty);
+                    if (match) upay[idx] = (uint32_t)(sv & kPayloadMask);
+                    if (act && sub == 0 && ((uint32_t)(me >> (g * 8)) & 0xFF) == 0) {
+                        const uint32_t b = ubucket[idx] + 1;
+                        ubucket[idx] = b == tb.nbuckets ? 0u : b;
+                        pnext[atomicAdd(ncnt, 1u)] = (uint16_t)idx;
                     }
                 }
             }
+        };
+        if (lane < 2) pcnt[lane] = 0;
+        WSYNC();
+        probe_pass(std::integral_constant<int, NL>{}, std::true_type{}, nuniq, plist, plist + U, pcnt + 1);
+        WSYNC();
+        uint32_t np = pcnt[1];
+        int round = 1;
+        while (np > 0) {
+            const uint16_t* pcur = plist + ((round & 1) ? U : 0);
+            uint16_t* pnext = plist + ((round & 1) ? 0 : U);
+            unsigned int* ncnt = pcnt + ((round & 1) ^ 1);
+            if (lane == 0) *ncnt = 0;
+            WSYNC();
+            probe_pass(std::integral_constant<int, 4>{}, std::false_type{}, np, pcur, pnext, ncnt);
+            WSYNC();
+            np = *ncnt;
+            ++round;
         }
     }
     WSYNC();
