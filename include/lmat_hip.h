@@ -30,6 +30,7 @@ extern "C" {
 
 typedef struct lmat_ctx lmat_ctx;
 typedef struct lmat_reads lmat_reads;
+typedef struct lmat_ingest lmat_ingest;
 
 /* ScoreOptions + the scalar thresholds proc_line takes
  * (src/read_label.cpp:487-497, :1211-1212, getopt cases :1353-1441). */
@@ -97,6 +98,16 @@ int lmat_taxonomy_load_files(lmat_ctx* ctx, const char* tree_fn, const char* dep
 int lmat_db_begin(lmat_ctx* ctx, int k, uint64_t n_kmers_hint, uint64_t table_bytes);
 int lmat_db_add_taxhisto(lmat_ctx* ctx, const char* fn);
 int lmat_db_finalize(lmat_ctx* ctx);
+/* make_db_table's content-changing options (src/make_db_table.cpp:150-213,303-313): build-time pruning of
+ * lists longer than tid_cutoff by the rank map (-g N -m file; SortedDb.cpp:296-409), human k-mer feed (-j;
+ * SortedDb.cpp:170-233,475-530,664-715), adaptor k-mer feed (-u; SortedDb.cpp:190-204,275-292).  Call between
+ * lmat_db_begin and the first lmat_db_add_taxhisto; NULL / 0 disables an option. */
+int lmat_db_set_build_options(lmat_ctx* ctx, int tid_cutoff, const char* rank_map_fn, const char* human_kmers_fn,
+                              const char* adaptor_kmers_fn, uint32_t adaptor_tid);
+/* Engine-native image of the ingested database (replaces the PERM heap image make_db_table leaves on disk,
+ * src/make_db_table.cpp:330-343,429): save between begin and finalize; load + finalize to use it. */
+int lmat_db_save_image(lmat_ctx* ctx, const char* fn);
+int lmat_db_load_image(lmat_ctx* ctx, const char* fn, uint64_t table_bytes);
 int lmat_db_kmer_length(const lmat_ctx* ctx);   /* SortedDb::get_kmer_length (SortedDb.hpp:433) */
 uint64_t lmat_db_size(const lmat_ctx* ctx);      /* SortedDb::size (SortedDb.hpp:438)            */
 uint64_t lmat_db_table_bytes(const lmat_ctx* ctx);
@@ -153,6 +164,22 @@ int lmat_counts_layout(const lmat_ctx* ctx, uint32_t* n_ids, uint64_t* bytes);
 void* lmat_counts_device_ptr(lmat_ctx* ctx);
 int lmat_counts_get(lmat_ctx* ctx, uint32_t* tid32, uint64_t* count, double* score, uint32_t cap, uint32_t* n_nonzero,
                     uint64_t nomatch3[3]);
+
+/* ---- GPU-free ingest (the make_db_image tool; also usable without any device) ----------------------
+ * Same parsing and options as above, producing the canonical (k-mer, 16-bit taxid list) form;
+ * lmat_ingest_lookup returns the stored list of one k-mer (16-bit DB ids, stored order; 0 = absent). */
+int lmat_ingest_create(int k, const char* idmap_fn, lmat_ingest** out);
+void lmat_ingest_destroy(lmat_ingest* ing);
+const char* lmat_ingest_error(const lmat_ingest* ing);
+int lmat_ingest_set_options(lmat_ingest* ing, int tid_cutoff, const char* rank_map_fn, const char* human_kmers_fn,
+                            const char* adaptor_kmers_fn, uint32_t adaptor_tid);
+int lmat_ingest_add_taxhisto(lmat_ingest* ing, const char* fn);
+int lmat_ingest_save_image(const lmat_ingest* ing, const char* fn);
+int lmat_ingest_load_image(const char* fn, lmat_ingest** out);
+uint64_t lmat_ingest_size(const lmat_ingest* ing);
+int lmat_ingest_kmer_length(const lmat_ingest* ing);
+int lmat_ingest_lookup(const lmat_ingest* ing, uint64_t kmer, uint16_t* tids16, int cap);
+int lmat_db_from_ingest(lmat_ctx* ctx, lmat_ingest* ing, uint64_t table_bytes);
 
 /* ---- measurement aid ---------------------------------------------------------
  * Random 64-byte bucket gather over the loaded table with the probe kernel's access shape;

@@ -56,6 +56,20 @@ def load_library(path: str | None = None):
         "lmat_db_begin": (i32, [vp, i32, u64, u64]),
         "lmat_db_add_taxhisto": (i32, [vp, cp]),
         "lmat_db_finalize": (i32, [vp]),
+        "lmat_db_set_build_options": (i32, [vp, i32, cp, cp, cp, u32]),
+        "lmat_db_save_image": (i32, [vp, cp]),
+        "lmat_db_load_image": (i32, [vp, cp, u64]),
+        "lmat_ingest_create": (i32, [i32, cp, P(vp)]),
+        "lmat_ingest_destroy": (None, [vp]),
+        "lmat_ingest_error": (cp, [vp]),
+        "lmat_ingest_set_options": (i32, [vp, i32, cp, cp, cp, u32]),
+        "lmat_ingest_add_taxhisto": (i32, [vp, cp]),
+        "lmat_ingest_save_image": (i32, [vp, cp]),
+        "lmat_ingest_load_image": (i32, [cp, P(vp)]),
+        "lmat_ingest_size": (u64, [vp]),
+        "lmat_ingest_kmer_length": (i32, [vp]),
+        "lmat_ingest_lookup": (i32, [vp, u64, vp, i32]),
+        "lmat_db_from_ingest": (i32, [vp, vp, u64]),
         "lmat_db_kmer_length": (i32, [vp]),
         "lmat_db_size": (u64, [vp]),
         "lmat_db_table_bytes": (u64, [vp]),
@@ -91,6 +105,10 @@ def load_library(path: str | None = None):
 
 EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
             "lmat_db_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
+            "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create",
+            "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
+            "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
+            "lmat_ingest_lookup", "lmat_db_from_ingest",
             "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_reads_upload",
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
@@ -128,6 +146,50 @@ class Reads:
             self.h = None
 
 
+class Ingest:
+    """GPU-free ingest (lmat_ingest): make_db_table's parsing and options, canonical 16-bit lists."""
+
+    def __init__(self, k=None, idmap=None, image=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.lmat_ingest_load_image(image.encode(), C.byref(h)) if image else \
+            self.lib.lmat_ingest_create(k, idmap.encode(), C.byref(h))
+        if rc != 0:
+            raise LmatError(rc, "cannot create ingest")
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise LmatError(rc, self.lib.lmat_ingest_error(self.h).decode(errors="replace"))
+
+    def set_options(self, tid_cutoff=0, rank_map=None, human_kmers=None, adaptor_kmers=None, adaptor_tid=0):
+        e = lambda s: s.encode() if s else None
+        self._chk(self.lib.lmat_ingest_set_options(self.h, tid_cutoff, e(rank_map), e(human_kmers), e(adaptor_kmers), adaptor_tid))
+
+    def add_taxhisto(self, fn):
+        self._chk(self.lib.lmat_ingest_add_taxhisto(self.h, fn.encode()))
+
+    def save_image(self, fn):
+        self._chk(self.lib.lmat_ingest_save_image(self.h, fn.encode()))
+
+    def __len__(self):
+        return int(self.lib.lmat_ingest_size(self.h))
+
+    @property
+    def k(self):
+        return int(self.lib.lmat_ingest_kmer_length(self.h))
+
+    def lookup(self, kmer, cap=4096):
+        out = np.zeros(cap, dtype=np.uint16)
+        n = self.lib.lmat_ingest_lookup(self.h, int(kmer), _ptr(out), cap)
+        return out[:max(n, 0)].tolist()
+
+    def close(self):
+        if self.h:
+            self.lib.lmat_ingest_destroy(self.h)
+            self.h = None
+
+
 class Engine:
     """One context on one GPU (lmat_ctx)."""
 
@@ -158,10 +220,21 @@ class Engine:
         e = lambda s: s.encode() if s else None
         self._chk(self.lib.lmat_taxonomy_load_files(self.ctx, e(tree), e(depth), e(rank), e(idmap), e(plasmids)))
 
-    def build_db(self, files, k=20, table_bytes=0):
+    def build_db(self, files, k=20, table_bytes=0, tid_cutoff=0, rank_map=None, human_kmers=None, adaptor_kmers=None,
+                 save_image=None):
+        """make_db_table's job: tax_histo files (+ its -g/-m, -j, -u options) -> device table."""
+        e = lambda s: s.encode() if s else None
         self._chk(self.lib.lmat_db_begin(self.ctx, k, 0, table_bytes))
+        if tid_cutoff or human_kmers or adaptor_kmers:
+            self._chk(self.lib.lmat_db_set_build_options(self.ctx, tid_cutoff, e(rank_map), e(human_kmers), e(adaptor_kmers), 0))
         for f in ([files] if isinstance(files, str) else files):
             self._chk(self.lib.lmat_db_add_taxhisto(self.ctx, f.encode()))
+        if save_image:
+            self._chk(self.lib.lmat_db_save_image(self.ctx, save_image.encode()))
+        self._chk(self.lib.lmat_db_finalize(self.ctx))
+
+    def load_image(self, path, table_bytes=0):
+        self._chk(self.lib.lmat_db_load_image(self.ctx, path.encode(), table_bytes))
         self._chk(self.lib.lmat_db_finalize(self.ctx))
 
     def synth_taxonomy(self, branching=(3, 4, 4, 4, 4, 3)):

@@ -1,0 +1,61 @@
+// dbbuild.hpp -- host-side ingest of make_db_table's input into the engine's canonical (k-mer, payload)
+// form.  No GPU involved: this is what the `make_db_image` tool and lmat_db_add_taxhisto share.
+//
+// Restates SortedDb::add_data (src/kmerdb/SortedDb.cpp:84-751) for the tax_histo format, including the
+// options of make_db_table that change database contents (src/make_db_table.cpp:150-213,259-313):
+//   -f 32->16 map          every stored id goes through it (SortedDb.cpp:503-511,678-690)
+//   -j human k-mer feed    sorted ASCII k-mers merged in: new singleton 9606 k-mers, and 9606 appended to
+//                          the lists of matching k-mers (SortedDb.cpp:170-233,475-530,664-715)
+//   -u adaptor k-mer feed  k-mers of this set become singleton adaptor-taxid entries (SortedDb.cpp:190-204,275-292)
+//   -g N -m rank map       build-time pruning of lists longer than N by rank priority (SortedDb.cpp:296-409)
+#pragma once
+#include <stdint.h>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace lmat {
+
+// canonical payload: 1..65535 = the 16-bit DB taxid of a one-element list; 65536 + i = lists[i]
+struct Ingest {
+    int k = 0;
+    std::unordered_map<uint32_t, uint16_t> br;  // 32 -> 16
+    // options
+    int tid_cutoff = 0;
+    std::unordered_map<uint32_t, uint32_t> species_map;
+    uint32_t adaptor_tid = 32630;
+    FILE* human_fp = nullptr;
+    bool adaptor_loaded = false;
+    std::unordered_set<uint64_t> adaptor_set;
+    // output
+    std::vector<uint64_t> kmers;
+    std::vector<uint32_t> payload;
+    std::vector<std::vector<uint16_t>> lists;
+    std::map<std::vector<uint16_t>, uint32_t> list_index;
+    // add_data's function-static state
+    uint64_t last_kmer = 0;
+    uint64_t last_human = ~0ull;
+    bool human_primed = false;
+    // counters printed by add_data
+    uint64_t singletons = 0, doubles = 0, reduced_kmers = 0, cut_kmers = 0, new_human = 0, matched_in = 0, new_isect = 0;
+    std::string err;
+
+    ~Ingest() { if (human_fp) fclose(human_fp); }
+    bool load_idmap(const char* fn);
+    bool set_options(int cutoff, const char* species_map_fn, const char* human_fn, const char* adaptor_fn, uint32_t adaptor);
+    bool add_taxhisto(const char* fn);
+    bool save_image(const char* fn) const;
+    bool load_image(const char* fn);
+    // stored list of a k-mer (16-bit ids, stored order); returns false when absent
+    bool lookup(uint64_t kmer, std::vector<uint16_t>& out) const;
+
+private:
+    uint64_t read_encode(FILE* f);
+    bool to16(uint32_t tid, uint16_t& out, const char* what);
+    void push(uint64_t kmer, const std::vector<uint16_t>& lst);
+};
+
+}  // namespace lmat

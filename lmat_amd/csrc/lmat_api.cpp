@@ -90,6 +90,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
+    delete c->ingest;
     delete c;
 }
 
@@ -109,89 +110,95 @@ int lmat_taxonomy_load_files(lmat_ctx* c, const char* tree_fn, const char* depth
 }
 
 // ---------------------------------------------------------------------------------- DB
+// GPU-free ingest objects (dbbuild.cpp): what make_db_table does up to the in-memory table
+int lmat_ingest_create(int k, const char* idmap_fn, lmat_ingest** out) {
+    if (!out || !idmap_fn || k < 1 || k > 20) return LMAT_E_ARG;
+    lmat_ingest* g = new lmat_ingest();
+    g->ing.k = k;
+    if (!g->ing.load_idmap(idmap_fn)) { delete g; *out = nullptr; return LMAT_E_IO; }
+    *out = g;
+    return LMAT_OK;
+}
+void lmat_ingest_destroy(lmat_ingest* g) { delete g; }
+const char* lmat_ingest_error(const lmat_ingest* g) { return g ? g->ing.err.c_str() : "null ingest"; }
+int lmat_ingest_set_options(lmat_ingest* g, int tid_cutoff, const char* rank_map_fn, const char* human_kmers_fn,
+                            const char* adaptor_kmers_fn, uint32_t adaptor_tid) {
+    if (!g) return LMAT_E_ARG;
+    return g->ing.set_options(tid_cutoff, rank_map_fn, human_kmers_fn, adaptor_kmers_fn, adaptor_tid) ? LMAT_OK : LMAT_E_IO;
+}
+int lmat_ingest_add_taxhisto(lmat_ingest* g, const char* fn) {
+    if (!g || !fn) return LMAT_E_ARG;
+    return g->ing.add_taxhisto(fn) ? LMAT_OK : LMAT_E_IO;
+}
+int lmat_ingest_save_image(const lmat_ingest* g, const char* fn) {
+    if (!g || !fn) return LMAT_E_ARG;
+    return g->ing.save_image(fn) ? LMAT_OK : LMAT_E_IO;
+}
+int lmat_ingest_load_image(const char* fn, lmat_ingest** out) {
+    if (!fn || !out) return LMAT_E_ARG;
+    lmat_ingest* g = new lmat_ingest();
+    if (!g->ing.load_image(fn)) { delete g; *out = nullptr; return LMAT_E_IO; }
+    *out = g;
+    return LMAT_OK;
+}
+uint64_t lmat_ingest_size(const lmat_ingest* g) { return g ? g->ing.kmers.size() : 0; }
+int lmat_ingest_kmer_length(const lmat_ingest* g) { return g ? g->ing.k : 0; }
+int lmat_ingest_lookup(const lmat_ingest* g, uint64_t kmer, uint16_t* tids16, int cap) {
+    if (!g) return LMAT_E_ARG;
+    std::vector<uint16_t> l;
+    if (!g->ing.lookup(kmer, l)) return 0;
+    for (int i = 0; i < (int)l.size() && i < cap; ++i) tids16[i] = l[i];
+    return (int)l.size();
+}
+
 int lmat_db_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_bytes) {
     if (!c) return LMAT_E_ARG;
     if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
     if (k < 1 || k > 20) return set_err(c, LMAT_E_ARG, "k must be in 1..20 (40-bit keys)");
-    c->builder = DbBuilder();
-    c->builder.k = k;
-    c->builder.table_bytes = table_bytes;
-    c->builder.open = true;
-    if (n_kmers_hint) { c->builder.kmers.reserve(n_kmers_hint); c->builder.payload.reserve(n_kmers_hint); }
+    delete c->ingest;
+    c->ingest = new Ingest();
+    c->ingest->k = k;
+    c->ingest->br = c->tax.br;
+    c->ingest_table_bytes = table_bytes;
+    if (n_kmers_hint) { c->ingest->kmers.reserve(n_kmers_hint); c->ingest->payload.reserve(n_kmers_hint); }
     c->db_ready = false;
     return LMAT_OK;
 }
 
-// tax_histo binary: KmerFileMetaData header (src/kmerdb/KmerFileMetaData.cpp:44-94) then
-// u64 kmer | u16 n | n x u32 taxid, a u64 ~0 after every 1500th record
-// (src/tax_histo.cpp:257-281, src/kmerdb/SortedDb.cpp:159-167,236-243,717-722).
+int lmat_db_set_build_options(lmat_ctx* c, int tid_cutoff, const char* rank_map_fn, const char* human_kmers_fn,
+                              const char* adaptor_kmers_fn, uint32_t adaptor_tid) {
+    if (!c || !c->ingest) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
+    if (!c->ingest->set_options(tid_cutoff, rank_map_fn, human_kmers_fn, adaptor_kmers_fn, adaptor_tid))
+        return set_err(c, LMAT_E_IO, c->ingest->err);
+    return LMAT_OK;
+}
+
 int lmat_db_add_taxhisto(lmat_ctx* c, const char* fn) {
     if (!c || !fn) return LMAT_E_ARG;
-    DbBuilder& B = c->builder;
-    if (!B.open) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
-    FILE* in = fopen(fn, "rb");
-    if (!in) return set_err(c, LMAT_E_IO, std::string("Error: unable to open kmer db [") + fn + "]");
-    fseek(in, 0, SEEK_END);
-    const long fsz = ftell(in);
-    fseek(in, 0, SEEK_SET);
-    uint32_t data_start, version, klen;
-    uint64_t kmer_count, test;
-    char loc;
-    bool ok = fread(&data_start, 4, 1, in) == 1 && fread(&kmer_count, 8, 1, in) == 1 && fread(&test, 8, 1, in) == 1 &&
-              fread(&version, 4, 1, in) == 1 && fread(&loc, 1, 1, in) == 1 && fread(&klen, 4, 1, in) == 1;
-    if (!ok || test != ~0ull) { fclose(in); return set_err(c, LMAT_E_IO, "kmer data file is invalid; should have read 64 1s, but didn't"); }
-    if (version != 999 || loc != 'N') { fclose(in); return set_err(c, LMAT_E_IO, "not a tax_histo file (version/location flag)"); }
-    if ((int)klen != B.k) { fclose(in); return set_err(c, LMAT_E_IO, "k-mer length of file differs from lmat_db_begin"); }
-    const HostTaxonomy& T = c->tax;
-    std::vector<uint16_t> raw;
-    int rc = LMAT_OK;
-    for (uint64_t i = 0; i < kmer_count; ++i) {
-        if (ftell(in) == fsz) break;
-        uint64_t kmer;
-        uint16_t n;
-        if (fread(&kmer, 8, 1, in) != 1 || fread(&n, 2, 1, in) != 1) { rc = set_err(c, LMAT_E_IO, "truncated tax_histo record"); break; }
-        if (B.last_kmer > 0 && kmer <= B.last_kmer) { rc = set_err(c, LMAT_E_IO, "Kmers arriving out of order."); break; }
-        if (kmer >> (2 * B.k)) { rc = set_err(c, LMAT_E_IO, "k-mer wider than 2k bits"); break; }
-        raw.resize(n);
-        bool plain = n == 1;
-        for (uint16_t j = 0; j < n; ++j) {
-            uint32_t tid;
-            if (fread(&tid, 4, 1, in) != 1) { rc = set_err(c, LMAT_E_IO, "truncated taxid list"); break; }
-            auto b = T.br.find(tid);
-            const uint16_t t16 = b == T.br.end() ? 0 : b->second;
-            if (t16 == 0 || t16 > T.br.size() + 1) {  // SortedDb.cpp:503-511,678-690
-                rc = set_err(c, LMAT_E_TAXONOMY, "bad read: " + std::to_string(tid) + " " + std::to_string(t16));
-                break;
-            }
-            raw[j] = t16;
-        }
-        if (rc) break;
-        uint32_t payload = 0;
-        if (plain) {
-            const uint32_t t32 = T.conv[raw[0]];
-            const bool special = t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
-            auto it = T.index_of.find(t32);
-            if (!special && it != T.index_of.end()) payload = it->second;
-        }
-        if (!payload) {
-            auto li = B.list_index.find(raw);
-            uint32_t idx;
-            if (li == B.list_index.end()) {
-                idx = (uint32_t)B.lists.size();
-                B.lists.push_back(raw);
-                B.list_index[raw] = idx;
-            } else idx = li->second;
-            payload = kListBase + idx;
-        }
-        B.kmers.push_back(kmer);
-        B.payload.push_back(payload);
-        if ((i + 1) % 1500 == 0) {
-            if (fread(&test, 8, 1, in) != 1 || test != ~0ull) { rc = set_err(c, LMAT_E_IO, "tax_histo sanity word missing"); break; }
-        }
-        B.last_kmer = kmer;
+    if (!c->ingest) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
+    if (!c->ingest->add_taxhisto(fn)) {
+        const bool tax = c->ingest->err.compare(0, 3, "bad") == 0;
+        return set_err(c, tax ? LMAT_E_TAXONOMY : LMAT_E_IO, c->ingest->err);
     }
-    fclose(in);
-    return rc;
+    return LMAT_OK;
+}
+
+int lmat_db_save_image(lmat_ctx* c, const char* fn) {
+    if (!c || !fn) return LMAT_E_ARG;
+    if (!c->ingest) return set_err(c, LMAT_E_ARG, "no open ingest: save the image between lmat_db_begin and lmat_db_finalize");
+    return c->ingest->save_image(fn) ? LMAT_OK : set_err(c, LMAT_E_IO, std::string("cannot write ") + fn);
+}
+
+int lmat_db_load_image(lmat_ctx* c, const char* fn, uint64_t table_bytes) {
+    if (!c || !fn) return LMAT_E_ARG;
+    if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
+    delete c->ingest;
+    c->ingest = new Ingest();
+    c->ingest_table_bytes = table_bytes;
+    c->db_ready = false;
+    if (!c->ingest->load_image(fn)) return set_err(c, LMAT_E_IO, c->ingest->err);
+    if (c->ingest->k < 1 || c->ingest->k > 20) return set_err(c, LMAT_E_IO, "image holds an unsupported k-mer length");
+    return LMAT_OK;
 }
 
 static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes) {
@@ -209,43 +216,62 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes) {
     return LMAT_OK;
 }
 
-int lmat_db_finalize(lmat_ctx* c) {
-    if (!c) return LMAT_E_ARG;
-    DbBuilder& B = c->builder;
-    if (!B.open) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
+// canonical payloads (16-bit DB id / list number) -> device payloads (internal taxid index / arena offset)
+static int build_device_db(lmat_ctx* c, Ingest& B, uint64_t table_bytes) {
     hipSetDevice(c->device);
-    // arena of distinct list records
+    const HostTaxonomy& T = c->tax;
     std::vector<uint16_t> arena(2, 0);  // offset 0 reserved
-    std::vector<uint32_t> list_off(B.lists.size());
+    std::vector<uint32_t> list_pay(B.lists.size());
     std::vector<uint16_t> rec;
     for (size_t i = 0; i < B.lists.size(); ++i) {
-        if (!build_list_record(c, B.lists[i], rec)) return c->err.empty() ? LMAT_E_TAXONOMY : LMAT_E_TAXONOMY;
-        list_off[i] = (uint32_t)(arena.size() / 2);
+        if (!build_list_record(c, B.lists[i], rec)) return LMAT_E_TAXONOMY;
+        list_pay[i] = kListBase + (uint32_t)(arena.size() / 2);
         arena.insert(arena.end(), rec.begin(), rec.end());
+    }
+    // one-element lists: a plain taxid index unless the id needs per-list treatment (unmapped, human
+    // variants folded to 9606, ignored ids): those get a one-element list record
+    std::vector<uint32_t> single_pay(65536, 0);
+    std::vector<uint16_t> one(1);
+    for (size_t i = 0; i < B.payload.size(); ++i) {
+        const uint32_t p = B.payload[i];
+        if (p >= kListBase || single_pay[p]) continue;
+        const uint32_t t32 = T.conv[p];
+        const bool special = t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
+        auto it = T.index_of.find(t32);
+        if (!special && it != T.index_of.end()) {
+            single_pay[p] = it->second;
+        } else {
+            one[0] = (uint16_t)p;
+            if (!build_list_record(c, one, rec)) return LMAT_E_TAXONOMY;
+            single_pay[p] = kListBase + (uint32_t)(arena.size() / 2);
+            arena.insert(arena.end(), rec.begin(), rec.end());
+        }
     }
     if (arena.size() / 2 + kListBase > kPayloadMask)
         return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
-    for (size_t i = 0; i < B.payload.size(); ++i)
-        if (B.payload[i] >= kListBase) B.payload[i] = kListBase + list_off[B.payload[i] - kListBase];
     int rc;
     if ((rc = dev_upload(c, &c->dev.arena, arena))) return rc;
     c->arena_words = arena.size();
     const uint64_t n = B.kmers.size();
-    if ((rc = alloc_table(c, n, B.table_bytes))) return rc;
+    if ((rc = alloc_table(c, n, table_bytes))) return rc;
     c->dev.k = B.k;
-    // upload pairs in chunks and insert
     const uint64_t chunk = 1ull << 24;
     uint64_t* d_k = nullptr;
     uint32_t* d_p = nullptr;
     uint32_t* d_fail = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_k, std::min(chunk, std::max<uint64_t>(n, 1)) * 8));
-    HIPCHK(c, hipMalloc((void**)&d_p, std::min(chunk, std::max<uint64_t>(n, 1)) * 4));
+    std::vector<uint32_t> pay(std::min(chunk, std::max<uint64_t>(n, 1)));
+    HIPCHK(c, hipMalloc((void**)&d_k, pay.size() * 8));
+    HIPCHK(c, hipMalloc((void**)&d_p, pay.size() * 4));
     HIPCHK(c, hipMalloc((void**)&d_fail, 4));
     HIPCHK(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
     for (uint64_t s = 0; s < n; s += chunk) {
         const uint64_t m = std::min(chunk, n - s);
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint32_t p = B.payload[s + i];
+            pay[i] = p < kListBase ? single_pay[p] : list_pay[p - kListBase];
+        }
         HIPCHK(c, hipMemcpyAsync(d_k, B.kmers.data() + s, m * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_p, B.payload.data() + s, m * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_p, pay.data(), m * 4, hipMemcpyHostToDevice, c->stream));
         launch_insert_pairs(c->dev.slots, c->dev.nbuckets, d_k, d_p, m, d_fail, c->stream);
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -255,8 +281,23 @@ int lmat_db_finalize(lmat_ctx* c) {
     if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during insert");
     c->n_kmers = n;
     c->db_ready = true;
-    B = DbBuilder();
     return LMAT_OK;
+}
+
+int lmat_db_finalize(lmat_ctx* c) {
+    if (!c) return LMAT_E_ARG;
+    if (!c->ingest) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
+    int rc = build_device_db(c, *c->ingest, c->ingest_table_bytes);
+    delete c->ingest;
+    c->ingest = nullptr;
+    return rc;
+}
+
+int lmat_db_from_ingest(lmat_ctx* c, lmat_ingest* g, uint64_t table_bytes) {
+    if (!c || !g) return LMAT_E_ARG;
+    if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
+    c->db_ready = false;
+    return build_device_db(c, g->ing, table_bytes);
 }
 
 int lmat_db_kmer_length(const lmat_ctx* c) { return c ? c->dev.k : 0; }

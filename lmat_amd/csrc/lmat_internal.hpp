@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../include/lmat_hip.h"
 #include "lmat_common.hpp"
+#include "dbbuild.hpp"
 
 namespace lmat {
 
@@ -55,17 +56,6 @@ struct KernelParams {
     int stop_after;  // debug/profiling only (env LMAT_STOP_AFTER): 0 = full path, n = return after phase n
 };
 
-struct DbBuilder {
-    int k = 0;
-    uint64_t table_bytes = 0;
-    std::vector<uint64_t> kmers;
-    std::vector<uint32_t> payload;  // provisional: < kListBase = singleton internal idx, else kListBase + list number
-    std::vector<std::vector<uint16_t>> lists;  // distinct raw lists (16-bit DB ids, stored order)
-    std::map<std::vector<uint16_t>, uint32_t> list_index;
-    uint64_t last_kmer = 0;
-    bool open = false;
-};
-
 }  // namespace lmat
 
 struct lmat_reads {
@@ -76,6 +66,10 @@ struct lmat_reads {
     uint32_t max_len = 0;
 };
 
+struct lmat_ingest {
+    lmat::Ingest ing;
+};
+
 struct lmat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -83,7 +77,8 @@ struct lmat_ctx {
     std::string err;
     lmat::HostTaxonomy tax;
     lmat::DeviceTables dev;
-    lmat::DbBuilder builder;
+    lmat::Ingest* ingest = nullptr;      // open between lmat_db_begin / lmat_db_load_image and lmat_db_finalize
+    uint64_t ingest_table_bytes = 0;
     uint64_t n_kmers = 0;
     uint64_t arena_words = 0;  // u16 units
     bool db_ready = false;

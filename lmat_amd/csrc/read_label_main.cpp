@@ -8,8 +8,8 @@
 // reads, formats records and merges tallies (:1760-1800).
 //
 // Differences that are forced by the environment, all loud:
-//   * -d takes a tax_histo binary (make_db_table's input) or a text file listing several; PERM heap
-//     images cannot be opened without perm-je.
+//   * -d takes an image written by make_db_image, a tax_histo binary (make_db_table's input) or a text
+//     file listing several; PERM heap images cannot be opened without perm-je.
 //   * -n (null models), -s (permissive), -g/-m (run-time pruning) are not implemented yet: the
 //     program refuses them instead of ignoring them.
 //   * -t N is the number of output shards (<o>0.out .. <o>N-1.out) and of formatter threads; reads
@@ -161,7 +161,17 @@ int main(int argc, char* argv[]) {
         while (l >> f) files.push_back(f);
     } else files.push_back(kmer_db_fn);
     if (files.empty()) { std::cerr << "Error: unable to open kmer db [" << kmer_db_fn << "]" << std::endl; return -1; }
+    bool is_image = false;
     {
+        FILE* f = fopen(files[0].c_str(), "rb");
+        char magic[8] = {0};
+        if (f) { if (fread(magic, 1, 8, f) == 8 && memcmp(magic, "LMATIMG1", 8) == 0) is_image = true; fclose(f); }
+    }
+    if (is_image) {  // image written by make_db_image (the engine's counterpart of the PERM .db file)
+        if (lmat_db_load_image(ctx, files[0].c_str(), 0) != LMAT_OK) return fail("k-mer DB image");
+        if (lmat_db_finalize(ctx) != LMAT_OK) return fail("k-mer DB image");
+        if (k_size < 1) k_size = lmat_db_kmer_length(ctx);
+    } else {
         // k-mer length comes from the first file's header (KmerFileMetaData.cpp:44-94)
         FILE* f = fopen(files[0].c_str(), "rb");
         if (!f) { std::cerr << "Error: unable to open kmer db [" << files[0] << "]" << std::endl; return -1; }
@@ -171,10 +181,10 @@ int main(int argc, char* argv[]) {
         fclose(f);
         if (k_size < 1) k_size = (int)klen;
         if (lmat_db_begin(ctx, (int)klen, 0, 0) != LMAT_OK) return fail("k-mer DB");
+        for (auto& fn : files)
+            if (lmat_db_add_taxhisto(ctx, fn.c_str()) != LMAT_OK) return fail("k-mer DB");
+        if (lmat_db_finalize(ctx) != LMAT_OK) return fail("k-mer DB");
     }
-    for (auto& f : files)
-        if (lmat_db_add_taxhisto(ctx, f.c_str()) != LMAT_OK) return fail("k-mer DB");
-    if (lmat_db_finalize(ctx) != LMAT_OK) return fail("k-mer DB");
     std::cout << "Loaded k-mer DB into a " << (lmat_db_table_bytes(ctx) >> 20) << " MiB GPU hash. Num of k-mers: " << lmat_db_size(ctx)
               << " of size " << k_size << std::endl;
     if (k_size <= 0) { std::cerr << "ERROR! Unable to read database, k-mer size=" << k_size << std::endl; return -1; }

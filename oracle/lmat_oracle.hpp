@@ -36,6 +36,7 @@
 #include <iostream>
 #include <list>
 #include <map>
+#include <queue>
 #include <set>
 #include <sstream>
 #include <string>
@@ -202,8 +203,53 @@ struct KmerDb {
     int k = 0;
     std::unordered_map<kmer_t, std::vector<uint16_t>> table;
     kmer_t last_kmer = 0;  // add_data's static last_kmer: ordering is checked across files
+    // make_db_table options that change the stored lists (src/make_db_table.cpp:150-213,303-313)
+    int tid_cutoff = 0;                                   // -g
+    std::unordered_map<uint32_t, uint32_t> species_map;   // -m (taxid -> numeric rank)
+    FILE* human_fp = nullptr;                             // -j sorted ASCII k-mers
+    bool have_adaptors = false;                           // -u
+    std::unordered_set<kmer_t> adaptor_set;
+    uint32_t adaptor_tid = 32630;
+    kmer_t last_human = ~(kmer_t)0;                       // add_data's static last_human
+    bool human_primed = false;
 
-    // KmerFileMetaData::read (src/kmerdb/KmerFileMetaData.cpp:44-94)
+    struct MyPair {  // SortedDb.hpp:129-139
+        unsigned int first;
+        uint32_t second;
+        MyPair(unsigned int f, uint32_t s) : first(f), second(s) {}
+        bool operator<(const MyPair& mp) const { return first < mp.first; }
+    };
+    // read_encode + kencode_c::kencode (SortedDb.cpp:39-59, include/kencode.hpp:27-40,79-85)
+    kmer_t read_encode(FILE* f) const {
+        char buf[64];
+        if (fscanf(f, "%63s", buf) == EOF || strlen(buf) == 0) return ~(kmer_t)0;
+        kmer_t v = 0;
+        for (int i = 0; i < k; ++i) {
+            int t = encode_base_fwd(buf[i]);
+            v = (v << 2) | (kmer_t)t;
+        }
+        return v;
+    }
+    static int encode_base_fwd(char c) {
+        switch (c) { case 'a': case 'A': return 0; case 'c': case 'C': return 1; case 'g': case 'G': return 2; case 't': case 'T': return 3; }
+        return 0;
+    }
+    bool set_options(int cutoff, const std::string& rank_map_fn, const std::string& human_fn, const std::string& adaptor_fn) {
+        tid_cutoff = cutoff;
+        if (cutoff > 0 && !rank_map_fn.empty()) {
+            FILE* f = fopen(rank_map_fn.c_str(), "r");
+            if (!f) return false;
+            int a, b;
+            while (fscanf(f, "%d%d", &a, &b) > 0) species_map[(uint32_t)a] = (uint32_t)b;
+            fclose(f);
+        }
+        if (!human_fn.empty()) { human_fp = fopen(human_fn.c_str(), "r"); if (!human_fp) return false; }
+        adaptor_file = adaptor_fn;  // encoded inside add_data once k is known (SortedDb.cpp:103,114-118)
+        return true;
+    }
+    std::string adaptor_file;
+
+    // KmerFileMetaData::read (src/kmerdb/KmerFileMetaData.cpp:44-94) + SortedDb::add_data (SortedDb.cpp:84-751)
     bool add_taxhisto(const std::string& fn, const Taxonomy& tax, std::string* err) {
         FILE* in = fopen(fn.c_str(), "rb");
         if (!in) { if (err) *err = "cannot open " + fn; return false; }
@@ -222,32 +268,96 @@ struct KmerDb {
             return false;
         }
         if (k == 0) k = (int)klen;
+        if (human_fp && !human_primed) { last_human = read_encode(human_fp); human_primed = true; }
+        if (!have_adaptors && !adaptor_file.empty()) {  // get_kmer_set, SortedDb.cpp:61-80
+            FILE* f = fopen(adaptor_file.c_str(), "r");
+            if (!f) { if (err) *err = "cannot open " + adaptor_file; fclose(in); return false; }
+            kmer_t km;
+            while ((km = read_encode(f)) != ~(kmer_t)0) adaptor_set.insert(km);
+            fclose(f);
+            have_adaptors = true;
+        }
+        auto map16 = [&](uint32_t tid, uint16_t& out) -> bool {  // SortedDb.cpp:503-511,678-690
+            auto b = tax.br.find(tid);
+            uint16_t t16 = b == tax.br.end() ? 0 : b->second;
+            if (t16 == 0 || t16 > tax.br.size() + 1) {
+                if (err) { std::ostringstream o; o << "bad read: " << tid << " " << t16; *err = o.str(); }
+                return false;
+            }
+            out = t16;
+            return true;
+        };
+        uint16_t HUMAN_16 = 0, ADAPTOR_16 = 0;
+        { auto h = tax.br.find(9606); if (h != tax.br.end()) HUMAN_16 = h->second; }
+        { auto a = tax.br.find(adaptor_tid); if (a != tax.br.end()) ADAPTOR_16 = a->second; }
         for (uint64_t i = 0; i < kmer_count; ++i) {
             if (ftell(in) == fsz) break;  // SortedDb.cpp:159
             kmer_t kmer;
-            uint16_t n;
-            if (fread(&kmer, 8, 1, in) != 1 || fread(&n, 2, 1, in) != 1) {
-                if (err) *err = "truncated tax_histo record";
-                fclose(in);
-                return false;
-            }
+            uint16_t tid_count;
+            if (fread(&kmer, 8, 1, in) != 1) { if (err) *err = "truncated tax_histo record"; fclose(in); return false; }
             if (last_kmer > 0 && kmer <= last_kmer) {  // SortedDb.cpp:164-167
                 if (err) *err = "Kmers arriving out of order";
                 fclose(in);
                 return false;
             }
+            while (last_human < kmer) {  // SortedDb.cpp:170-222: human k-mers the stream does not contain
+                const bool ad = have_adaptors && adaptor_set.count(last_human);
+                table[last_human] = std::vector<uint16_t>(1, ad ? (ADAPTOR_16 ? ADAPTOR_16 : (uint16_t)adaptor_tid)
+                                                                 : (HUMAN_16 ? HUMAN_16 : (uint16_t)9606));
+                last_human = read_encode(human_fp);
+            }
+            bool add_human = false;
+            if (last_human == kmer) { add_human = true; last_human = read_encode(human_fp); }  // :226-233
+            if (fread(&tid_count, 2, 1, in) != 1) { if (err) *err = "truncated tax_histo record"; fclose(in); return false; }
+            std::vector<uint32_t> tids(tid_count);
+            for (uint16_t j = 0; j < tid_count; ++j)
+                if (fread(&tids[j], 4, 1, in) != 1) { if (err) *err = "truncated taxid list"; fclose(in); return false; }
             std::vector<uint16_t>& lst = table[kmer];
-            for (uint16_t j = 0; j < n; ++j) {
-                uint32_t tid;
-                if (fread(&tid, 4, 1, in) != 1) { if (err) *err = "truncated taxid list"; fclose(in); return false; }
-                auto b = tax.br.find(tid);  // SortedDb.cpp:503-511,678-690
-                uint16_t t16 = b == tax.br.end() ? 0 : b->second;
-                if (t16 == 0 || t16 > tax.br.size() + 1) {
-                    if (err) { std::ostringstream o; o << "bad read: " << tid << " " << t16; *err = o.str(); }
-                    fclose(in);
-                    return false;
+            lst.clear();
+            uint16_t t16 = 0;
+            if (have_adaptors && adaptor_set.count(kmer)) {  // :275-292
+                lst.push_back(ADAPTOR_16 ? ADAPTOR_16 : (uint16_t)adaptor_tid);
+            } else {
+                uint16_t tmp = tid_count;
+                std::priority_queue<MyPair> q;
+                if (tid_cutoff > 0 && tid_count > tid_cutoff) {  // :296-409
+                    if (species_map.size() == 0) {
+                        tmp = 0;
+                    } else {
+                        for (uint16_t j = 0; j < tid_count; ++j) {
+                            if (add_human && tids[j] == 9606) add_human = false;
+                            q.push(MyPair(species_map[tids[j]], tids[j]));
+                        }
+                        if (add_human) q.push(MyPair(species_map[9606], 9606));
+                        while (!q.empty()) {
+                            int cur = q.top().first;
+                            while ((int)q.top().first == cur) { q.pop(); if (q.empty()) break; }
+                            if ((int)q.size() <= tid_cutoff) { tmp = q.size(); break; }
+                        }
+                        if (q.size() == 0) { tmp = 1; q.push(MyPair(1, 1)); }
+                    }
                 }
-                lst.push_back(t16);
+                bool good = true;
+                if (tmp > 1 && q.size() > 1) {           // :589-637
+                    for (int j = 0; j < tmp && good; ++j) { good = map16(q.top().second, t16); q.pop(); lst.push_back(t16); }
+                } else if (tmp > 1) {                     // :640-712
+                    for (uint16_t j = 0; j < tid_count && good; ++j) {
+                        if (tids[j] == 9606) add_human = false;
+                        good = map16(tids[j], t16);
+                        lst.push_back(t16);
+                    }
+                    if (good && add_human) { good = map16(9606, t16); lst.push_back(t16); }
+                } else if (tid_count == 1) {              // :426-515
+                    good = map16(tids[0], t16);
+                    lst.push_back(t16);
+                    if (add_human && tids[0] != 9606) lst.push_back(HUMAN_16);
+                } else if (tmp == 1) {                    // :517-533
+                    good = map16(q.top().second, t16);
+                    lst.push_back(t16);
+                } else {                                  // :534-538
+                    lst.push_back(1);
+                }
+                if (!good) { fclose(in); return false; }
             }
             if ((i + 1) % 1500 == 0) {  // TAX_HISTO_SANITY_COUNT, SortedDb.cpp:717-722
                 if (fread(&test, 8, 1, in) != 1 || test != ~(uint64_t)0) {

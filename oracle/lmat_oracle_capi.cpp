@@ -27,6 +27,9 @@ orc_ctx* orc_create(const char* tree, const char* depth, const char* rank, const
 void orc_destroy(orc_ctx* c) { delete c; }
 const char* orc_error(orc_ctx* c) { return c->err.c_str(); }
 
+int orc_set_build_options(orc_ctx* c, int tid_cutoff, const char* rank_map, const char* human, const char* adaptors) {
+    return c->db.set_options(tid_cutoff, rank_map ? rank_map : "", human ? human : "", adaptors ? adaptors : "") ? 0 : -1;
+}
 int orc_add_taxhisto(orc_ctx* c, const char* fn) { return c->db.add_taxhisto(fn, c->tax, &c->err) ? 0 : -1; }
 int orc_db_k(orc_ctx* c) { return c->db.k; }
 void orc_set_k(orc_ctx* c, int k) { c->db.k = k; }

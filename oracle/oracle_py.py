@@ -30,6 +30,7 @@ def _load():
     L.orc_error.restype = cp
     L.orc_error.argtypes = [vp]
     L.orc_add_taxhisto.argtypes = [vp, cp]
+    L.orc_set_build_options.argtypes = [vp, i32, cp, cp, cp]
     L.orc_db_k.argtypes = [vp]
     L.orc_set_k.argtypes = [vp, i32]
     L.orc_db_size.restype = u64
@@ -65,6 +66,11 @@ class Oracle:
         if self.h:
             self.L.orc_destroy(self.h)
             self.h = None
+
+    def set_build_options(self, tid_cutoff=0, rank_map=None, human=None, adaptors=None):
+        e = lambda s: s.encode() if s else b""
+        if self.L.orc_set_build_options(self.h, tid_cutoff, e(rank_map), e(human), e(adaptors)) != 0:
+            raise RuntimeError("oracle: cannot read build-option files")
 
     def add_taxhisto(self, fn):
         if self.L.orc_add_taxhisto(self.h, fn.encode()) != 0:

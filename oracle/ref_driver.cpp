@@ -18,7 +18,7 @@
 using namespace metag;
 
 static int do_lookup(int argc, char** argv) {
-    // lookup <taxhisto.bin> <map32to16.txt> <kmers.txt> [n_kmers_hint]
+    // lookup <taxhisto.bin> <map32to16.txt> <kmers.txt> [n_kmers_hint [tid_cutoff rank_map|- human_kmers|- adaptor_kmers|-]]
     if (argc < 5) return 2;
     bitreduce_map_t br_map;
     id_convback_map_t conv_map;
@@ -38,7 +38,16 @@ static int do_lookup(int argc, char** argv) {
     SortedDb<uint16_t>* db = new SortedDb<uint16_t>(n_kmers, space);
     db->set_kmer_length(20);
     my_map species_map;
-    db->add_data(argv[2], 0, true, &br_map, species_map, 0, false, NULL, NULL, 32630);
+    int tid_cut = argc > 6 ? atoi(argv[6]) : 0;
+    if (argc > 7 && std::string(argv[7]) != "-" && tid_cut > 0) {  // make_db_table.cpp:303-313
+        FILE* smfp = fopen(argv[7], "r");
+        uint32_t src, dest;
+        while (fscanf(smfp, "%d%d", &src, &dest) > 0) species_map[src] = dest;
+        fclose(smfp);
+    }
+    FILE* human_fp = (argc > 8 && std::string(argv[8]) != "-") ? fopen(argv[8], "r") : NULL;
+    FILE* illu_fp = (argc > 9 && std::string(argv[9]) != "-") ? fopen(argv[9], "r") : NULL;
+    db->add_data(argv[2], 0, true, &br_map, species_map, tid_cut, false, human_fp, illu_fp, 32630);
     std::ifstream kin(argv[4]);
     uint64_t kmer;
     my_map tid_rank_map;

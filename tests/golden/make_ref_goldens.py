@@ -37,7 +37,6 @@ with open(os.path.join(here, "ref_lookup.txt"), "w") as o:
     out = subprocess.run([os.path.join(ref, "ref_lookup"), "lookup", info["db"], info["idmap"], kf, "200000"],
                          capture_output=True, text=True, check=True).stdout
     o.write("".join(l + "\n" for l in out.splitlines() if l and l[0].isdigit()))
-os.remove(kf)
 with open(os.path.join(here, "ref_paths.txt"), "w") as o:
     o.write(subprocess.run([os.path.join(ref, "ref_lookup"), "paths", info["tree"]], capture_output=True, text=True,
                            check=True).stdout)
@@ -56,4 +55,34 @@ open(sf, "w").write("\n".join(strs) + "\n")
 with open(os.path.join(here, "ref_kencode.txt"), "w") as o:
     o.write(subprocess.run([os.path.join(ref, "ref_kencode"), "20", sf], capture_output=True, text=True, check=True).stdout)
 os.remove(sf)
+# ---- make_db_table options: pruning (-g 2 -m rank map), human feed (-j), adaptor feed (-u)
+def decode(v, k=20):
+    return "".join("ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+tax = synth.make_taxonomy((2, 2, 2, 2, 3, 3), True)
+with open(os.path.join(ds, "numeric_ranks.txt"), "w") as f:
+    for t in tax.ids:
+        f.write(f"{t} {tax.depth[t]}\n")
+dbk, lists = synth.build_kmer_table(tax, synth.make_genomes(tax, 300, 2002), 20)
+rng2 = np.random.default_rng(11)
+multi = [int(k) for k, l in zip(dbk.tolist(), lists) if len(l) > 1]
+single = [int(k) for k, l in zip(dbk.tolist(), lists) if len(l) == 1]
+human = sorted(set(rng2.choice(multi, 150, replace=False).tolist() + rng2.choice(single, 150, replace=False).tolist()
+                   + rng2.integers(0, 1 << 40, size=300, dtype=np.uint64).tolist()))
+human = [h for h in human if h < int(dbk.max())]  # the reference only merges human k-mers below the last DB k-mer
+with open(os.path.join(ds, "human_kmers.txt"), "w") as f:
+    f.write("\n".join(decode(h) for h in human) + "\n")
+adapt = sorted(set(rng2.choice(multi, 20, replace=False).tolist() + human[5:25:2]))
+with open(os.path.join(ds, "adaptor_kmers.txt"), "w") as f:
+    f.write("\n".join(decode(a) for a in adapt) + "\n")
+q = np.unique(np.concatenate([kms, np.array(human, dtype=np.uint64), np.array(adapt, dtype=np.uint64)]))
+np.savetxt(kf, q, fmt="%d")
+with open(os.path.join(here, "ref_lookup_opts.txt"), "w") as o:
+    out = subprocess.run([os.path.join(ref, "ref_lookup"), "lookup", info["db"], info["idmap"], kf, "200000", "2",
+                          os.path.join(ds, "numeric_ranks.txt"), os.path.join(ds, "human_kmers.txt"),
+                          os.path.join(ds, "adaptor_kmers.txt")], capture_output=True, text=True, check=True).stdout
+    o.write("".join(l + "\n" for l in out.splitlines() if l and l[0].isdigit() and len(l.split()) >= 2 and l.split()[1].isdigit()))
+os.remove(kf)
+print("option lookups:", q.size)
 print("k-mers looked up:", kms.size, "db k-mers:", info["n_kmers"], "reads:", len(reads))

@@ -1,0 +1,86 @@
+"""DB ingest tooling on CPU: the engine's GPU-free ingest and the oracle reproduce what the
+REFERENCE's SortedDb::add_data stores under make_db_table's options (-g/-m pruning, -j human feed, -u adaptor
+feed); fixtures come from the reference compiled in place (tests/golden/make_ref_goldens.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+DS = os.path.join(G, "ds")
+OPTS = dict(tid_cutoff=2, rank_map=os.path.join(DS, "numeric_ranks.txt"), human_kmers=os.path.join(DS, "human_kmers.txt"),
+            adaptor_kmers=os.path.join(DS, "adaptor_kmers.txt"))
+
+
+def _golden(name):
+    out = []
+    for line in open(os.path.join(G, name)):
+        f = line.split()
+        out.append((int(f[0]), [int(x) for x in f[2:]]))
+    return out
+
+
+def _conv():
+    m = {}
+    for line in open(os.path.join(DS, "map32to16.txt")):
+        a, b = line.split()
+        m[int(b)] = int(a)
+    return m
+
+
+@pytest.mark.parametrize("with_opts", [False, True])
+def test_ingest_matches_reference_add_data(with_opts, tmp_path):
+    from lmat_amd import Ingest
+    ing = Ingest(20, os.path.join(DS, "map32to16.txt"))
+    if with_opts:
+        ing.set_options(**OPTS)
+    ing.add_taxhisto(os.path.join(DS, "th.bin"))
+    conv = _conv()
+    gold = _golden("ref_lookup_opts.txt" if with_opts else "ref_lookup.txt")
+    changed = 0
+    for km, want in gold:
+        got = [conv[t] for t in ing.lookup(km)]
+        assert got == want, km
+    if with_opts:
+        plain = dict(_golden("ref_lookup.txt"))
+        changed = sum(1 for km, want in gold if km in plain and plain[km] != want)
+        assert changed > 1000  # pruning / feeds really changed lists
+    # image round trip through the GPU-free tool path
+    img = str(tmp_path / "db.img")
+    ing.save_image(img)
+    back = Ingest(image=img)
+    assert len(back) == len(ing) and back.k == 20
+    for km, want in gold[::37]:
+        assert [conv[t] for t in back.lookup(km)] == want
+    ing.close()
+    back.close()
+
+
+def test_oracle_matches_reference_add_data_with_options():
+    import oracle_py
+    o = oracle_py.Oracle(os.path.join(DS, "tax.dat"), os.path.join(DS, "depth.dat"), os.path.join(DS, "rank.txt"),
+                         os.path.join(DS, "map32to16.txt"))
+    o.set_build_options(OPTS["tid_cutoff"], OPTS["rank_map"], OPTS["human_kmers"], OPTS["adaptor_kmers"])
+    o.add_taxhisto(os.path.join(DS, "th.bin"))
+    for km, want in _golden("ref_lookup_opts.txt"):
+        n, lst = o.lookup(km)
+        assert (lst.tolist() if n > 0 else []) == want
+    o.close()
+
+
+def test_make_db_image_tool(tmp_path):
+    exe = os.path.join(ROOT, "lmat_amd", "csrc", "make_db_image")
+    img = str(tmp_path / "t.img")
+    r = subprocess.run([exe, "-i", os.path.join(DS, "th.bin"), "-o", img, "-k", "20", "-f", os.path.join(DS, "map32to16.txt"),
+                        "-g", "2", "-m", OPTS["rank_map"], "-j", OPTS["human_kmers"], "-u", OPTS["adaptor_kmers"]],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "new human k-mers:" in r.stdout
+    from lmat_amd import Ingest
+    back = Ingest(image=img)
+    conv = _conv()
+    for km, want in _golden("ref_lookup_opts.txt")[::11]:
+        assert [conv[t] for t in back.lookup(km)] == want
+    back.close()

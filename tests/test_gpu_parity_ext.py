@@ -230,3 +230,67 @@ def test_full_size_sample_parity(tmp_path):
     orc.close()
     reads.free()
     eng.close()
+
+
+# ---- DB ingest tooling ------------------------------------------------------------------
+_OPTS = dict(tid_cutoff=2, rank_map=os.path.join(DS, "numeric_ranks.txt"), human_kmers=os.path.join(DS, "human_kmers.txt"),
+             adaptor_kmers=os.path.join(DS, "adaptor_kmers.txt"))
+_GDS = {k: os.path.join(DS, v) for k, v in dict(tree="tax.dat", depth="depth.dat", rank="rank.txt", idmap="map32to16.txt",
+                                                db="th.bin", fasta="reads.fa", names="rank_names.txt").items()}
+
+
+def test_gpu_lookup_with_build_options_matches_reference(tmp_path):
+    """Pruned / human-fed / adaptor-fed database: the GPU hash holds what the REFERENCE's add_data stores; the
+    same holds after a save-image / load-image round trip."""
+    from lmat_amd import Engine, Params
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(_GDS["tree"], _GDS["depth"], _GDS["rank"], _GDS["idmap"])
+    img = str(tmp_path / "db.img")
+    eng.build_db(_GDS["db"], k=20, save_image=img, **_OPTS)
+    kms, want = [], []
+    for line in open(os.path.join(G, "ref_lookup_opts.txt")):
+        f = line.split()
+        kms.append(int(f[0]))
+        want.append([int(x) for x in f[2:]])
+    kms = np.array(kms, dtype=np.uint64)
+    for phase in ("built", "image"):
+        counts, tids = eng.lookup(kms, stride=32)
+        for i, w in enumerate(want):
+            assert counts[i] == len(w), (phase, int(kms[i]))
+            assert tids[i, :len(w)].tolist() == w
+        if phase == "built":
+            eng.load_image(img)
+    eng.close()
+
+
+def test_classify_parity_on_pruned_database():
+    import oracle_py
+    from lmat_amd import Engine, Params
+    reads = [l.rstrip("\n") for l in open(_GDS["fasta"]) if not l.startswith(">")]
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(_GDS["tree"], _GDS["depth"], _GDS["rank"], _GDS["idmap"])
+    eng.build_db(_GDS["db"], k=20, **_OPTS)
+    orc = oracle_py.Oracle(_GDS["tree"], _GDS["depth"], _GDS["rank"], _GDS["idmap"])
+    orc.set_build_options(_OPTS["tid_cutoff"], _OPTS["rank_map"], _OPTS["human_kmers"], _OPTS["adaptor_kmers"])
+    orc.add_taxhisto(_GDS["db"])
+    orc.set_options()
+    _compare(eng, orc, reads)
+    orc.close()
+    eng.close()
+
+
+def test_cli_reads_make_db_image_output(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img = str(tmp_path / "t.img")
+    subprocess.check_call([os.path.join(root, "lmat_amd", "csrc", "make_db_image"), "-i", _GDS["db"], "-o", img, "-k", "20",
+                           "-f", _GDS["idmap"]], stdout=subprocess.DEVNULL)
+    outs = []
+    for tag, db in (("a", _GDS["db"]), ("b", img)):
+        out = str(tmp_path / tag)
+        r = subprocess.run([os.path.join(root, "lmat_amd", "csrc", "read_label"), "-f", _GDS["idmap"], "-u", _GDS["names"], "-w",
+                            _GDS["rank"], "-x", "0", "-j", "30", "-l", "0", "-b", "1.0", "-e", _GDS["depth"], "-p", "-t", "1", "-i",
+                            _GDS["fasta"], "-d", db, "-c", _GDS["tree"], "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out + "0.out").read() + open(out + ".0.30.fastsummary").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 10000
