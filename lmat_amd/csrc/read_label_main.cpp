@@ -53,6 +53,7 @@ static bool is_list_file(const std::string& fn) {
     unsigned char b[20];
     size_t n = fread(b, 1, 20, f);
     fclose(f);
+    if (n >= 8 && memcmp(b, "LMATIMG1", 8) == 0) return false;  // database image
     if (n < 20) return true;
     for (int i = 12; i < 20; ++i)
         if (b[i] != 0xff) return true;
