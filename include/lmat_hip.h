@@ -122,6 +122,14 @@ int lmat_db_lookup(lmat_ctx* ctx, const uint64_t* kmers, uint64_t n, uint32_t* c
 int lmat_synth_taxonomy(lmat_ctx* ctx, const uint32_t* branching6);
 int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes);
 
+/* ---- null models (-n) -----------------------------------------------------------
+ * Replaces loadRandHits (read_label.cpp:512-678) and switches scoring to log(label_prob / null_prob)
+ * (construct_labels :735-819, log_odds_score :680-690).  list_fn holds `<kmer_count> <gz file relative to
+ * $LMAT_DIR>` lines.  A taxid met during classification without a null-model entry is an error
+ * (LMAT_E_TAXONOMY), as upstream's assert is. */
+int lmat_nullmodel_load(lmat_ctx* ctx, const char* list_fn);
+int lmat_nullmodel_clear(lmat_ctx* ctx);
+
 /* ---- reads ----------------------------------------------------------------
  * A batch of reads packed on the device (2-bit bases + validity bits).
  * Replaces the (read,hdr) queue hand-off of main() (read_label.cpp:1716-1746):

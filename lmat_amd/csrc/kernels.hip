@@ -318,8 +318,9 @@ struct WL {
     static constexpr int LIN = T + 72; // lineage scratch entries (in-kernel K4 only)
     static constexpr int RD_WORDS = (U + 96) / 16 + (U + 96) / 32 + 4;
     static constexpr int R1_HASH = 8 * H;                              // u64 hv[H]
-    // reg, stamp, cnt, leaf (u16) | hent, best (u32) | in-kernel K4: dep, ord, tin, tout (u16), score (f32), sflags (u8)
-    static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T : 0);
+    // reg, stamp, cnt, leaf (u16) | hent, best (u32) | in-kernel K4: dep, ord, tin, tout (u16), score (f32), sflags (u8),
+    // score0, nm_rp (f32), nm_cl (u8)
+    static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T + 4 * T + 4 * T + T : 0);
     static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
     static constexpr int R2_K = 8 * U + 4 * U;                         // ukmer, ubucket
     static constexpr int R2_D = 4 * U + 2 * U + 2 * U + 2 * U + U;     // dpay, dmult, dn, dstart, dfl
@@ -411,6 +412,59 @@ struct CmpDepthDev {  // CmpDepth, read_label.cpp:159-167
     __device__ bool operator()(const LinEnt& a, const LinEnt& b) const { return (int)a.dep > (int)b.dep; }
 };
 
+// glibc's logf (sysdeps/ieee754/flt-32/e_logf.c, the ARM optimized-routines algorithm): 16-entry table on the
+// top mantissa bits, degree-3 polynomial in double, one final rounding.  read_label scores with
+// std::log(float) when null models are on (read_label.cpp:680-690), so the device has to produce glibc's bits;
+// checked against the host libm on 3e8 inputs (tests/test_host_logic.py) and through the GPU parity tests.
+__device__ __constant__ double kLogfInvC[16] = {
+    0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0,
+    0x1.25e227b0b8eap+0, 0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0,
+    0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1, 0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1,
+    0x1.767dcf5534862p-1};
+__device__ __constant__ double kLogfLogC[16] = {
+    -0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3, -0x1.6574f0ac07758p-3,
+    -0x1.1aa2bc79c81p-3, -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4, -0x1.252f438e10c1ep-5, 0x0p+0,
+    0x1.aa5aa5df25984p-5, 0x1.c5e53aa362eb4p-4, 0x1.526e57720db08p-3, 0x1.bc2860d22477p-3, 0x1.1058bc8a07ee1p-2,
+    0x1.4043057b6ee09p-2};
+__device__ __forceinline__ float glibc_logf(float x) {
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2 == 0) return -__builtin_inff();
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return __builtin_nanf("");
+        ix = __float_as_uint(x * 0x1p23f);  // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (tmp >> (23 - 4)) % 16;
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double invc = kLogfInvC[i], logc = kLogfLogC[i];
+    const double z = (double)__uint_as_float(iz);
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
+// which null-model table a read with `cand` distinct k-mers uses: closest / getReadLen (read_label.cpp:107-133),
+// then _rand_hits.find (:738-739); -1 = no table, scores stay plain fractions
+__device__ __forceinline__ int nm_table_of(const NullModelDev& nm, uint32_t cand) {
+    if (!nm.active) return -1;
+    const GAS int* len_vec = (const GAS int*)nm.len_vec;
+    const GAS int* len_avg = (const GAS int*)nm.len_avg;
+    const GAS int* len_table = (const GAS int*)nm.len_table;
+    int i = 0;
+    for (; i < nm.n_len - 1; ++i)
+        if ((int)cand <= len_avg[i]) break;
+    const int len = len_vec[i];
+    return len > 0 ? len_table[i] : len_table[nm.n_len];
+}
+
 // K4 state that lives in lane 0's registers between the two sequential parts
 struct K4State {
     float top_score, diff_thresh;
@@ -423,16 +477,40 @@ struct K4State {
 // K4 part 1 (lane 0): scores, running sums, PhiX screen, mean/stdev, human bias, TCmp sort, lineage
 // building loop of findReadLabelVer2.  read_label.cpp:748-764, 803-893, 295-325.
 template <int LIN>
-__device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& S, const uint16_t* cnt, float* score,
+__device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& S, const uint16_t* cnt, float* score, float* score0,
                          const uint16_t* dep, const uint8_t* sflags, const uint16_t* tin, const uint16_t* tout,
-                         const uint16_t* reg, uint16_t* ord, LinEnt* lin, int nT, uint32_t cand) {
+                         const uint16_t* reg, uint16_t* ord, LinEnt* lin, int nT, uint32_t cand, bool use_nm,
+                         const float* nm_rp, const uint8_t* nm_cl, const NullModelDev& ND) {
     bool fnd_phix = false, has_human = false;
     float log_sum = 0.0f, pos_log_sum = 0.0f, top_score = 0.0f, phix_score = 0.0f;
     unsigned sig_hits = 0, pos_sig_hits = 0;
     const float fcand = (float)cand;
+    // per class string: running null-model probability (read_label.cpp:746,776-800).  An absent class reads as 0
+    // (operator[] default-inserts) and every random_prob is > 0, so "first time: assign" == max with 0.
+    float track[64];
+    if (use_nm) {
+        const GAS uint8_t* cls_rank = (const GAS uint8_t*)ND.cls_rank;
+        const GAS uint8_t* lower_cls = (const GAS uint8_t*)ND.lower_cls;
+        for (int c = 0; c < ND.n_cls; ++c) track[c] = 0.0f;
+        for (int s = 0; s < nT; ++s) {
+            const int cl = nm_cl[s];
+            const float rp = nm_rp[s];
+            track[cl] = track[cl] < rp ? rp : track[cl];              // std::max(random_prob, track[cval])
+            for (int ti = (int)cls_rank[cl] - 1; ti >= 0; --ti) {
+                const int lc = lower_cls[ti];
+                track[cl] = track[cl] < track[lc] ? track[lc] : track[cl];
+            }
+        }
+    }
     for (int s = 0; s < nT; ++s) {
-        const float sc = (float)cnt[s] / fcand;
+        float sc = (float)cnt[s] / fcand;
+        if (use_nm) {  // log_odds_score, read_label.cpp:680-690
+            const float random_prob = track[nm_cl[s]];
+            const float denom = random_prob <= 0 ? 0.00001f : random_prob;
+            sc = glibc_logf(sc / denom);
+        }
         score[s] = sc;
+        score0[s] = sc;  // all_cand_set keeps the pre-bias score (:821)
         const uint8_t fl = sflags[s];
         if (fl & kFlagHuman) has_human = true;
         log_sum += sc;
@@ -612,6 +690,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     uint16_t* tout = tin + T;
     float* score = (float*)(tout + T);
     uint8_t* sflags = (uint8_t*)(score + T);
+    float* score0 = (float*)(sflags + T);
+    float* nm_rp = score0 + T;
+    uint8_t* nm_cl = (uint8_t*)(nm_rp + T);
     // R2: k-mers, then per-distinct-payload arrays, then the lineage scratch
     unsigned long long* ukmer = (unsigned long long*)(lds + L::OFF_R2);
     uint32_t* ubucket = (uint32_t*)(lds + L::OFF_R2 + 8 * U);
@@ -1147,19 +1228,29 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         return;
     }
     // ---- K4 staging: per-slot taxonomy facts in one round of loads
+    const int nmt = nm_table_of(A.nm, cand);
     for (uint32_t s = lane; s < nT; s += 64) {
         const uint32_t t = reg[s];
         dep[s] = g_fdepth[t];
         sflags[s] = g_flags[t];
         tin[s] = g_tin[t];
         tout[s] = g_tout[t];
+        if (nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
+            const size_t row = (size_t)nmt * tb.n_ids + t;
+            const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
+            const int nb = ((const GAS int*)A.nm.nbins)[nmt];
+            const int bin = res.bin_sel < nb ? res.bin_sel : nb - 1;
+            if (cl == 0xFF) G_OR(&g_cursor[1], (uint32_t)kErrNoNullModel);
+            nm_cl[s] = cl == 0xFF ? 0 : cl;
+            nm_rp[s] = (float)((double)((const GAS float*)A.nm.val)[row * A.nm.nb_max + bin] + 0.0001);
+        }
     }
     WSYNC();
     // ---- K4 part 1 on lane 0 (LDS only)
     K4State S;
     S.done = false; S.nlin = 0; S.highest = -1; S.highest_depth = 0; S.lidx = -1; S.lowest = -1; S.plasmid_slot = -1;
     S.top_score = 0; S.diff_thresh = 0;
-    if (lane == 0) k4_part1<L::LIN>(A.prm, res, S, cnt, score, dep, sflags, tin, tout, reg, ord, lin, (int)nT, cand);
+    if (lane == 0) k4_part1<L::LIN>(A.prm, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, (int)nT, cand, nmt >= 0, nm_rp, nm_cl, A.nm);
     const int done = __builtin_amdgcn_readfirstlane((int)S.done);
     int nlin = __builtin_amdgcn_readfirstlane(S.nlin);
     const int highest = __builtin_amdgcn_readfirstlane(S.highest);
@@ -1188,7 +1279,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                     const int s = tid_slot(hent, THM, a);
                     LinEnt en;
                     en.tid = (uint16_t)a; en.flag = 0; en.pad = 0;
-                    en.score = s >= 0 ? (float)cnt[s] / fcand : -10000.0f;
+                    en.score = s >= 0 ? score0[s] : -10000.0f;
                     en.dep = g_fdepth[a]; en.tin = g_tin[a]; en.tout = g_tout[a];
                     lin[nlin + j] = en;
                 }
@@ -1259,9 +1350,10 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
         const int nT = (int)(hdr & 0xFFFFu);
         const uint32_t cand = hdr >> 16;
         uint16_t reg[kK4T], cnt[kK4T], dep[kK4T], tin[kK4T], tout[kK4T], ord[kK4T];
-        uint8_t sflags[kK4T];
-        float score[kK4T];
+        uint8_t sflags[kK4T], nm_cl[kK4T];
+        float score[kK4T], score0[kK4T], nm_rp[kK4T];
         LinEnt lin[LIN];
+        const int nmt = nm_table_of(A.nm, cand);
         for (int s = 0; s < nT; ++s) {
             const uint32_t w = krec[2 + s];
             const uint32_t t = w & 0xFFFFu;
@@ -1271,9 +1363,19 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
             sflags[s] = g_flags[t];
             tin[s] = g_tin[t];
             tout[s] = g_tout[t];
+            if (nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
+                const size_t row = (size_t)nmt * tb.n_ids + t;
+                const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
+                const int nb = ((const GAS int*)A.nm.nbins)[nmt];
+                const int bin = res.bin_sel < nb ? res.bin_sel : nb - 1;
+                if (cl == 0xFF) G_OR(&g_cursor[1], (uint32_t)kErrNoNullModel);
+                nm_cl[s] = cl == 0xFF ? 0 : cl;
+                nm_rp[s] = (float)((double)((const GAS float*)A.nm.val)[row * A.nm.nb_max + bin] + 0.0001);
+            }
         }
         K4State S;
-        k4_part1<LIN>(A.prm, res, S, cnt, score, dep, sflags, tin, tout, reg, ord, lin, nT, cand);
+        k4_part1<LIN>(A.prm, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, nT, cand, nmt >= 0, nm_rp, nm_cl,
+                      A.nm);
         uint32_t call_idx = A.phix_call_idx, ncand = 0, coff = 0;
         if (!S.done) {
             int nlin = S.nlin;
@@ -1292,7 +1394,7 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
                     for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
                     LinEnt en;
                     en.tid = (uint16_t)a; en.flag = 0; en.pad = 0;
-                    en.score = sl >= 0 ? (float)cnt[sl] / fcand : -10000.0f;
+                    en.score = sl >= 0 ? score0[sl] : -10000.0f;
                     en.dep = g_fdepth[a]; en.tin = g_tin[a]; en.tout = g_tout[a];
                     lin[nlin++] = en;
                 }

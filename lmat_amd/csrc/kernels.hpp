@@ -21,13 +21,14 @@ struct ClassifyArgs {
     uint32_t* ovf_list;        // fast kernel: reads whose tables overflowed are appended here (count in cursor[2])
     const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
     uint32_t* k4buf;           // per-read records handed from the fast classify kernel to k4_kernel
+    NullModelDev nm;           // -n null models (active == 0: scores are plain k-mer fractions)
 };
 
 // record handed to k4_kernel: word0 = nT | cand << 16, word1 reserved, then K4T words reg | cnt << 16
 static const int kK4T = 64;
 static const int kK4RecWords = 2 + kK4T;
 
-enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8 };
+enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8, kErrNoNullModel = 16 };
 
 // launchers (all asynchronous on `stream`)
 void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t* rec_off, uint32_t* words, uint64_t n,

@@ -89,6 +89,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
                     c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    free_null_models(c);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c->ingest;
     delete c;
@@ -591,6 +592,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.ovf_list = c->d_ovf;
     a.count_ptr = nullptr;
     a.k4buf = c->d_k4buf;
+    a.nm = c->nm;
     return a;
 }
 
@@ -651,6 +653,7 @@ int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t
         if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
         if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
         if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
+        if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
         std::vector<lmat_read_result> host(count);
         HIPCHK(c, hipMemcpy(host.data(), c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
         if (cur[1] & kErrTidOverflow)
@@ -703,6 +706,24 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     if (getenv("LMAT_DEBUG")) fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags %u, reads re-run by the large kernel %u\n", cur[0], cur[1], cur[2]);
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
     if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
+    if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
+    return LMAT_OK;
+}
+
+int lmat_nullmodel_load(lmat_ctx* c, const char* list_fn) {
+    if (!c || !list_fn) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    int rc = load_null_models(c, list_fn);
+    if (rc == LMAT_OK && c->nm.n_cls > 64) {
+        free_null_models(c);
+        return set_err(c, LMAT_E_CAPACITY, "more than 64 distinct null-model class strings");
+    }
+    return rc;
+}
+int lmat_nullmodel_clear(lmat_ctx* c) {
+    if (!c) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    free_null_models(c);
     return LMAT_OK;
 }
 

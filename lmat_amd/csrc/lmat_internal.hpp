@@ -50,6 +50,20 @@ struct DeviceTables {
     int k = 0;
 };
 
+// Null models on the device (loadRandHits, src/read_label.cpp:512-678).  One table per k-mer-count class
+// that has a readable file; tables are dense over the internal taxid index.
+struct NullModelDev {
+    const float* val = nullptr;       // [(table * n_ids + id) * nb_max + bin]
+    const uint8_t* cls = nullptr;     // [table * n_ids + id] class id, 0xFF = taxid has no null model
+    const int* len_vec = nullptr;     // [n_len] sorted k-mer-count classes, first entry 0 (read_len_vec)
+    const int* len_avg = nullptr;     // [n_len - 1] midpoints (read_len_avgs)
+    const int* len_table = nullptr;   // [n_len] table index of a class or -1; [n_len] = table of class 80 or -1
+    const int* nbins = nullptr;       // [n_tables]
+    const uint8_t* cls_rank = nullptr;   // [n_cls] gRank2num of the class string (0 for unknown strings)
+    const uint8_t* lower_cls = nullptr;  // [10] class id of gNum2rank[ti]
+    int n_len = 0, n_tables = 0, nb_max = 0, n_cls = 0, active = 0;
+};
+
 struct KernelParams {
     float sdiff, hbias, min_score;
     int min_kmer, min_fnd_kmer, prn_all, screen_phix;
@@ -97,6 +111,8 @@ struct lmat_ctx {
     uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags, [2] overflow-list length
     uint32_t* d_ovf = nullptr;     // reads to re-run with the large-capacity kernel
     uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to k4_kernel
+    lmat::NullModelDev nm;         // device pointers owned by the context
+    std::vector<void*> nm_allocs;
     uint64_t ovf_cap = 0;
     void* d_counts = nullptr;      // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint64_t counts_bytes = 0;
@@ -114,6 +130,8 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
                         const char* idmap_fn, const char* plasmid_fn);
 int upload_taxonomy(lmat_ctx* c);
 void build_euler_intervals(HostTaxonomy& T);
+int load_null_models(lmat_ctx* c, const char* list_fn);
+void free_null_models(lmat_ctx* c);
 // compute the arena record of one raw list; returns false (err set) on invalid ids
 bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec);
 }  // namespace lmat

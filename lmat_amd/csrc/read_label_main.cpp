@@ -10,8 +10,8 @@
 // Differences that are forced by the environment, all loud:
 //   * -d takes an image written by make_db_image, a tax_histo binary (make_db_table's input) or a text
 //     file listing several; PERM heap images cannot be opened without perm-je.
-//   * -n (null models), -s (permissive), -g/-m (run-time pruning) are not implemented yet: the
-//     program refuses them instead of ignoring them.
+//   * -s (permissive), -g/-m (run-time pruning) are not implemented yet: the program refuses them
+//     instead of ignoring them.  -n (null models) is supported.
 //   * -t N is the number of output shards (<o>0.out .. <o>N-1.out) and of formatter threads; reads
 //     are dealt to shards in contiguous blocks (the reference deals them dynamically, so only the
 //     multiset of lines across shards is defined there; -t 1 gives the reference's -t 1 file).
@@ -74,7 +74,7 @@ int main(int argc, char* argv[]) {
     float min_score = 0.0f;
     int min_kmer = 35, min_fnd_kmer = 1;
     lmat_params prm = {1.0f, 3.0f, 0.0f, 35, 1, 0, 1};
-    std::string rank_map_file, rank_ids, kmer_db_fn, query_fn, ofbase, tax_tree_fn, depth_file, id_bit_conv_fn, plasmid_file;
+    std::string rank_map_file, rank_ids, kmer_db_fn, query_fn, ofbase, tax_tree_fn, depth_file, id_bit_conv_fn, plasmid_file, rand_hits_file;
     bool fastq = false, prn_read = true;
     std::string unsupported;
     while ((c = getopt(argc, argv, "u:ahn:j:b:ye:w:pk:c:v:k:i:d:l:t:r:sm:o:x:f:g:z:qVH")) != -1) {
@@ -89,7 +89,7 @@ int main(int argc, char* argv[]) {
             case 'a': prn_read = false; break;
             case 'w': rank_map_file = optarg; break;
             case 's': unsupported += " -s"; break;
-            case 'n': unsupported += " -n"; break;
+            case 'n': rand_hits_file = optarg; break;
             case 'b': prm.sdiff = atof(optarg); break;
             case 'l': prm.hbias = atof(optarg); break;
             case 'y': break;  // verbose dumps are not produced
@@ -121,7 +121,7 @@ int main(int argc, char* argv[]) {
         return -1;
     }
     if (!unsupported.empty()) {
-        std::cerr << "ERROR! option(s)" << unsupported << " (null models / permissive match / run-time pruning) are not "
+        std::cerr << "ERROR! option(s)" << unsupported << " (permissive match / run-time pruning) are not "
                   << "implemented by the MI355X engine yet; refusing to run without them" << std::endl;
         return -2;
     }
@@ -153,6 +153,7 @@ int main(int argc, char* argv[]) {
                                  id_bit_conv_fn.c_str(), plasmid_file.empty() ? nullptr : plasmid_file.c_str()) != LMAT_OK)
         return fail("taxonomy");
     std::cout << "OK!" << std::endl;
+    if (!rand_hits_file.empty() && lmat_nullmodel_load(ctx, rand_hits_file.c_str()) != LMAT_OK) return fail("null models");
 
     std::cout << "Start kmer DB load..." << std::endl;
     std::vector<std::string> files;

@@ -326,6 +326,42 @@ def write_fastq(path, reads):
             f.write(f"@{h}\n{s}\n+\n{'I' * len(s)}\n")
 
 
+NULL_CLASS = {"no_rank": "depth=0", "superkingdom": "kingdom", "phylum": "phylum", "family": "family", "genus": "genus",
+              "species": "species", "strain": "no_rank"}
+
+
+def write_null_models(outdir: str, tax: Taxonomy, kmer_counts=(31, 56, 81, 131, 181, 281), num_bins=11, seed=4004) -> str:
+    """Null-model list + gz tables in the grammar loadRandHits parses (src/read_label.cpp:553-671):
+    list lines `<kmer_count> <file relative to $LMAT_DIR>`; each gz file: first line num_bins, then per taxid
+    `taxid <class>-<anything> (num_obs max_val kmer_cnt) x num_bins`.  Exercises: zero observations with a large
+    genome (-> 0.5), zero observations filled from neighbouring bins, class strings starting with no_ (-> genus),
+    and one class the rank table does not know."""
+    import gzip
+    rng = np.random.default_rng(seed)
+    os.makedirs(outdir, exist_ok=True)
+    lst = os.path.join(outdir, "null_lst.txt")
+    with open(lst, "w") as lf:
+        for kc in kmer_counts:
+            name = f"null.{kc}.rand_lst.gz"
+            lf.write(f"{kc} {name}\n")
+            with gzip.open(os.path.join(outdir, name), "wt") as g:
+                g.write(f"{num_bins}\n")
+                for i, tid in enumerate(tax.ids):
+                    cls = NULL_CLASS.get(tax.rank[tid], "genus")
+                    if i % 37 == 5:
+                        cls = "tribe"  # not in gRank2num: rank 0
+                    parts = [str(tid), f"{cls}-x{i}"]
+                    big = i % 11 == 3
+                    for b in range(num_bins):
+                        u = rng.random()
+                        if u < 0.15:
+                            parts += ["0", "0", str(250000 if big else 4000)]
+                        else:
+                            parts += [str(int(rng.integers(1, 500))), f"{rng.random() * 0.3 * (1 + 0.1 * tax.depth[tid]):.6g}", "50000"]
+                    g.write(" ".join(parts) + "\n")
+    return lst
+
+
 def generate_dataset(outdir: str, branching=(2, 2, 2, 2, 3, 3), G=600, n_reads=400, L=150, k=20,
                      specials=True, seeds=(1001, 2002, 3003), **read_kw) -> dict:
     tax = make_taxonomy(branching, specials)

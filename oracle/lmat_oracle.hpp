@@ -43,6 +43,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
+#include <zlib.h>
 
 namespace orc {
 
@@ -379,6 +380,109 @@ struct KmerDb {
 };
 
 // ---------------------------------------------------------------------------
+// Null models: loadRandHits (src/read_label.cpp:512-678), closest / getReadLen (:107-133)
+// ---------------------------------------------------------------------------
+struct NullModel {
+    std::unordered_map<uint16_t, std::unordered_map<tid_t, std::vector<float>>> rand_hits;  // ScoreOptions::_rand_hits
+    std::unordered_map<uint16_t, std::unordered_map<tid_t, std::string>> rand_class;        // ScoreOptions::_rand_class
+    std::vector<int> read_len_vec = std::vector<int>(1, 0), read_len_avgs = std::vector<int>(1, 0);
+    std::unordered_map<std::string, int> rank2num;  // gRank2num
+    std::unordered_map<int, std::string> num2rank;  // gNum2rank
+    bool loaded = false;
+
+    static bool gz_getline(gzFile f, std::string& out) {  // igzstream::getline with a 20004-byte buffer (:577-585)
+        char buf[20004];
+        if (!gzgets(f, buf, sizeof buf)) return false;
+        out = buf;
+        while (!out.empty() && (out.back() == '\n')) out.pop_back();
+        return true;
+    }
+    bool load(const std::string& file_lst) {
+        std::ifstream ifs_lst(file_lst.c_str());
+        if (!ifs_lst) { std::cerr << "Unexpected reading error (RandHits file list): " << file_lst << std::endl; return false; }
+        unsigned cnt = 0;
+        rank2num.insert(std::make_pair("no_rank", cnt));
+        rank2num.insert(std::make_pair("ethnic", cnt++));
+        const char* names[] = {"region", "species", "genus", "family", "order", "class", "phylum", "kingdom", "depth=0"};
+        for (const char* n : names) rank2num.insert(std::make_pair(n, cnt++));
+        cnt = 0;
+        num2rank.insert(std::make_pair(cnt, "no_rank"));
+        num2rank.insert(std::make_pair(cnt++, "ethnic"));  // key 0 is taken: insert() keeps "no_rank"
+        for (const char* n : names) num2rank.insert(std::make_pair(cnt++, n));
+        int read_len;
+        std::string file;
+        while (ifs_lst >> read_len >> file) {
+            const char* path = getenv("LMAT_DIR");
+            if (path) file = std::string(path) + std::string("/") + file;
+            else std::cerr << "WARNING! Missing LMAT_DIR environment variable!" << std::endl;
+            read_len_vec.push_back(read_len);
+            std::ifstream pre(file.c_str());
+            if (!pre) { std::cerr << "Unexpected reading error (RandHits file), skipping... " << file << std::endl; continue; }
+            pre.close();
+            gzFile gz = gzopen(file.c_str(), "rb");
+            auto& rh = rand_hits[(uint16_t)read_len];
+            auto& rc = rand_class[(uint16_t)read_len];
+            std::string line;
+            gz_getline(gz, line);
+            int num_bins = 0;
+            { std::istringstream is(line); is >> num_bins; }
+            std::vector<float> save_ecoli(num_bins, 0.5);
+            while (gz_getline(gz, line)) {
+                std::istringstream istrm(line);
+                tid_t taxid;
+                float max_val = 0;
+                std::string class_str;
+                istrm >> taxid >> class_str;
+                size_t pos = class_str.find("-");
+                std::string val = class_str.substr(0, pos);
+                if (val.size() >= 3 && val[0] == 'n' && val[1] == 'o' && val[2] == '_') val = "genus";
+                std::list<unsigned> revisit;
+                std::vector<float> cutoff(num_bins, 0);
+                for (unsigned bin = 0; (signed)bin < num_bins; ++bin) {
+                    int num_obs, kmer_cnt;
+                    istrm >> num_obs >> max_val >> kmer_cnt;
+                    if (num_obs == 0 && kmer_cnt >= 100000) { max_val = 0.5; cutoff[bin] = max_val; }
+                    else if (num_obs == 0 && kmer_cnt < 100000) revisit.push_back(bin);
+                    if (num_obs > 0) { cutoff[bin] = max_val; if (taxid == 562) save_ecoli[bin] = cutoff[bin]; }
+                    if (taxid == 28384) { val = "genus"; cutoff = save_ecoli; }
+                }
+                for (auto it = revisit.begin(); it != revisit.end(); ++it) {
+                    signed j = *it - 1;
+                    unsigned i = *it + 1;
+                    while (j >= (signed)0 || i < cutoff.size()) {
+                        float a_val = 0.0, b_val = 0.0;
+                        if (j >= 0) a_val = cutoff[j];
+                        if (i < cutoff.size()) b_val = cutoff[i];
+                        if (a_val > 0 && b_val > 0) cutoff[*it] = std::max(a_val, b_val);
+                        else if (a_val > 0) cutoff[*it] = a_val;
+                        else if (b_val > 0) cutoff[*it] = b_val;
+                        if (cutoff[*it] > 0) break;
+                        --j;
+                        ++i;
+                    }
+                    if (cutoff[*it] <= 0) cutoff[*it] = 0.5;
+                }
+                rh[taxid] = cutoff;
+                rc[taxid] = val;
+            }
+            gzclose(gz);
+        }
+        std::sort(read_len_vec.begin(), read_len_vec.end());
+        read_len_avgs.resize(0);
+        for (int i = 1; i < (signed)read_len_vec.size(); i++) read_len_avgs.push_back((read_len_vec[i - 1] + read_len_vec[i]) / 2);
+        loaded = true;
+        return true;
+    }
+    int closest(int value) const {  // :107-120
+        unsigned i;
+        for (i = 0; i < read_len_avgs.size(); i++)
+            if (value <= read_len_avgs[i]) return read_len_vec[i];
+        return read_len_vec[i];
+    }
+    int get_read_len(int rl) const { int len = closest(rl); return len > 0 ? len : 80; }  // :124-133
+};
+
+// ---------------------------------------------------------------------------
 // Options (src/read_label.cpp:487-497,1336-1347)
 // ---------------------------------------------------------------------------
 struct Options {
@@ -433,7 +537,8 @@ struct Classifier {
     const Taxonomy& tax;
     const KmerDb& db;
     Options opt;
-    Classifier(const Taxonomy& t, const KmerDb& d, const Options& o) : tax(t), db(d), opt(o) {}
+    const NullModel* nm = nullptr;  // -n
+    Classifier(const Taxonomy& t, const KmerDb& d, const Options& o, const NullModel* n = nullptr) : tax(t), db(d), opt(o), nm(n) {}
 
     // src/read_label.cpp:225-262
     bool add_to_cand_lineage(const ufpair_t cand, std::list<ufpair_t>& lineage) const {
@@ -714,7 +819,7 @@ struct Classifier {
     // src/read_label.cpp:692-941, no-null-model path (useRandMod == false)
     std::pair<ufpair_t, Match> construct_labels(const std::vector<label_info_t>& label_vec,
                                                 const std::list<tid_t>& taxid_lst, const hmap_t& tax2idx,
-                                                const hmap_t& idx2taxid, std::ostream& ofs, int min_valid_kmers,
+                                                const hmap_t& idx2taxid, std::ostream& ofs, int bin_sel, int min_valid_kmers,
                                                 int min_fnd_kmers, ReadTrace* tr) const {
         const unsigned num_tax_ids = taxid_lst.size();
         unsigned cnt_fnd_kmers = 0;
@@ -736,6 +841,15 @@ struct Classifier {
         std::vector<float> rank_first(num_tax_ids, 0);
         std::unordered_map<tid_t, float> all_cand_set;
         bool has_human = false;
+        // null-model tables for this read's k-mer count class (:735-742)
+        const int cand_kmer_cnt_match = nm && nm->loaded ? nm->get_read_len(cand_kmer_cnt) : 0;
+        const bool use_rand_mod = nm && nm->loaded && nm->rand_hits.find((uint16_t)cand_kmer_cnt_match) != nm->rand_hits.end();
+        const std::unordered_map<tid_t, std::vector<float>>* rand_hits = use_rand_mod ? &nm->rand_hits.find((uint16_t)cand_kmer_cnt_match)->second : nullptr;
+        const std::unordered_map<tid_t, std::string>* equiv_class = use_rand_mod ? &nm->rand_class.find((uint16_t)cand_kmer_cnt_match)->second : nullptr;
+        std::unordered_map<std::string, float> track;
+        std::unordered_map<std::string, int> rank2num;  // gRank2num / gNum2rank are mutated by operator[]: work on copies
+        std::unordered_map<int, std::string> num2rank;
+        if (use_rand_mod) { rank2num = nm->rank2num; num2rank = nm->num2rank; }
         for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
             float found = 0;
             const tid_t taxid = idx2taxid.find(tax_idx)->second;
@@ -744,6 +858,25 @@ struct Classifier {
                 if (label_matrix[pos][tax_idx] > 0) found += 1;
             rank_first[tax_idx] = (float)found / (float)cand_kmer_cnt;
             if (tr) tr->reg_count.push_back((uint32_t)found);
+            if (use_rand_mod) {  // :765-800
+                float random_prob = 0.5;
+                auto rh = rand_hits->find(taxid);
+                if (rh != rand_hits->end()) {
+                    const float val = rh->second[bin_sel];
+                    random_prob = val + 0.0001;
+                } else {
+                    std::cerr << "ERROR, ALL TAXIDS MUST HAVE NULL MODELS: " << taxid << " " << cand_kmer_cnt_match << " " << cand_kmer_cnt << std::endl;
+                    exit(-3);  // upstream: assert(chk != equiv_class.end()) right below
+                }
+                const std::string cval = equiv_class->find(taxid)->second;
+                if (track.find(cval) == track.end()) track[cval] = random_prob;
+                else track[cval] = std::max(random_prob, track[cval]);
+                const int cval_rank = rank2num[cval];
+                for (signed ti = cval_rank - 1; ti >= 0; ti--) {
+                    const std::string cval_lower = num2rank[ti];
+                    track[cval] = std::max(track[cval], track[cval_lower]);
+                }
+            }
         }
         std::vector<ufpair_t> rank_label(num_tax_ids, std::make_pair(0, 0));
         bool fnd_phix = false;
@@ -751,7 +884,13 @@ struct Classifier {
         unsigned sig_hits = 0, pos_sig_hits = 0;
         for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
             const tid_t taxid = idx2taxid.find(tax_idx)->second;
-            const float log_odds = rank_first[tax_idx];  // useRandMod false: score = label_prob
+            float log_odds = rank_first[tax_idx];  // useRandMod false: score = label_prob (:818)
+            if (use_rand_mod) {  // log_odds_score, :680-690
+                const float random_prob = track[equiv_class->find(taxid)->second];
+                const float numer = rank_first[tax_idx];
+                const float denom = random_prob <= 0 ? 0.00001 : random_prob;
+                log_odds = std::log(numer / denom);
+            }
             rank_label[tax_idx] = std::make_pair(taxid, log_odds);
             all_cand_set.insert(rank_label[tax_idx]);
             log_sum += log_odds;
@@ -889,7 +1028,7 @@ struct Classifier {
                 tl.nomatch[kReadTooShort] += 1;
             } else if (!taxid_lst.empty()) {
                 std::pair<ufpair_t, Match> m =
-                    construct_labels(label_vec, taxid_lst, tax2idx, idx2tax, ofs, opt.min_kmer, opt.min_fnd_kmer, tr);
+                    construct_labels(label_vec, taxid_lst, tax2idx, idx2tax, ofs, res.second, opt.min_kmer, opt.min_fnd_kmer, tr);
                 if (m.second == kNoMatchT && valid_kmers < opt.min_kmer) {
                     ofs << "-1 -1 -1" << "\t-1 -1\t" << valid_kmers << " " << opt.min_kmer << " ReadTooShort" << std::endl;
                     tl.nomatch[kReadTooShort] += 1;

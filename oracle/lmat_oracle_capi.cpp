@@ -10,6 +10,7 @@ struct orc_ctx {
     Taxonomy tax;
     KmerDb db;
     Options opt;
+    NullModel nm;
     std::string err;
     std::string text;  // last classify output
 };
@@ -30,6 +31,7 @@ const char* orc_error(orc_ctx* c) { return c->err.c_str(); }
 int orc_set_build_options(orc_ctx* c, int tid_cutoff, const char* rank_map, const char* human, const char* adaptors) {
     return c->db.set_options(tid_cutoff, rank_map ? rank_map : "", human ? human : "", adaptors ? adaptors : "") ? 0 : -1;
 }
+int orc_load_null_models(orc_ctx* c, const char* list_fn) { return c->nm.load(list_fn) ? 0 : -1; }
 int orc_add_taxhisto(orc_ctx* c, const char* fn) { return c->db.add_taxhisto(fn, c->tax, &c->err) ? 0 : -1; }
 int orc_db_k(orc_ctx* c) { return c->db.k; }
 void orc_set_k(orc_ctx* c, int k) { c->db.k = k; }
@@ -104,7 +106,7 @@ int orc_extract(const char* read, int len, int k, uint64_t* kmers, int* pos, int
 // caller's arrays when non-null: counts/scores for up to cap distinct taxids.
 long orc_classify(orc_ctx* c, const char* blob, const uint64_t* off, long n, long first_index, int k_size,
                   uint32_t* t_tid, int* t_cnt, float* t_score, int t_cap, int* n_tids, int* nomatch3) {
-    Classifier cls(c->tax, c->db, c->opt);
+    Classifier cls(c->tax, c->db, c->opt, c->nm.loaded ? &c->nm : nullptr);
     Tallies tl;
     std::ostringstream ofs;
     for (long i = 0; i < n; ++i) {
@@ -150,7 +152,7 @@ long orc_classify_mt(orc_ctx* c, const char* blob, const uint64_t* off, long n, 
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t) {
         th.emplace_back([&, t]() {
-            Classifier cls(c->tax, c->db, c->opt);
+            Classifier cls(c->tax, c->db, c->opt, c->nm.loaded ? &c->nm : nullptr);
             Tallies tl;
             std::ostringstream ofs;
             for (long i = t; i < n; i += nthreads) {
@@ -174,7 +176,7 @@ long orc_classify_mt(orc_ctx* c, const char* blob, const uint64_t* off, long n, 
 long orc_summaries_from_calls(orc_ctx* c, const uint32_t* tids, const float* scores, const int* nomatch, long n,
                               int extra_short, int extra_nodb, char* fastsummary, long fs_cap, char* nomatchsum,
                               long nm_cap) {
-    Classifier cls(c->tax, c->db, c->opt);
+    Classifier cls(c->tax, c->db, c->opt, c->nm.loaded ? &c->nm : nullptr);
     Tallies tl;
     if (extra_short) tl.nomatch[kReadTooShort] = extra_short;
     if (extra_nodb) tl.nomatch[kNoDbHits] = extra_nodb;
@@ -193,7 +195,7 @@ long orc_run_file(orc_ctx* c, const char* query, int k_size, const char* rank_id
                   char* nomatchsum, long nm_cap) {
     std::ifstream in(query);
     if (!in) { c->err = "cannot open query"; return -1; }
-    Classifier cls(c->tax, c->db, c->opt);
+    Classifier cls(c->tax, c->db, c->opt, c->nm.loaded ? &c->nm : nullptr);
     RunOutputs ro = run_reads(cls, in, k_size, rank_ids ? rank_ids : "");
     c->text = ro.out;
     if (fastsummary) snprintf(fastsummary, fs_cap, "%s", ro.fastsummary.c_str());

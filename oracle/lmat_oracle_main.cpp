@@ -26,7 +26,7 @@ static bool is_list_file(const std::string& fn) {
 int main(int argc, char* argv[]) {
     Options opt;
     std::string rank_ids, kmer_db_fn, query_fn, ofbase, tax_tree_fn, depth_file, rank_map_file, id_map_fn, plasmid_fn,
-        trace_fn;
+        trace_fn, null_fn;
     int n_threads = 0, k_size = -1;
     int c;
     while ((c = getopt(argc, argv, "u:ahn:j:b:ye:w:pk:c:v:i:d:l:t:r:sm:o:x:f:g:z:qVHT:")) != -1) {
@@ -52,8 +52,9 @@ int main(int argc, char* argv[]) {
             case 'd': kmer_db_fn = optarg; break;
             case 'o': ofbase = optarg; break;
             case 'T': trace_fn = optarg; break;  // oracle-only: per-read intermediate dump
-            case 'n': case 's': case 'm': case 'g':
-                std::cerr << "oracle: option -" << (char)c << " (null model / permissive / pruning) is not restated\n";
+            case 'n': null_fn = optarg; break;
+            case 's': case 'm': case 'g':
+                std::cerr << "oracle: option -" << (char)c << " (permissive / run-time pruning) is not restated\n";
                 return -2;
             default: break;
         }
@@ -91,7 +92,9 @@ int main(int argc, char* argv[]) {
         if (!qf) { std::cerr << "ERROR! Did not open for reading: " << query_fn << std::endl; return -1; }
         in = &qf;
     }
-    Classifier cls(tax, db, opt);
+    NullModel nm;
+    if (!null_fn.empty() && !nm.load(null_fn)) return -1;
+    Classifier cls(tax, db, opt, nm.loaded ? &nm : nullptr);
     auto t0 = std::chrono::steady_clock::now();
     RunOutputs ro;
     if (trace_fn.empty()) {

@@ -30,6 +30,7 @@ def _load():
     L.orc_error.restype = cp
     L.orc_error.argtypes = [vp]
     L.orc_add_taxhisto.argtypes = [vp, cp]
+    L.orc_load_null_models.argtypes = [vp, cp]
     L.orc_set_build_options.argtypes = [vp, i32, cp, cp, cp]
     L.orc_db_k.argtypes = [vp]
     L.orc_set_k.argtypes = [vp, i32]
@@ -71,6 +72,10 @@ class Oracle:
         e = lambda s: s.encode() if s else b""
         if self.L.orc_set_build_options(self.h, tid_cutoff, e(rank_map), e(human), e(adaptors)) != 0:
             raise RuntimeError("oracle: cannot read build-option files")
+
+    def load_null_models(self, list_fn):
+        if self.L.orc_load_null_models(self.h, list_fn.encode()) != 0:
+            raise RuntimeError("oracle: cannot read null-model list")
 
     def add_taxhisto(self, fn):
         if self.L.orc_add_taxhisto(self.h, fn.encode()) != 0:

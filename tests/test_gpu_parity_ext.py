@@ -294,3 +294,71 @@ def test_cli_reads_make_db_image_output(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(open(out + "0.out").read() + open(out + ".0.30.fastsummary").read())
     assert outs[0] == outs[1] and len(outs[0]) > 10000
+
+
+# ---- null-model scoring (-n) ----------------------------------------
+@pytest.fixture(scope="module")
+def nullmodel_ds(tmp_path_factory):
+    from lmat_amd import synth
+    d = tmp_path_factory.mktemp("nm")
+    info = synth.generate_dataset(str(d), (2, 2, 2, 2, 3, 3), 2000, 3000, L=(50, 75, 100, 150, 200, 300), frac_short=0.01)
+    tax = synth.make_taxonomy((2, 2, 2, 2, 3, 3), True)
+    info["null_lst"] = synth.write_null_models(os.path.join(str(d), "nm"), tax)
+    info["lmat_dir"] = os.path.join(str(d), "nm")
+    info["reads"] = [l.rstrip("\n") for l in open(info["fasta"]) if not l.startswith(">")]
+    return info
+
+
+@pytest.mark.parametrize("hbias", [0.0, 3.0])
+def test_null_model_text_parity(nullmodel_ds, hbias):
+    """log-odds scores against GC-binned null models: GPU (device logf) vs oracle (host libm logf), byte for byte."""
+    import oracle_py
+    from lmat_amd import Engine, Params
+    ds = nullmodel_ds
+    os.environ["LMAT_DIR"] = ds["lmat_dir"]
+    p = Params.run_rl()
+    p.hbias = hbias
+    eng = Engine(0, p)
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    eng.build_db(ds["db"], k=20)
+    eng.load_null_models(ds["null_lst"])
+    orc = oracle_py.Oracle(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    orc.add_taxhisto(ds["db"])
+    orc.set_options(hbias=hbias)
+    orc.load_null_models(ds["null_lst"])
+    eng.counts_reset()
+    res, tally, nm = _compare(eng, orc, ds["reads"])
+    counts, nomatch = eng.counts()
+    assert nomatch == nm and {t: c for t, (c, s) in counts.items()} == {t: c for t, (c, s) in tally.items()}
+    called = res[res["status"] == 0]
+    assert (called["call_score"] < 0).sum() > 20 and (called["call_score"] > 1).sum() > 20  # genuinely log-odds
+    assert nm[2] > 0  # LowScore exists now
+    # without the tables the same engine goes back to plain fractions
+    eng.clear_null_models()
+    res2, _ = eng.classify(eng.upload_reads(ds["reads"][:200]))
+    assert (res2["call_score"][res2["status"] == 0] <= 1.0).all()
+    orc.close()
+    eng.close()
+
+
+def test_cli_with_null_models(nullmodel_ds, tmp_path):
+    import subprocess
+    import oracle_py
+    ds = nullmodel_ds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "o")
+    env = dict(os.environ, LMAT_DIR=ds["lmat_dir"])
+    r = subprocess.run([os.path.join(root, "lmat_amd", "csrc", "read_label"), "-f", ds["idmap"], "-u", ds["names"], "-w", ds["rank"],
+                        "-x", "0", "-j", "30", "-l", "0", "-b", "1.0", "-n", ds["null_lst"], "-e", ds["depth"], "-p", "-t", "1", "-i",
+                        ds["fasta"], "-d", ds["db"], "-c", ds["tree"], "-o", out], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    os.environ["LMAT_DIR"] = ds["lmat_dir"]
+    orc = oracle_py.Oracle(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    orc.add_taxhisto(ds["db"])
+    orc.set_options()
+    orc.load_null_models(ds["null_lst"])
+    want, fs, nm = orc.run_file(ds["fasta"], 20, ds["names"])
+    orc.close()
+    assert open(out + "0.out").read() == want
+    assert open(out + ".0.30.nomatchsum").read() == nm
+    assert open(out + ".0.30.fastsummary").read() == fs

@@ -136,3 +136,36 @@ def test_committed_dataset_matches_generator(tmp_path):
     a = synth.generate_dataset(str(tmp_path / "a"), (2, 2, 2, 2, 3, 3), 300, 300, frac_short=0.03, lower_frac=0.05)
     for f in ("th.bin", "reads.fa", "tax.dat", "map32to16.txt", "depth.dat", "rank.txt"):
         assert open(os.path.join(g, f), "rb").read() == open(os.path.join(str(tmp_path / "a"), f), "rb").read(), f
+
+
+def test_device_logf_algorithm_matches_host_libm(tmp_path):
+    """The null-model score is std::log(float) (read_label.cpp:680-690).  The device evaluates glibc's logf
+    algorithm in double arithmetic; the same C code compiled for the host must give libm's bits on a dense
+    sweep of the positive floats (the GPU parity tests then check the device build of it)."""
+    src = tmp_path / "l.cpp"
+    kern = open(os.path.join(ROOT, "lmat_amd", "csrc", "kernels.hip")).read()
+    i0 = kern.index("__device__ __constant__ double kLogfInvC[16]")
+    i1 = kern.index("// which null-model table a read")
+    body = kern[i0:i1].replace("__device__ __constant__ ", "static const ").replace("__device__ __forceinline__ ", "static inline ")
+    body = body.replace("__float_as_uint(", "f2u(").replace("__uint_as_float(", "u2f(")
+    src.write_text(r'''
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+''' + body + r'''
+int main() {
+    unsigned long long bad = 0, n = 0;
+    for (uint32_t u = 1; u < 0x7f800000u; u += 13) { float x = u2f(u); float a = logf(x), b = glibc_logf(x); ++n; if (f2u(a) != f2u(b)) ++bad; }
+    for (int c = 1; c <= 300; ++c) for (int t = 1; t <= c; ++t) for (int d = 1; d < 400; d += 7) {
+        float x = ((float)t / (float)c) / (0.0001f * d); float a = logf(x), b = glibc_logf(x); ++n; if (f2u(a) != f2u(b)) ++bad; }
+    printf("%llu %llu\n", n, bad);
+    return bad != 0;
+}''')
+    exe = tmp_path / "l"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", str(src), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert int(r.stdout.split()[0]) > 1e8
