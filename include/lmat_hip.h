@@ -122,6 +122,13 @@ int lmat_db_lookup(lmat_ctx* ctx, const uint64_t* kmers, uint64_t n, uint32_t* c
 int lmat_synth_taxonomy(lmat_ctx* ctx, const uint32_t* branching6);
 int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes);
 
+/* ---- label modes -------------------------------------------------------------------
+ * -s permissive match (gPERMISSIVE_MATCH, read_label.cpp:1050-1058,1075-1102,1143) and run-time pruning of
+ * lists longer than tid_cutoff (-g N [-m numeric ranks]; TaxNodeStat::begin, TaxNodeStat.hpp:76-203).  Both are
+ * functions of a k-mer's taxid list alone, so they are applied when the list records are built: call before
+ * lmat_db_finalize.  rank_map_fn may be NULL (then only the first stored taxid survives, as upstream). */
+int lmat_set_label_modes(lmat_ctx* ctx, int permissive, int tid_cutoff, const char* rank_map_fn);
+
 /* ---- null models (-n) -----------------------------------------------------------
  * Replaces loadRandHits (read_label.cpp:512-678) and switches scoring to log(label_prob / null_prob)
  * (construct_labels :735-819, log_odds_score :680-690).  list_fn holds `<kmer_count> <gz file relative to

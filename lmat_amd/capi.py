@@ -70,6 +70,7 @@ def load_library(path: str | None = None):
         "lmat_ingest_kmer_length": (i32, [vp]),
         "lmat_ingest_lookup": (i32, [vp, u64, vp, i32]),
         "lmat_db_from_ingest": (i32, [vp, vp, u64]),
+        "lmat_set_label_modes": (i32, [vp, i32, i32, cp]),
         "lmat_nullmodel_load": (i32, [vp, cp]),
         "lmat_nullmodel_clear": (i32, [vp]),
         "lmat_db_kmer_length": (i32, [vp]),
@@ -110,7 +111,7 @@ EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_
             "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create",
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
             "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
-            "lmat_ingest_lookup", "lmat_db_from_ingest", "lmat_nullmodel_load", "lmat_nullmodel_clear",
+            "lmat_ingest_lookup", "lmat_db_from_ingest", "lmat_nullmodel_load", "lmat_nullmodel_clear", "lmat_set_label_modes",
             "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_reads_upload",
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
@@ -238,6 +239,10 @@ class Engine:
     def load_image(self, path, table_bytes=0):
         self._chk(self.lib.lmat_db_load_image(self.ctx, path.encode(), table_bytes))
         self._chk(self.lib.lmat_db_finalize(self.ctx))
+
+    def set_label_modes(self, permissive=False, tid_cutoff=0, rank_map=None):
+        """-s / -g N -m ranks; call before build_db / load_image."""
+        self._chk(self.lib.lmat_set_label_modes(self.ctx, int(permissive), tid_cutoff, rank_map.encode() if rank_map else None))
 
     def load_null_models(self, list_fn):
         """-n: null-model list file (gz tables resolved against $LMAT_DIR like the reference)."""

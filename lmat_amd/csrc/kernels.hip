@@ -1107,7 +1107,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     WSYNC();
     if (A.prm.stop_after == 5) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nT; store_result(out, res); } return; }
     // representative strain per species (read_label.cpp:1144-1177): max leaf count, ties -> smallest taxid
-    for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
+    // (-s: the whole post pass :1143-1204 is skipped; the list records already hold the lineages)
+    for (uint32_t e0 = 0; e0 < nel && !A.prm.permissive; e0 += 64) {
         const uint32_t e = e0 + lane;
         if (e < nel && (el_fl[e] & kFlagStrain) && el_sp[e]) {
             const uint32_t u = el_ta[e];
@@ -1122,6 +1123,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     //      Everything but the path elements is already in LDS; the next chain is prefetched.
     {
         auto eligible = [&](uint32_t e) -> bool {
+            if (A.prm.permissive) return false;              // gPERMISSIVE_MATCH: no closure pass
             if (dfl[el_d[e]] & kListNegFirst) return false;  // closure only where first >= 0 (:1179)
             if (!(el_fl[e] & kFlagStrain)) return true;      // rank != "strain" (:1184)
             const uint32_t sp = el_sp[e];

@@ -54,6 +54,7 @@ static KernelParams kparams(const lmat_params& p) {
     KernelParams k;
     k.sdiff = p.sdiff; k.hbias = p.hbias; k.min_score = p.min_score;
     k.min_kmer = p.min_kmer; k.min_fnd_kmer = p.min_fnd_kmer; k.prn_all = p.prn_all; k.screen_phix = p.screen_phix;
+    k.permissive = 0;
     const char* sa = getenv("LMAT_STOP_AFTER");
     k.stop_after = sa ? atoi(sa) : 0;
     return k;
@@ -237,7 +238,8 @@ static int build_device_db(lmat_ctx* c, Ingest& B, uint64_t table_bytes) {
         const uint32_t p = B.payload[i];
         if (p >= kListBase || single_pay[p]) continue;
         const uint32_t t32 = T.conv[p];
-        const bool special = t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
+        // (-s: even a lone taxid brings its lineage into the position set, so it needs a record too)
+        const bool special = c->permissive || t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
         auto it = T.index_of.find(t32);
         if (!special && it != T.index_of.end()) {
             single_pay[p] = it->second;
@@ -576,6 +578,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     ClassifyArgs a;
     a.tb = c->dev;
     a.prm = kparams(c->params);
+    a.prm.permissive = c->permissive;
     a.words = reads->words;
     a.rec_off = reads->rec_off;
     a.index = nullptr;
@@ -707,6 +710,22 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
     if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
     if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
+    return LMAT_OK;
+}
+
+int lmat_set_label_modes(lmat_ctx* c, int permissive, int tid_cutoff, const char* rank_map_fn) {
+    if (!c) return LMAT_E_ARG;
+    if (c->db_ready) return set_err(c, LMAT_E_ARG, "label modes shape the database records: set them before lmat_db_finalize");
+    c->permissive = permissive ? 1 : 0;
+    c->rt_tid_cut = tid_cutoff > 0 ? tid_cutoff : 0;
+    c->rt_rank_map.clear();
+    if (tid_cutoff > 0 && rank_map_fn && *rank_map_fn) {  // read_label.cpp:1543-1557
+        FILE* f = fopen(rank_map_fn, "r");
+        if (!f) return set_err(c, LMAT_E_IO, std::string("cannot read rank map ") + rank_map_fn);
+        int s, d;
+        while (fscanf(f, "%d%d", &s, &d) > 0) c->rt_rank_map[(uint32_t)s] = (uint32_t)d;
+        fclose(f);
+    }
     return LMAT_OK;
 }
 

@@ -67,6 +67,7 @@ struct NullModelDev {
 struct KernelParams {
     float sdiff, hbias, min_score;
     int min_kmer, min_fnd_kmer, prn_all, screen_phix;
+    int permissive;  // -s: no representative-strain / lineage-closure pass (read_label.cpp:1143)
     int stop_after;  // debug/profiling only (env LMAT_STOP_AFTER): 0 = full path, n = return after phase n
 };
 
@@ -96,6 +97,10 @@ struct lmat_ctx {
     uint64_t n_kmers = 0;
     uint64_t arena_words = 0;  // u16 units
     bool db_ready = false;
+    // label modes that shape the list records (set before the database is finalized)
+    int rt_tid_cut = 0;                                  // -g: run-time pruning threshold (TaxNodeStat.hpp:76)
+    std::unordered_map<uint32_t, uint32_t> rt_rank_map;  // -m: taxid -> numeric rank (read_label.cpp:1547-1553)
+    int permissive = 0;                                  // -s (gPERMISSIVE_MATCH)
     // synthetic generator state
     uint32_t synth_branching[6] = {0, 0, 0, 0, 0, 0};
     uint32_t synth_n_species = 0, synth_strains_per_species = 0;

@@ -10,8 +10,8 @@
 // Differences that are forced by the environment, all loud:
 //   * -d takes an image written by make_db_image, a tax_histo binary (make_db_table's input) or a text
 //     file listing several; PERM heap images cannot be opened without perm-je.
-//   * -s (permissive), -g/-m (run-time pruning) are not implemented yet: the program refuses them
-//     instead of ignoring them.  -n (null models) is supported.
+//   * -n (null models), -s (permissive match) and -g/-m (run-time pruning) are supported; the blank line
+//     upstream prints to stdout per pruned k-mer (TaxNodeStat.hpp:192) is not reproduced.
 //   * -t N is the number of output shards (<o>0.out .. <o>N-1.out) and of formatter threads; reads
 //     are dealt to shards in contiguous blocks (the reference deals them dynamically, so only the
 //     multiset of lines across shards is defined there; -t 1 gives the reference's -t 1 file).
@@ -76,6 +76,8 @@ int main(int argc, char* argv[]) {
     lmat_params prm = {1.0f, 3.0f, 0.0f, 35, 1, 0, 1};
     std::string rank_map_file, rank_ids, kmer_db_fn, query_fn, ofbase, tax_tree_fn, depth_file, id_bit_conv_fn, plasmid_file, rand_hits_file;
     bool fastq = false, prn_read = true;
+    int permissive = 0, max_count = 0;
+    std::string rank_table_file;
     std::string unsupported;
     while ((c = getopt(argc, argv, "u:ahn:j:b:ye:w:pk:c:v:k:i:d:l:t:r:sm:o:x:f:g:z:qVH")) != -1) {
         switch (c) {
@@ -88,7 +90,7 @@ int main(int argc, char* argv[]) {
             case 'x': min_score = atof(optarg); break;
             case 'a': prn_read = false; break;
             case 'w': rank_map_file = optarg; break;
-            case 's': unsupported += " -s"; break;
+            case 's': permissive = 1; break;
             case 'n': rand_hits_file = optarg; break;
             case 'b': prm.sdiff = atof(optarg); break;
             case 'l': prm.hbias = atof(optarg); break;
@@ -96,12 +98,12 @@ int main(int argc, char* argv[]) {
             case 'e': depth_file = optarg; break;
             case 'q': fastq = true; break;
             case 'p': prm.prn_all = 1; break;
-            case 'm': unsupported += " -m"; break;
+            case 'm': rank_table_file = optarg; break;
             case 't': n_threads = atoi(optarg); break;
             case 'v': break;  // threshold: parsed and unused upstream too (proc_line's `threshold`)
             case 'c': tax_tree_fn = optarg; break;
             case 'k': k_size = atoi(optarg); break;
-            case 'g': unsupported += " -g"; break;
+            case 'g': max_count = atoi(optarg); break;
             case 'i': query_fn = optarg; break;
             case 'd': kmer_db_fn = optarg; break;
             case 'o': ofbase = optarg; break;
@@ -154,6 +156,9 @@ int main(int argc, char* argv[]) {
         return fail("taxonomy");
     std::cout << "OK!" << std::endl;
     if (!rand_hits_file.empty() && lmat_nullmodel_load(ctx, rand_hits_file.c_str()) != LMAT_OK) return fail("null models");
+    if (!rank_table_file.empty() && max_count <= 0) std::cout << "Need to set -h <tid-cutoff> to use rank file map!\n";  // :1544-1545
+    if (lmat_set_label_modes(ctx, permissive, max_count, max_count > 0 && !rank_table_file.empty() ? rank_table_file.c_str() : nullptr) != LMAT_OK)
+        return fail("label modes");
 
     std::cout << "Start kmer DB load..." << std::endl;
     std::vector<std::string> files;

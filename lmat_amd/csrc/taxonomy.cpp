@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <fstream>
+#include <queue>
 #include <sstream>
 #include "lmat_internal.hpp"
 
@@ -222,24 +223,62 @@ void build_euler_intervals(HostTaxonomy& T) {
 // (src/read_label.cpp:1028-1134): 16->32 conversion, human folding, ignored ids, int16
 // store of the raw count, std::sort by depth descending, leaf-most filter.  It is a pure
 // function of the list, so it is evaluated once per distinct list at DB build time.
+namespace {
+struct RankPair {  // MyPair, src/kmerdb/SortedDb.hpp:129-139
+    unsigned int first;
+    uint32_t second;
+    RankPair(unsigned int f, uint32_t s) : first(f), second(s) {}
+    bool operator<(const RankPair& o) const { return first < o.first; }
+};
+}  // namespace
+
 bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec) {
     const HostTaxonomy& T = c->tax;
-    std::vector<uint16_t> obs;
-    bool seen_human = false, neg_first = false;
-    unsigned dcnt = 0;
+    // what TaxNodeStat::begin / next hand to the caller (TaxNodeStat.hpp:60-256): the stored ids converted
+    // 16 -> 32, or, with run-time pruning (-g N [-m ranks]) on a list longer than N, the survivors of the
+    // rank-priority queue in pop order (or just the first stored id when no rank map was given)
+    std::vector<uint32_t> seq;
+    uint32_t count = (uint32_t)raw.size();
     for (size_t i = 0; i < raw.size(); ++i) {
-        uint32_t tid = T.conv[raw[i]];
+        const uint32_t tid = T.conv[raw[i]];
         if (tid == 0) {  // TaxNodeStat.hpp:235-238: "bad taxid" assert
             set_err(c, LMAT_E_TAXONOMY, "bad taxid: 16-bit id " + std::to_string(raw[i]) + " has no 32-bit mapping");
             return false;
         }
+        seq.push_back(tid);
+    }
+    if (c->rt_tid_cut > 0 && (int)count > c->rt_tid_cut) {
+        if (c->rt_rank_map.empty()) {
+            seq.resize(1);
+            count = 1;
+        } else {
+            std::priority_queue<RankPair> q;
+            for (uint32_t t : seq) {
+                auto r = c->rt_rank_map.find(t);
+                q.push(RankPair(r == c->rt_rank_map.end() ? 0u : r->second, t));
+            }
+            while (!q.empty()) {
+                const unsigned cur = q.top().first;
+                while (q.top().first == cur) { q.pop(); if (q.empty()) break; }
+                if ((int)q.size() <= c->rt_tid_cut) { count = (uint32_t)q.size(); break; }
+            }
+            if (q.size() == 0) { count = 1; q.push(RankPair(1, 1)); }
+            seq.clear();
+            for (uint32_t j = 0; j < count; ++j) { seq.push_back(q.top().second); q.pop(); }
+        }
+    }
+    std::vector<uint16_t> obs;
+    bool seen_human = false, neg_first = false;
+    unsigned dcnt = 0;
+    for (size_t i = 0; i < seq.size(); ++i) {  // read_label.cpp:1031-1066
+        uint32_t tid = seq[i];
         if (is_human32(tid)) {
             if (seen_human) continue;
             tid = 9606;
             seen_human = true;
         }
         if (tid == 20999999 || tid == 12721 || tid == 693660) continue;
-        if (dcnt == 0) neg_first = ((int16_t)(uint16_t)raw.size()) < 0;
+        if (dcnt == 0) neg_first = ((int16_t)(uint16_t)count) < 0;
         auto it = T.index_of.find(tid);
         if (it == T.index_of.end()) {
             set_err(c, LMAT_E_TAXONOMY, "taxid " + std::to_string(tid) + " missing from internal index");
@@ -248,19 +287,32 @@ bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vecto
         obs.push_back(it->second);
         dcnt++;
     }
-    // CmpDepth1 (read_label.cpp:169-177) through the same std::sort the reference calls
-    std::sort(obs.begin(), obs.end(), [&T](uint16_t a, uint16_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
-    std::unordered_set<uint16_t> non_leaf;
     std::vector<uint16_t> kept;
-    for (size_t i = 0; i < obs.size(); ++i) {
-        const uint16_t t = obs[i];
-        if (non_leaf.count(t)) continue;
-        if (std::find(kept.begin(), kept.end(), t) != kept.end()) {
-            set_err(c, LMAT_E_IO, "taxid list holds taxid " + std::to_string(T.tid32[t]) + " twice");
-            return false;
+    auto add_unique = [&kept](uint16_t t) { if (std::find(kept.begin(), kept.end(), t) == kept.end()) kept.push_back(t); };
+    if (c->permissive) {
+        // -s (read_label.cpp:1050-1058,1075-1102): every accepted id joins the position set in list order, then,
+        // walking the depth-sorted ids until one of depth 0, all their ancestors do; no leaf-most filter
+        for (uint16_t t : obs) add_unique(t);
+        std::vector<uint16_t> sorted(obs);
+        std::sort(sorted.begin(), sorted.end(), [&T](uint16_t a, uint16_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
+        for (uint16_t t : sorted) {
+            if (T.fdepth[t] == 0) break;
+            for (uint32_t p = 0; p < T.path_len[t]; ++p) add_unique(T.paths[T.path_off[t] + p]);
         }
-        kept.push_back(t);
-        for (uint32_t p = 0; p < T.path_len[t]; ++p) non_leaf.insert(T.paths[T.path_off[t] + p]);
+    } else {
+        // CmpDepth1 (read_label.cpp:169-177) through the same std::sort the reference calls, then the leaf-most filter
+        std::sort(obs.begin(), obs.end(), [&T](uint16_t a, uint16_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
+        std::unordered_set<uint16_t> non_leaf;
+        for (size_t i = 0; i < obs.size(); ++i) {
+            const uint16_t t = obs[i];
+            if (non_leaf.count(t)) continue;
+            if (std::find(kept.begin(), kept.end(), t) != kept.end()) {
+                set_err(c, LMAT_E_IO, "taxid list holds taxid " + std::to_string(T.tid32[t]) + " twice");
+                return false;
+            }
+            kept.push_back(t);
+            for (uint32_t p = 0; p < T.path_len[t]; ++p) non_leaf.insert(T.paths[T.path_off[t] + p]);
+        }
     }
     if (kept.size() > 65535 || raw.size() > 65535) {
         set_err(c, LMAT_E_CAPACITY, "taxid list too long");

@@ -495,6 +495,9 @@ struct Options {
     int min_fnd_kmer = 1;        // -z
     bool prn_read = true;        // -a turns off
     bool fastq = false;          // -q
+    bool permissive = false;     // -s  gPERMISSIVE_MATCH
+    uint16_t max_count = 0xFFFF; // -g  run-time pruning threshold (uint16_t max_count = ~0, :1346)
+    std::unordered_map<uint32_t, uint32_t> tid_rank_map;  // -m  (read_label.cpp:1547-1553)
 };
 
 typedef std::pair<tid_t, float> ufpair_t;
@@ -684,7 +687,47 @@ struct Classifier {
         return std::make_pair(call, match);
     }
 
-    // src/read_label.cpp:974-1209 (non-permissive, pruning off)
+    // TaxNodeStat::begin (5-argument form, TaxNodeStat.hpp:60-205) + next()/taxid()/taxidCount() (:208-264):
+    // the taxid sequence and count the caller sees for one k-mer, run-time pruning (-g/-m) included
+    void taxnodestat_sequence(const std::vector<uint16_t>* lst, kmer_t kmer_id, std::vector<tid_t>& seq,
+                              uint16_t& taxid_count) const {
+        seq.clear();
+        taxid_count = lst ? (uint16_t)lst->size() : 0;
+        if (!lst) return;
+        for (unsigned li = 0; li < lst->size(); ++li) {
+            auto cv = tax.conv.find((*lst)[li]);
+            tid_t tid = cv == tax.conv.end() ? 0 : cv->second;
+            if (tid == 0) {  // :235-238 assert(0)
+                std::cerr << "bad taxid: " << (*lst)[li] << " kmer: " << kmer_id << "\n";
+                exit(-1);
+            }
+            seq.push_back(tid);
+        }
+        const int tid_cut = opt.max_count;
+        if (tid_cut > 0 && taxid_count > tid_cut) {
+            if (opt.tid_rank_map.size() == 0) {
+                // m_filtered_list is filled but never read back: next() re-reads the first stored id
+                seq.resize(1);
+                taxid_count = 1;
+            } else {
+                std::priority_queue<KmerDb::MyPair> q;
+                for (tid_t t : seq) {
+                    auto r = opt.tid_rank_map.find(t);
+                    q.push(KmerDb::MyPair(r == opt.tid_rank_map.end() ? 0u : r->second, t));
+                }
+                while (!q.empty()) {
+                    int cur_priority = q.top().first;
+                    while ((int)q.top().first == cur_priority) { q.pop(); if (q.empty()) break; }
+                    if ((int)q.size() <= tid_cut) { taxid_count = q.size(); break; }
+                }
+                if (q.size() == 0) { taxid_count = 1; q.push(KmerDb::MyPair(1, 1)); }
+                seq.clear();
+                for (unsigned j = 0; j < taxid_count; ++j) { seq.push_back(q.top().second); q.pop(); }
+            }
+        }
+    }
+
+    // src/read_label.cpp:974-1209 (pruning and permissive mode included)
     std::pair<int, int> retrieve_kmer_labels(const char* str, const int slen, const int klen,
                                              std::vector<label_info_t>& label_vec, std::list<tid_t>& taxid_lst,
                                              hmap_t& tax2idx, hmap_t& idx2tax, ReadTrace* tr) const {
@@ -716,30 +759,58 @@ struct Classifier {
                 if (tr) { tr->uniq_kmers.push_back(kmer_id); tr->uniq_pos.push_back(pos); }
 
                 const std::vector<uint16_t>* lst = db.lookup(kmer_id);
-                const uint16_t taxid_count = lst ? (uint16_t)lst->size() : 0;
+                std::vector<tid_t> seq;
+                uint16_t taxid_count = 0;
+                taxnodestat_sequence(lst, kmer_id, seq, taxid_count);
                 unsigned dcnt = 0;
                 std::list<tid_t> obs_tids;
                 bool seen_human = false;
-                for (unsigned li = 0; li < taxid_count; ++li) {  // while(h->next())
-                    auto cv = tax.conv.find((*lst)[li]);
-                    tid_t tid = cv == tax.conv.end() ? 0 : cv->second;
-                    if (tid == 0) {  // TaxNodeStat.hpp:235-238 assert(0)
-                        std::cerr << "bad taxid: " << (*lst)[li] << " kmer: " << kmer_id << "\n";
-                        exit(-1);
-                    }
+                for (unsigned li = 0; li < seq.size(); ++li) {  // while(h->next()), read_label.cpp:1031-1066
+                    tid_t tid = seq[li];
                     if (is_human(tid) && seen_human) continue;
                     else if (is_human(tid) && !seen_human) { tid = kHumanTid; seen_human = true; }
                     if (tid == 20999999 || bad_genome(tid)) continue;
                     uint16_t ng = taxid_count;
                     if (dcnt == 0) label_vec[pos].first = (int16_t)ng;  // int16 store of a u16 (quirk Q4)
                     obs_tids.push_back(tid);
+                    if (opt.permissive) {  // :1050-1058
+                        label_vec[pos].second.insert(std::make_pair(tid, (uint16_t)1));
+                        if (tax2idx.find(tid) == tax2idx.end()) {
+                            const unsigned idx = taxid_lst.size();
+                            tax2idx[tid] = idx;
+                            idx2tax[idx] = tid;
+                            taxid_lst.push_back(tid);
+                        }
+                    }
                     dcnt++;
                 }
                 std::vector<tid_t> obs(obs_tids.begin(), obs_tids.end());
                 CmpDepth1 cd{&tax};
                 std::sort(obs.begin(), obs.end(), cd);
                 std::unordered_set<tid_t> non_leaf;
-                for (unsigned i = 0; i < obs.size(); ++i) {
+                if (opt.permissive) {  // :1075-1102 (last_depth is never updated upstream, so the walk only stops at depth 0)
+                    int last_depth = -1;
+                    for (unsigned i = 0; i < obs.size(); ++i) {
+                        const tid_t tid = obs[i];
+                        const int depth = (int)tax.depth_of(tid);
+                        if (depth == 0) break;
+                        if (last_depth == depth || last_depth == -1) {
+                            std::vector<tid_t> path;
+                            tax.path_to_root(tid, path);
+                            for (unsigned p = 0; p < path.size(); ++p) {
+                                const tid_t ptid = path[p];
+                                label_vec[pos].second.insert(std::make_pair(ptid, (uint16_t)1));
+                                if (tax2idx.find(ptid) == tax2idx.end()) {
+                                    const unsigned idx = taxid_lst.size();
+                                    tax2idx[ptid] = idx;
+                                    idx2tax[idx] = ptid;
+                                    taxid_lst.push_back(ptid);
+                                }
+                            }
+                        } else break;
+                    }
+                }
+                for (unsigned i = 0; i < obs.size() && !opt.permissive; ++i) {
                     const tid_t tid = obs[i];
                     if (non_leaf.find(tid) == non_leaf.end()) {
                         label_vec[pos].second.insert(std::make_pair(tid, (uint16_t)1));
@@ -759,7 +830,7 @@ struct Classifier {
             }
         }
         // post pass: representative strain per species, lineage closure (:1143-1204)
-        {
+        if (!opt.permissive) {
             std::map<tid_t, std::pair<tid_t, unsigned>> save_spec_rep;
             for (auto cb = leaf_track.begin(); cb != leaf_track.end(); ++cb) {
                 const tid_t stid = cb->first;

@@ -31,6 +31,19 @@ const char* orc_error(orc_ctx* c) { return c->err.c_str(); }
 int orc_set_build_options(orc_ctx* c, int tid_cutoff, const char* rank_map, const char* human, const char* adaptors) {
     return c->db.set_options(tid_cutoff, rank_map ? rank_map : "", human ? human : "", adaptors ? adaptors : "") ? 0 : -1;
 }
+int orc_set_label_modes(orc_ctx* c, int permissive, int tid_cutoff, const char* rank_map) {
+    c->opt.permissive = permissive != 0;
+    c->opt.max_count = tid_cutoff > 0 ? (uint16_t)tid_cutoff : 0xFFFF;
+    c->opt.tid_rank_map.clear();
+    if (tid_cutoff > 0 && rank_map && *rank_map) {
+        FILE* f = fopen(rank_map, "r");
+        if (!f) return -1;
+        int a, b;
+        while (fscanf(f, "%d%d", &a, &b) > 0) c->opt.tid_rank_map[(uint32_t)a] = (uint32_t)b;
+        fclose(f);
+    }
+    return 0;
+}
 int orc_load_null_models(orc_ctx* c, const char* list_fn) { return c->nm.load(list_fn) ? 0 : -1; }
 int orc_add_taxhisto(orc_ctx* c, const char* fn) { return c->db.add_taxhisto(fn, c->tax, &c->err) ? 0 : -1; }
 int orc_db_k(orc_ctx* c) { return c->db.k; }
@@ -59,6 +72,18 @@ int orc_lookup(orc_ctx* c, uint64_t kmer, uint32_t* out, int cap) {
         out[i] = cv == c->tax.conv.end() ? 0 : cv->second;
     }
     return (int)l->size();
+}
+
+// the sequence TaxNodeStat hands out under the current label modes (run-time pruning); -1 = miss
+int orc_lookup_rt(orc_ctx* c, uint64_t kmer, uint32_t* out, int cap) {
+    const std::vector<uint16_t>* l = c->db.lookup(kmer);
+    if (!l) return -1;
+    Classifier cls(c->tax, c->db, c->opt);
+    std::vector<tid_t> seq;
+    uint16_t count = 0;
+    cls.taxnodestat_sequence(l, kmer, seq, count);
+    for (int i = 0; i < (int)seq.size() && i < cap; ++i) out[i] = seq[i];
+    return (int)count;
 }
 
 int orc_path_to_root(orc_ctx* c, uint32_t tid, uint32_t* out, int cap) {

@@ -31,6 +31,7 @@ def _load():
     L.orc_error.argtypes = [vp]
     L.orc_add_taxhisto.argtypes = [vp, cp]
     L.orc_load_null_models.argtypes = [vp, cp]
+    L.orc_set_label_modes.argtypes = [vp, i32, i32, cp]
     L.orc_set_build_options.argtypes = [vp, i32, cp, cp, cp]
     L.orc_db_k.argtypes = [vp]
     L.orc_set_k.argtypes = [vp, i32]
@@ -38,6 +39,7 @@ def _load():
     L.orc_db_size.argtypes = [vp]
     L.orc_add_list32.argtypes = [vp, u64, vp, i32]
     L.orc_lookup.argtypes = [vp, u64, vp, i32]
+    L.orc_lookup_rt.argtypes = [vp, u64, vp, i32]
     L.orc_path_to_root.argtypes = [vp, C.c_uint32, vp, i32]
     L.orc_set_options.argtypes = [vp, C.c_float, C.c_float, i32, i32, C.c_float, i32, i32, i32, i32]
     L.orc_extract.argtypes = [cp, i32, i32, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)]
@@ -72,6 +74,10 @@ class Oracle:
         e = lambda s: s.encode() if s else b""
         if self.L.orc_set_build_options(self.h, tid_cutoff, e(rank_map), e(human), e(adaptors)) != 0:
             raise RuntimeError("oracle: cannot read build-option files")
+
+    def set_label_modes(self, permissive=False, tid_cutoff=0, rank_map=None):
+        if self.L.orc_set_label_modes(self.h, int(permissive), tid_cutoff, (rank_map or "").encode()) != 0:
+            raise RuntimeError("oracle: cannot read rank map")
 
     def load_null_models(self, list_fn):
         if self.L.orc_load_null_models(self.h, list_fn.encode()) != 0:
@@ -108,6 +114,11 @@ class Oracle:
     def lookup(self, kmer, cap=4096):
         out = np.zeros(cap, dtype=np.uint32)
         n = self.L.orc_lookup(self.h, int(kmer), out.ctypes.data, cap)
+        return n, out[:max(n, 0)].copy()
+
+    def lookup_rt(self, kmer, cap=4096):
+        out = np.zeros(cap, dtype=np.uint32)
+        n = self.L.orc_lookup_rt(self.h, int(kmer), out.ctypes.data, cap)
         return n, out[:max(n, 0)].copy()
 
     def path_to_root(self, tid, cap=256):

@@ -51,9 +51,17 @@ static int do_lookup(int argc, char** argv) {
     std::ifstream kin(argv[4]);
     uint64_t kmer;
     my_map tid_rank_map;
+    // run-time pruning as read_label passes it (read_label.cpp:1023,1543-1557): env REF_RT_CUT / REF_RT_RANKS
+    int rt_cut = getenv("REF_RT_CUT") ? atoi(getenv("REF_RT_CUT")) : (uint16_t)~0;
+    if (getenv("REF_RT_RANKS")) {
+        FILE* rmfp = fopen(getenv("REF_RT_RANKS"), "r");
+        uint32_t src, dest;
+        while (fscanf(rmfp, "%d%d", &src, &dest) > 0) tid_rank_map[src] = dest;
+        fclose(rmfp);
+    }
     while (kin >> kmer) {
         TaxNodeStat<uint16_t> h(*db);
-        h.begin(kmer, tid_rank_map, (uint16_t)~0, false, &conv_map);
+        h.begin(kmer, tid_rank_map, rt_cut, false, &conv_map);
         printf("%llu %u", (unsigned long long)kmer, (unsigned)h.taxidCount());
         while (h.next()) printf(" %u", h.taxid());
         printf("\n");

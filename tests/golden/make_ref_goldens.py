@@ -84,5 +84,13 @@ with open(os.path.join(here, "ref_lookup_opts.txt"), "w") as o:
                           os.path.join(ds, "adaptor_kmers.txt")], capture_output=True, text=True, check=True).stdout
     o.write("".join(l + "\n" for l in out.splitlines() if l and l[0].isdigit() and len(l.split()) >= 2 and l.split()[1].isdigit()))
 os.remove(kf)
+# ---- run-time pruning through the reference's TaxNodeStat::begin (read_label -g 2 [-m ranks])
+np.savetxt(kf, kms, fmt="%d")
+for tag, env in (("ranks", {"REF_RT_CUT": "2", "REF_RT_RANKS": os.path.join(ds, "numeric_ranks.txt")}), ("noranks", {"REF_RT_CUT": "2"})):
+    with open(os.path.join(here, f"ref_lookup_rt_{tag}.txt"), "w") as o:
+        out = subprocess.run([os.path.join(ref, "ref_lookup"), "lookup", info["db"], info["idmap"], kf, "200000"],
+                             capture_output=True, text=True, check=True, env=dict(os.environ, **env)).stdout
+        o.write("".join(l + "\n" for l in out.splitlines() if l and l[0].isdigit() and len(l.split()) >= 2 and l.split()[1].isdigit()))
+os.remove(kf)
 print("option lookups:", q.size)
 print("k-mers looked up:", kms.size, "db k-mers:", info["n_kmers"], "reads:", len(reads))

@@ -84,3 +84,22 @@ def test_make_db_image_tool(tmp_path):
     for km, want in _golden("ref_lookup_opts.txt")[::11]:
         assert [conv[t] for t in back.lookup(km)] == want
     back.close()
+
+
+@pytest.mark.parametrize("tag,ranks", [("ranks", True), ("noranks", False)])
+def test_runtime_pruning_matches_reference_taxnodestat(tag, ranks):
+    """read_label -g 2 [-m ranks]: the sequence TaxNodeStat::begin/next hands out (TaxNodeStat.hpp:60-256), taken from
+    the REFERENCE's TaxNodeStat compiled in place; without a rank map only the first stored id survives."""
+    import oracle_py
+    o = oracle_py.Oracle(os.path.join(DS, "tax.dat"), os.path.join(DS, "depth.dat"), os.path.join(DS, "rank.txt"),
+                         os.path.join(DS, "map32to16.txt"))
+    o.add_taxhisto(os.path.join(DS, "th.bin"))
+    o.set_label_modes(False, 2, os.path.join(DS, "numeric_ranks.txt") if ranks else None)
+    pruned = 0
+    plain = dict(_golden("ref_lookup.txt"))
+    for km, want in _golden(f"ref_lookup_rt_{tag}.txt"):
+        n, lst = o.lookup_rt(km)
+        assert (lst.tolist() if n > 0 else []) == want
+        pruned += want != plain[km]
+    assert pruned > 3000
+    o.close()

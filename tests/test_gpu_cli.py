@@ -50,8 +50,8 @@ def test_cli_refuses_unsupported_and_missing_args(small_dataset, tmp_path):
     r = subprocess.run([EXE, "-t", "1", "-o", str(tmp_path / "x"), "-i", ds["fasta"]], capture_output=True, text=True)
     assert r.returncode == 255 and "ERROR! Missing depth_file" in r.stderr
     r = subprocess.run([EXE, "-f", ds["idmap"], "-e", ds["depth"], "-t", "1", "-i", ds["fasta"], "-d", ds["db"], "-c", ds["tree"],
-                        "-o", str(tmp_path / "x"), "-s"], capture_output=True, text=True)
-    assert r.returncode != 0 and "-s" in r.stderr  # permissive mode: refused, not ignored
+                        "-o", str(tmp_path / "x"), "-g", "3", "-m", "no_such_rank_map.txt"], capture_output=True, text=True)
+    assert r.returncode != 0 and "rank map" in r.stderr
     r = subprocess.run([EXE, "-f", ds["idmap"], "-e", ds["depth"], "-t", "1", "-i", ds["fasta"], "-d", ds["db"], "-c", ds["tree"],
                         "-o", str(tmp_path / "x"), "-n", "no_such_list.txt"], capture_output=True, text=True)
     assert r.returncode != 0 and "RandHits file list" in r.stderr

@@ -362,3 +362,65 @@ def test_cli_with_null_models(nullmodel_ds, tmp_path):
     assert open(out + "0.out").read() == want
     assert open(out + ".0.30.nomatchsum").read() == nm
     assert open(out + ".0.30.fastsummary").read() == fs
+
+
+# ---- run-time pruning (-g/-m), permissive match (-s), 18-mers ------------------------------
+@pytest.mark.parametrize("mode", ["prune_ranks", "prune_noranks", "permissive", "permissive_prune"])
+def test_label_modes_text_parity(config1, mode):
+    import oracle_py
+    from lmat_amd import Engine, Params, synth
+    ds = config1
+    ranks = os.path.join(os.path.dirname(ds["tree"]), "numeric_ranks.txt")
+    tax = synth.make_taxonomy((2, 2, 2, 2, 3, 3), True)
+    with open(ranks, "w") as f:
+        for t in tax.ids:
+            f.write(f"{t} {tax.depth[t]}\n")
+    perm = mode.startswith("permissive")
+    cut = 0 if mode == "permissive" else 2
+    rk = ranks if mode in ("prune_ranks", "permissive_prune") else None
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    eng.set_label_modes(perm, cut, rk)
+    eng.build_db(ds["db"], k=20)
+    orc = oracle_py.Oracle(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    orc.add_taxhisto(ds["db"])
+    orc.set_options()
+    orc.set_label_modes(perm, cut, rk)
+    eng.counts_reset()
+    res, tally, nm = _compare(eng, orc, ds["reads"][:3000])
+    counts, nomatch = eng.counts()
+    assert nomatch == nm and {t: c for t, (c, s) in counts.items()} == {t: c for t, (c, s) in tally.items()}
+    # the mode really changes the output
+    base = _oracle(ds)
+    blob, off = _blob(ds["reads"][:3000])
+    t0, _, _ = base.classify(blob, off, 20)
+    t1, _, _ = orc.classify(blob, off, 20)
+    assert t0 != t1
+    base.close()
+    orc.close()
+    eng.close()
+
+
+def test_18mer_database(tmp_path):
+    from lmat_amd import synth
+    info = synth.generate_dataset(str(tmp_path), (2, 2, 2, 2, 3, 3), 1500, 1200, L=(60, 100, 150), k=18)
+    reads = [l.rstrip("\n") for l in open(info["fasta"]) if not l.startswith(">")]
+    eng = _engine_k(info, 18)
+    orc = _oracle(info)
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    res, cands = eng.classify(dr, cand_cap=256 * len(reads))
+    got = eng.format_out(res, cands, (blob, off))
+    want, _, _ = orc.classify(blob, off, 18)
+    assert got == want and eng.k == 18
+    assert (res["status"] == 0).sum() > 500
+    orc.close()
+    eng.close()
+
+
+def _engine_k(ds, k):
+    from lmat_amd import Engine, Params
+    e = Engine(0, Params.run_rl())
+    e.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    e.build_db(ds["db"], k=k)
+    return e
