@@ -668,11 +668,15 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
     lo |= nl;
 }
 
-template <int U, int T, int E, bool INK4>
+template <int U, int T, int E, bool INK4, bool PERM>
 __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane,
                                              const uint32_t* wcur, uint32_t (&nmacc)[2]) {
     using L = WL<U, T, E, INK4>;
     constexpr int THM = L::TH - 1;
+    // RELANE: values derived from the lane id (LDS addresses, masks) are cheap; re-deriving them per phase keeps the
+    // register allocator from carrying (and spilling) them across the probe phase, where 34 VGPRs hold loads in flight
+#define RELANE() asm volatile("" : "+v"(lane))
+    RELANE();
     uint32_t* rd = (uint32_t*)(lds + L::OFF_RD);
     // R1, hash phases
     unsigned long long* hv = (unsigned long long*)(lds + L::OFF_R1);
@@ -728,22 +732,30 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
     // record words were prefetched by the caller: lane l holds word l + 64*j in wcur[j] (word 0 = length)
     const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)wcur[0]);
-    lmat_read_result res;
-    res.status = LMAT_ST_NODBHITS; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = 0;
-    res.read_len = (int)len; res.log_avg = 0; res.stdev = 0; res.call_tid = 0; res.call_score = 0;
-    res.cand_off = 0; res.n_cand = 0; res.bin_sel = 0;
+    // The result record is assembled from wave-uniform scalars at each exit: a struct kept live from here on
+    // costs ten VGPRs across the probe phase (they were spilled to scratch, 4.5 KB of HBM writes per read).
+    int valid_kmers = 0, bin_sel = 0;
     GAS uint64_t* out = (GAS uint64_t*)(A.results + (r - A.result_base));
     GAS unsigned long long* tally_count = (GAS unsigned long long*)A.counts;
     GAS double* tally_score = (GAS double*)(tally_count + tb.n_ids);
     GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + tb.n_ids);
+    auto emit = [&](uint32_t status, uint32_t cand_cnt) {
+        uint32_t z = 0;
+        asm volatile("" : "+v"(z));  // keeps the constant words from being hoisted out of the read loop (and spilled)
+        lmat_read_result q;
+        q.status = (uint8_t)status; q.match_type = LMAT_MT_NOMATCH; q.cand_kmer_cnt = (uint16_t)cand_cnt;
+        q.valid_kmers = valid_kmers; q.read_len = (int)len; q.log_avg = __uint_as_float(z); q.stdev = __uint_as_float(z);
+        q.call_tid = z; q.call_score = __uint_as_float(z); q.cand_off = z; q.n_cand = z; q.bin_sel = bin_sel;
+        store_result(out, q);
+    };
 
     if ((int)len < k) {  // proc_line :1217-1223
-        if (lane == 0) { res.status = LMAT_ST_SHORT_LEN; store_result(out, res); nmacc[0]++; }
+        if (lane == 0) { emit(LMAT_ST_SHORT_LEN, 0); nmacc[0]++; }
         return;
     }
     const uint32_t P = len - k + 1;
     if (P > (uint32_t)U) {  // the host sizes U from the batch's longest read
-        if (lane == 0) { res.status = 255; store_result(out, res); G_OR(&g_cursor[1], (uint32_t)kErrReadTooLong); }
+        if (lane == 0) { emit(255, 0); G_OR(&g_cursor[1], (uint32_t)kErrReadTooLong); }
         return;
     }
     // ---- packed record -> LDS (coalesced), zero tail so windows past the end are invalid
@@ -787,7 +799,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     uint64_t kreg[KC];
     uint32_t hreg[KC];
     uint64_t okm[KC];
-    int valid_kmers = 0, gc = 0, tot = 0;
+    int gc = 0, tot = 0;
     uint64_t prevV = 0;
 #pragma unroll
     for (int c = 0; c < (CACHE ? CH : 1); ++c) {
@@ -828,17 +840,17 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         for (uint32_t p0 = 0; p0 < len; p0 += 64) { uint64_t a; uint32_t b; uint64_t v; pass1_chunk(p0, a, b, v); }
     }
     WSYNC();
-    res.valid_kmers = valid_kmers;
     if (tot > 0) {  // :1205-1206
         const float q = (float)gc / (float)tot;
         const float gc_pcnt = (float)((double)q * 100.0);
-        res.bin_sel = (int)(gc_pcnt / 10.0f);
+        bin_sel = __builtin_amdgcn_readfirstlane((int)(gc_pcnt / 10.0f));
     }
     if (valid_kmers < A.prm.min_kmer) {  // proc_line :1232-1238
-        if (lane == 0) { res.status = LMAT_ST_SHORT_VALID; store_result(out, res); nmacc[0]++; }
+        if (lane == 0) { emit(LMAT_ST_SHORT_VALID, 0); nmacc[0]++; }
         return;
     }
-    if (A.prm.stop_after == 1) { if (lane == 0) { res.status = 250; store_result(out, res); } return; }
+    if (A.prm.stop_after == 1) { if (lane == 0) { emit(250, 0); } return; }
+    RELANE();
     // ---- K1 pass 2: compact first occurrences in position order
     uint32_t nuniq = 0;
     auto pass2_chunk = [&](uint32_t p0, uint64_t km, uint32_t h, bool ok) {
@@ -870,7 +882,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
     }
     WSYNC();
-    if (A.prm.stop_after == 2) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nuniq; store_result(out, res); } return; }
+    if (A.prm.stop_after == 2) { if (lane == 0) { emit(250, nuniq); } return; }
+    RELANE();
     // ---- K2: probe in rounds.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets; all
     //      wave-loads of a group (a whole 150 bp read) are issued before the first is consumed.  K-mers whose
     //      bucket is full and does not hold the key (31 % of buckets are full at load 0.8) go on a pending
@@ -881,29 +894,23 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         constexpr int NL = U / 8 < 17 ? U / 8 : 17;
         uint16_t* plist = (uint16_t*)hv;                               // two lists of U entries; the k-mer hash is dead
         unsigned int* pcnt = (unsigned int*)((uint16_t*)hv + 2 * U);   // [2] lengths of the two lists
-        // one pass over a list of np k-mer indices (identity list in round 0), NLX wave-loads in flight
-        auto probe_pass = [&](auto nlx_tag, auto ident_tag, uint32_t np, const uint16_t* pcur, uint16_t* pnext,
-                              unsigned int* ncnt) {
-            constexpr int NLX = decltype(nlx_tag)::value;
-            constexpr bool IDENT = decltype(ident_tag)::value;
-            for (uint32_t base = 0; base < np; base += NLX * 8) {
-                unsigned long long sl[NLX];
+        // round 0: every distinct k-mer's home bucket, NL wave-loads in flight (8 lanes per bucket, 8 k-mers per load)
+        auto probe_home = [&](uint32_t np, uint16_t* pnext, unsigned int* ncnt) {
+            for (uint32_t base = 0; base < np; base += NL * 8) {
+                unsigned long long sl[NL];
 #pragma unroll
-                for (int i = 0; i < NLX; ++i) {
+                for (int i = 0; i < NL; ++i) {
                     const uint32_t li = base + i * 8 + g;
                     unsigned long long v = 0;
-                    if (li < np) {
-                        const uint32_t idx = IDENT ? li : (uint32_t)pcur[li];
-                        v = slots[(uint64_t)ubucket[idx] * kSlotsPerBucket + sub];
-                    }
+                    if (li < np) v = slots[(uint64_t)ubucket[li] * kSlotsPerBucket + sub];
                     sl[i] = v;
                 }
 #pragma unroll
-                for (int i = 0; i < NLX; ++i) {
+                for (int i = 0; i < NL; ++i) {
                     if (base + i * 8 >= np) break;
                     const uint32_t li = base + i * 8 + g;
                     const bool act = li < np;
-                    const uint32_t idx = act ? (IDENT ? li : (uint32_t)pcur[li]) : 0u;
+                    const uint32_t idx = act ? li : 0u;
                     const uint64_t km = act ? ukmer[idx] : 0;
                     const unsigned long long sv = sl[i];
                     const bool match = act && sv != 0 && (sv >> kPayloadBits) == km;
@@ -918,9 +925,52 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 }
             }
         };
+        // later rounds: the pending k-mers' next TWO buckets at once (16 lanes per k-mer, 4 k-mers per load).  The
+        // chain of dependent HBM round trips per read is what bounds this kernel, and this roughly halves the
+        // number of rounds for ~25 % more bucket reads in those rounds.
+        constexpr int NLX = 10;
+        auto probe_next2 = [&](uint32_t np, const uint16_t* pcur, uint16_t* pnext, unsigned int* ncnt) {
+            const int g4 = lane >> 4, half = (lane >> 3) & 1;
+            for (uint32_t base = 0; base < np; base += NLX * 4) {
+                unsigned long long sl[NLX];
+#pragma unroll
+                for (int i = 0; i < NLX; ++i) {
+                    const uint32_t li = base + i * 4 + g4;
+                    unsigned long long v = 0;
+                    if (li < np) {
+                        uint32_t b = ubucket[pcur[li]] + half;
+                        b = b == tb.nbuckets ? 0u : b;
+                        v = slots[(uint64_t)b * kSlotsPerBucket + sub];
+                    }
+                    sl[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < NLX; ++i) {
+                    if (base + i * 4 >= np) break;
+                    const uint32_t li = base + i * 4 + g4;
+                    const bool act = li < np;
+                    const uint32_t idx = act ? (uint32_t)pcur[li] : 0u;
+                    const uint64_t km = act ? ukmer[idx] : 0;
+                    const unsigned long long sv = sl[i];
+                    const bool match = act && sv != 0 && (sv >> kPayloadBits) == km;
+                    const bool empty = act && sv == 0;
+                    const uint32_t mm = (uint32_t)(__ballot(match) >> (g4 * 16)) & 0xFFFFu;   // [7:0] first bucket, [15:8] second
+                    const uint32_t em = (uint32_t)(__ballot(empty) >> (g4 * 16)) & 0xFFFFu;
+                    // first bucket settles it when it matches or has a free slot; the second one counts only otherwise
+                    const bool first_settles = ((mm | em) & 0xFFu) != 0;
+                    if (match && (half == 0 || !first_settles)) upay[idx] = (uint32_t)(sv & kPayloadMask);
+                    if (act && (lane & 15) == 0 && !first_settles && ((mm | em) >> 8) == 0) {
+                        uint32_t b = ubucket[idx] + 2;
+                        if (b >= tb.nbuckets) b -= tb.nbuckets;
+                        ubucket[idx] = b;
+                        pnext[atomicAdd(ncnt, 1u)] = (uint16_t)idx;
+                    }
+                }
+            }
+        };
         if (lane < 2) pcnt[lane] = 0;
         WSYNC();
-        probe_pass(std::integral_constant<int, NL>{}, std::true_type{}, nuniq, plist, plist + U, pcnt + 1);
+        probe_home(nuniq, plist + U, pcnt + 1);
         WSYNC();
         uint32_t np = pcnt[1];
         int round = 1;
@@ -930,14 +980,15 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             unsigned int* ncnt = pcnt + ((round & 1) ^ 1);
             if (lane == 0) *ncnt = 0;
             WSYNC();
-            probe_pass(std::integral_constant<int, 4>{}, std::false_type{}, np, pcur, pnext, ncnt);
+            probe_next2(np, pcur, pnext, ncnt);
             WSYNC();
             np = *ncnt;
             ++round;
         }
     }
     WSYNC();
-    if (A.prm.stop_after == 3) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = upay[0]; store_result(out, res); } return; }
+    if (A.prm.stop_after == 3) { if (lane == 0) { emit(250, upay[0]); } return; }
+    RELANE();
     // ---- K3a: distinct payloads in first-occurrence order with multiplicities.  Identical payload
     //      means identical taxid list, hence identical contribution at every such position.
     for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
@@ -975,11 +1026,12 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (pay) add_u16(dmult, (uint32_t)(hv[lds_find(hv, L::H - 1, pay)] & 0x7FFFu), 1u);
     }
     WSYNC();
-    if (A.prm.stop_after == 4) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = ndist; store_result(out, res); } return; }
+    if (A.prm.stop_after == 4) { if (lane == 0) { emit(250, ndist); } return; }
     if (ndist == 0) {  // taxid_lst empty: NoDbHits record, proc_line :1270-1277
-        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); nmacc[1]++; }
+        if (lane == 0) { emit(LMAT_ST_NODBHITS, 0); nmacc[1]++; }
         return;
     }
+    RELANE();
     // ---- K3b stage 1: list headers of all distinct payloads in one round of loads; element offsets by scan
     const GAS uint16_t* arena = g_arena;
     uint32_t nel = 0, cand = nuniq, fnd = 0;
@@ -1018,8 +1070,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     bool overflow = nel > (uint32_t)E;
     if (overflow) {
         if (lane == 0) {
-            res.status = 255;
-            store_result(out, res);
+            emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
             else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
         }
@@ -1036,6 +1087,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
     for (int i = lane; i < L::TH; i += 64) { hent[i] = 0; best[i] = 0; }
     WSYNC();
+    RELANE();
     // ---- K3b stage 2: the elements and the taxonomy facts of the ascending-order copy, two rounds of loads
     for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
         const uint32_t e = e0 + lane;
@@ -1056,6 +1108,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
     }
     WSYNC();
+    RELANE();
     // ---- phase 1 registration (read_label.cpp:1104-1122): first-lookup position order, then the depth-sorted
     //      order inside a k-mer's kept list == element order.  Within a chunk the lowest lane holding a new
     //      taxid registers it (atomicMin on the entry), so order is kept with several lists per chunk.
@@ -1084,8 +1137,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
     if (overflow) {
         if (lane == 0) {
-            res.status = 255;
-            store_result(out, res);
+            emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
             else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
         }
@@ -1105,10 +1157,11 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
     }
     WSYNC();
-    if (A.prm.stop_after == 5) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nT; store_result(out, res); } return; }
+    if (A.prm.stop_after == 5) { if (lane == 0) { emit(250, nT); } return; }
+    RELANE();
     // representative strain per species (read_label.cpp:1144-1177): max leaf count, ties -> smallest taxid
     // (-s: the whole post pass :1143-1204 is skipped; the list records already hold the lineages)
-    for (uint32_t e0 = 0; e0 < nel && !A.prm.permissive; e0 += 64) {
+    for (uint32_t e0 = 0; e0 < nel && !PERM; e0 += 64) {
         const uint32_t e = e0 + lane;
         if (e < nel && (el_fl[e] & kFlagStrain) && el_sp[e]) {
             const uint32_t u = el_ta[e];
@@ -1118,12 +1171,13 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
     }
     WSYNC();
+    RELANE();
     // ---- phase 2 (read_label.cpp:1178-1203): per position, ancestors of the eligible kept ids, visited in
     //      ascending taxid order; positions ascending == distinct payloads in first-occurrence order.
     //      Everything but the path elements is already in LDS; the next chain is prefetched.
     {
         auto eligible = [&](uint32_t e) -> bool {
-            if (A.prm.permissive) return false;              // gPERMISSIVE_MATCH: no closure pass
+            if (PERM) return false;                       // gPERMISSIVE_MATCH: no closure pass
             if (dfl[el_d[e]] & kListNegFirst) return false;  // closure only where first >= 0 (:1179)
             if (!(el_fl[e] & kFlagStrain)) return true;      // rank != "strain" (:1184)
             const uint32_t sp = el_sp[e];
@@ -1186,35 +1240,32 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
     if (overflow) {
         if (lane == 0) {
-            res.status = 255;
-            store_result(out, res);
+            emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
             else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
         }
         return;
     }
-    if (A.prm.stop_after == 6) { if (lane == 0) { res.status = 250; res.cand_kmer_cnt = nT; store_result(out, res); } return; }
+    if (A.prm.stop_after == 6) { if (lane == 0) { emit(250, nT); } return; }
+    RELANE();
     cand &= 0xFFFF;  // uint16_t cand_kmer_cnt (:699)
     // ---- construct_labels early exits (:727-733): nothing is written (quirk Q1), tallied NoDbHits
     if ((int)fnd < A.prm.min_fnd_kmer || (int)cand < A.prm.min_kmer) {
         if (lane == 0) {
-            res.status = nT ? LMAT_ST_SILENT : LMAT_ST_NODBHITS;
-            res.cand_kmer_cnt = (uint16_t)cand;
-            store_result(out, res);
+            emit(nT ? LMAT_ST_SILENT : LMAT_ST_NODBHITS, cand);
             nmacc[1]++;
         }
         return;
     }
     if (nT == 0) {  // hits whose kept lists are all empty: taxid_lst empty, proc_line :1270-1277
-        if (lane == 0) { res.status = LMAT_ST_NODBHITS; store_result(out, res); nmacc[1]++; }
+        if (lane == 0) { emit(LMAT_ST_NODBHITS, 0); nmacc[1]++; }
         return;
     }
     if (!INK4) {
         // hand the read to k4_kernel (one lane per read): registration-ordered (taxid, count) table + cand
         if (nT > (uint32_t)kK4T) {
             if (lane == 0) {
-                res.status = 255;
-                store_result(out, res);
+                emit(255, 0);
                 ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;
             }
             return;
@@ -1223,13 +1274,15 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane < (int)nT) krec[2 + lane] = (uint32_t)reg[lane] | ((uint32_t)cnt[lane] << 16);
         if (lane == 0) {
             krec[0] = nT | (cand << 16);
-            res.status = 254;  // pending K4
-            res.cand_kmer_cnt = (uint16_t)cand;
-            store_result(out, res);
+            emit(254, cand);  // pending K4
         }
         return;
     }
     // ---- K4 staging: per-slot taxonomy facts in one round of loads
+    lmat_read_result res;
+    res.status = LMAT_ST_NODBHITS; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = valid_kmers;
+    res.read_len = (int)len; res.log_avg = 0; res.stdev = 0; res.call_tid = 0; res.call_score = 0;
+    res.cand_off = 0; res.n_cand = 0; res.bin_sel = bin_sel;
     const int nmt = nm_table_of(A.nm, cand);
     for (uint32_t s = lane; s < nT; s += 64) {
         const uint32_t t = reg[s];
@@ -1322,6 +1375,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 
 // K4 as its own kernel: one lane per read (64 reads per wave), per-read tables in private memory.
 // Runs the same k4_part1 / k4_part2 as the in-kernel lane-0 path of the large-capacity kernel.
+template <bool NM>
 __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     const DeviceTables& tb = A.tb;
     const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
@@ -1355,7 +1409,7 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
         uint8_t sflags[kK4T], nm_cl[kK4T];
         float score[kK4T], score0[kK4T], nm_rp[kK4T];
         LinEnt lin[LIN];
-        const int nmt = nm_table_of(A.nm, cand);
+        const int nmt = NM ? nm_table_of(A.nm, cand) : -1;  // NM: compile-time, keeps the plain path free of the track[] scratch
         for (int s = 0; s < nT; ++s) {
             const uint32_t w = krec[2 + s];
             const uint32_t t = w & 0xFFFFu;
@@ -1365,7 +1419,7 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
             sflags[s] = g_flags[t];
             tin[s] = g_tin[t];
             tout[s] = g_tout[t];
-            if (nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
+            if (NM && nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
                 const size_t row = (size_t)nmt * tb.n_ids + t;
                 const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
                 const int nb = ((const GAS int*)A.nm.nbins)[nmt];
@@ -1376,7 +1430,7 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
             }
         }
         K4State S;
-        k4_part1<LIN>(A.prm, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, nT, cand, nmt >= 0, nm_rp, nm_cl,
+        k4_part1<LIN>(A.prm, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, nT, cand, NM && nmt >= 0, nm_rp, nm_cl,
                       A.nm);
         uint32_t call_idx = A.phix_call_idx, ncand = 0, coff = 0;
         if (!S.done) {
@@ -1474,7 +1528,7 @@ __global__ __launch_bounds__(64) void gather_bench2_kernel(const uint64_t* __res
     if (acc == 0x123456789ull) atomicAdd(sink, acc);
 }
 
-template <int U, int T, int E, bool INK4>
+template <int U, int T, int E, bool INK4, bool PERM>
 __global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1499,7 +1553,7 @@ __global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs
         const uint64_t off2 = it + 2 * G < count ? rec_off[r_of(it + 2 * G)] : 0;
 #pragma unroll
         for (int j = 0; j < NW; ++j) wnext[j] = it + G < count ? words[off1 + lane + 64 * j] : 0u;
-        classify_one<U, T, E, INK4>(A, r_of(it), smem, lane, wcur, nmacc);
+        classify_one<U, T, E, INK4, PERM>(A, r_of(it), smem, lane, wcur, nmacc);
         WSYNC();
 #pragma unroll
         for (int j = 0; j < NW; ++j) wcur[j] = wnext[j];
@@ -1571,15 +1625,16 @@ void launch_k4(const ClassifyArgs& a, hipStream_t stream) {
     uint64_t blocks = (a.count + 63) / 64;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
-    k4_kernel<<<dim3((unsigned)blocks), dim3(64), 0, stream>>>(a);
+    if (a.nm.active) k4_kernel<true><<<dim3((unsigned)blocks), dim3(64), 0, stream>>>(a);
+    else k4_kernel<false><<<dim3((unsigned)blocks), dim3(64), 0, stream>>>(a);
 }
 
-template <int U, int T, int E, bool INK4>
+template <int U, int T, int E, bool INK4, bool PERM>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         constexpr int lds_bytes0 = WL<U, T, E, INK4>::BYTES;
-        hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
+        hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
         attr_set = true;
     }
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
@@ -1589,22 +1644,24 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     if (a.count_ptr && grid > 512) grid = 512;
     if (grid < 1) grid = 1;
     constexpr int lds_bytes = WL<U, T, E, INK4>::BYTES;
-    classify_kernel<U, T, E, INK4><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
+    classify_kernel<U, T, E, INK4, PERM><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
 
 int classify_max_read_len() { return 2048 + 19; }
 
+// permissive match (-s) is a compile-time variant: a run-time test of it inside the closure loops cost 22%
+#define LC(U, T, E, K) (a.prm.permissive ? launch_classify_t<U, T, E, K, true>(a, stream) : launch_classify_t<U, T, E, K, false>(a, stream))
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream) {
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
     if (P <= 160 && tcap_class == 0) {
-        launch_classify_t<160, 64, 128, false>(a, stream);
+        LC(160, 64, 128, false);
     } else if (P <= 256) {
-        if (tcap_class == 0) launch_classify_t<256, 64, 128, false>(a, stream); else launch_classify_t<256, 1024, 4096, true>(a, stream);
+        if (tcap_class == 0) LC(256, 64, 128, false); else LC(256, 1024, 4096, true);
     } else if (P <= 512) {
-        if (tcap_class == 0) launch_classify_t<512, 64, 128, false>(a, stream); else launch_classify_t<512, 1024, 4096, true>(a, stream);
+        if (tcap_class == 0) LC(512, 64, 128, false); else LC(512, 1024, 4096, true);
     } else if (P <= 2048) {
-        launch_classify_t<2048, 1024, 4096, true>(a, stream);
+        LC(2048, 1024, 4096, true);
     } else {
         return false;
     }
