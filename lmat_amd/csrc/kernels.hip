@@ -327,7 +327,7 @@ struct WL {
     static constexpr int R2_L = INK4 ? 16 * LIN : 0;                   // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
-    static constexpr int R3_E = 16 * E;                                // element staging
+    static constexpr int R3_E = (INK4 ? 16 : 20) * E;                  // element staging (+ tin/tout when slots map to lanes)
     static constexpr int R3 = R3_P > R3_E ? R3_P : R3_E;
     static constexpr int OFF_RD = 0;
     static constexpr int OFF_R1 = ((RD_WORDS * 4 + 15) / 16) * 16;
@@ -714,7 +714,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     uint16_t* el_d = el_ta + E;                  // owning distinct-payload index
     uint16_t* el_sp = el_d + E;                  // species_of[ta]
     uint16_t* el_plen = el_sp + E;               // path_len[ta]
-    uint8_t* el_fl = (uint8_t*)(el_plen + E);    // flags[ta]
+    uint8_t* el_fl = (uint8_t*)(el_plen + E);    // flags[ta]; bit 7 marks a closure-eligible element (lane-parallel closure)
+    uint16_t* el_tin = (uint16_t*)(lds + L::OFF_R3 + 16 * E);  // Euler interval of ta (lane-parallel closure only)
+    uint16_t* el_tout = el_tin + E;
 
     const DeviceTables& tb = A.tb;
     const int k = tb.k;
@@ -925,42 +927,44 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 }
             }
         };
-        // later rounds: the pending k-mers' next TWO buckets at once (16 lanes per k-mer, 4 k-mers per load).  The
-        // chain of dependent HBM round trips per read is what bounds this kernel, and this roughly halves the
-        // number of rounds for ~25 % more bucket reads in those rounds.
-        constexpr int NLX = 10;
-        auto probe_next2 = [&](uint32_t np, const uint16_t* pcur, uint16_t* pnext, unsigned int* ncnt) {
-            const int g4 = lane >> 4, half = (lane >> 3) & 1;
-            for (uint32_t base = 0; base < np; base += NLX * 4) {
+        // later rounds: the pending k-mers' next NB buckets at once (8*NB lanes per k-mer).  The chain of dependent
+        // HBM round trips per read is what bounds this kernel: round 1 reads two buckets per k-mer (~25 % more
+        // bucket reads in that round), later rounds four, which ends nearly every read by the third round.
+        auto probe_next = [&](auto nb_tag, uint32_t np, const uint16_t* pcur, uint16_t* pnext, unsigned int* ncnt) {
+            constexpr int NB = decltype(nb_tag)::value;       // buckets per k-mer: 2 or 4
+            constexpr int KPL = 8 / NB;                       // k-mers per wave-load
+            constexpr int NLX = NB == 2 ? 10 : 4;
+            constexpr uint32_t GM = NB == 2 ? 0xFFFFu : 0xFFFFFFFFu;
+            const int gk = lane / (8 * NB), bi = (lane >> 3) & (NB - 1);
+            for (uint32_t base = 0; base < np; base += NLX * KPL) {
                 unsigned long long sl[NLX];
 #pragma unroll
                 for (int i = 0; i < NLX; ++i) {
-                    const uint32_t li = base + i * 4 + g4;
+                    const uint32_t li = base + i * KPL + gk;
                     unsigned long long v = 0;
                     if (li < np) {
-                        uint32_t b = ubucket[pcur[li]] + half;
-                        b = b == tb.nbuckets ? 0u : b;
+                        uint32_t b = ubucket[pcur[li]] + bi;
+                        if (b >= tb.nbuckets) b -= tb.nbuckets;
                         v = slots[(uint64_t)b * kSlotsPerBucket + sub];
                     }
                     sl[i] = v;
                 }
 #pragma unroll
                 for (int i = 0; i < NLX; ++i) {
-                    if (base + i * 4 >= np) break;
-                    const uint32_t li = base + i * 4 + g4;
+                    if (base + i * KPL >= np) break;
+                    const uint32_t li = base + i * KPL + gk;
                     const bool act = li < np;
                     const uint32_t idx = act ? (uint32_t)pcur[li] : 0u;
                     const uint64_t km = act ? ukmer[idx] : 0;
                     const unsigned long long sv = sl[i];
                     const bool match = act && sv != 0 && (sv >> kPayloadBits) == km;
                     const bool empty = act && sv == 0;
-                    const uint32_t mm = (uint32_t)(__ballot(match) >> (g4 * 16)) & 0xFFFFu;   // [7:0] first bucket, [15:8] second
-                    const uint32_t em = (uint32_t)(__ballot(empty) >> (g4 * 16)) & 0xFFFFu;
-                    // first bucket settles it when it matches or has a free slot; the second one counts only otherwise
-                    const bool first_settles = ((mm | em) & 0xFFu) != 0;
-                    if (match && (half == 0 || !first_settles)) upay[idx] = (uint32_t)(sv & kPayloadMask);
-                    if (act && (lane & 15) == 0 && !first_settles && ((mm | em) >> 8) == 0) {
-                        uint32_t b = ubucket[idx] + 2;
+                    const uint32_t se = (uint32_t)(__ballot(match || empty) >> (gk * 8 * NB)) & GM;  // byte j = bucket j
+                    // the first bucket (in probe order) that matches or has a free slot settles the k-mer
+                    const int settle = se ? (__builtin_ctz(se) >> 3) : NB;
+                    if (match && bi == settle) upay[idx] = (uint32_t)(sv & kPayloadMask);
+                    if (act && (lane & (8 * NB - 1)) == 0 && settle == NB) {
+                        uint32_t b = ubucket[idx] + NB;
                         if (b >= tb.nbuckets) b -= tb.nbuckets;
                         ubucket[idx] = b;
                         pnext[atomicAdd(ncnt, 1u)] = (uint16_t)idx;
@@ -980,7 +984,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             unsigned int* ncnt = pcnt + ((round & 1) ^ 1);
             if (lane == 0) *ncnt = 0;
             WSYNC();
-            probe_next2(np, pcur, pnext, ncnt);
+            if (round == 1) probe_next(std::integral_constant<int, 2>{}, np, pcur, pnext, ncnt);
+            else probe_next(std::integral_constant<int, 4>{}, np, pcur, pnext, ncnt);
             WSYNC();
             np = *ncnt;
             ++round;
@@ -1105,6 +1110,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             el_sp[e] = g_species_of[ta];
             el_plen[e] = g_path_len[ta];
             el_poff[e] = g_path_off[ta];
+            if (!INK4) { el_tin[e] = g_tin[ta]; el_tout[e] = g_tout[ta]; }
         }
     }
     WSYNC();
@@ -1175,67 +1181,164 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     // ---- phase 2 (read_label.cpp:1178-1203): per position, ancestors of the eligible kept ids, visited in
     //      ascending taxid order; positions ascending == distinct payloads in first-occurrence order.
     //      Everything but the path elements is already in LDS; the next chain is prefetched.
-    {
-        auto eligible = [&](uint32_t e) -> bool {
-            if (PERM) return false;                       // gPERMISSIVE_MATCH: no closure pass
-            if (dfl[el_d[e]] & kListNegFirst) return false;  // closure only where first >= 0 (:1179)
-            if (!(el_fl[e] & kFlagStrain)) return true;      // rank != "strain" (:1184)
-            const uint32_t sp = el_sp[e];
-            if (!sp) return false;
-            const int h = tid_find(hent, THM, sp);
-            return h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - (uint32_t)el_ta[e]);
-        };
-        // next eligible element at or after e (uniform scan)
-        auto next_elig = [&](uint32_t e) -> uint32_t {
-            while (e < nel) {
-                const uint32_t x = e + lane;
-                const uint64_t m = __ballot(x < nel && eligible(x));
-                if (m) return e + (uint32_t)__builtin_ctzll(m);
-                e += 64;
-            }
-            return nel;
-        };
-        uint32_t e = next_elig(0);
-        uint32_t a_next = 0;
-        if (e < nel) a_next = (uint32_t)lane < (uint32_t)el_plen[e] ? g_paths[el_poff[e] + lane] : 0u;
-        int cur_d = -1;
-        while (e < nel && !overflow) {
-            const uint32_t d = el_d[e], m = dmult[d], plen = el_plen[e], poff = el_poff[e];
-            if ((int)d != cur_d) {  // entering a new position set: its kept ids are members already
-                cur_d = (int)d;
-                const uint32_t s0 = dstart[d], n = dn[d];
-                for (uint32_t j = lane; j < n; j += 64) stamp[hent[tid_find(hent, THM, el_t[s0 + j])] >> 16] = (uint16_t)d;
-                WSYNC();
-            }
-            uint32_t a_cur = a_next;
-            const uint32_t e2 = next_elig(e + 1);
-            if (e2 < nel) a_next = (uint32_t)lane < (uint32_t)el_plen[e2] ? g_paths[el_poff[e2] + lane] : 0u;
-            for (uint32_t c0 = 0; c0 < plen; c0 += 64) {
-                const uint32_t c = c0 + lane;
-                const bool act = c < plen;
-                const uint32_t a = c0 == 0 ? a_cur : (act ? g_paths[poff + c] : 0u);
-                uint32_t h = 0;
-                if (act) {
-                    h = tid_find_or_claim(hent, THM, a);
+    auto eligible = [&](uint32_t e) -> bool {
+        if (PERM) return false;                          // gPERMISSIVE_MATCH: no closure pass
+        if (dfl[el_d[e]] & kListNegFirst) return false;  // closure only where first >= 0 (:1179)
+        if (!(el_fl[e] & kFlagStrain)) return true;      // rank != "strain" (:1184)
+        const uint32_t sp = el_sp[e];
+        if (!sp) return false;
+        const int h = tid_find(hent, THM, sp);
+        return h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - (uint32_t)el_ta[e]);
+    };
+    if constexpr (INK4) {
+            // next eligible element at or after e (uniform scan)
+            auto next_elig = [&](uint32_t e) -> uint32_t {
+                while (e < nel) {
+                    const uint32_t x = e + lane;
+                    const uint64_t m = __ballot(x < nel && eligible(x));
+                    if (m) return e + (uint32_t)__builtin_ctzll(m);
+                    e += 64;
                 }
-                const bool unreg = act && (hent[h] >> 16) == 0xFFFFu;
-                const uint64_t nm_ = __ballot(unreg);
-                const uint32_t newcnt = popc64(nm_);
-                if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
-                if (unreg) {
-                    const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
-                    hent[h] = a | (s << 16);
-                    reg[s] = (uint16_t)a; stamp[s] = 0xFFFF;
+                return nel;
+            };
+            uint32_t e = next_elig(0);
+            uint32_t a_next = 0;
+            if (e < nel) a_next = (uint32_t)lane < (uint32_t)el_plen[e] ? g_paths[el_poff[e] + lane] : 0u;
+            int cur_d = -1;
+            while (e < nel && !overflow) {
+                const uint32_t d = el_d[e], m = dmult[d], plen = el_plen[e], poff = el_poff[e];
+                if ((int)d != cur_d) {  // entering a new position set: its kept ids are members already
+                    cur_d = (int)d;
+                    const uint32_t s0 = dstart[d], n = dn[d];
+                    for (uint32_t j = lane; j < n; j += 64) stamp[hent[tid_find(hent, THM, el_t[s0 + j])] >> 16] = (uint16_t)d;
+                    WSYNC();
                 }
-                nT += newcnt;
-                WSYNC();
-                if (act) {
-                    const uint32_t s = hent[h] >> 16;
-                    if (stamp[s] != (uint16_t)d) { stamp[s] = (uint16_t)d; cnt[s] += (uint16_t)m; }
+                uint32_t a_cur = a_next;
+                const uint32_t e2 = next_elig(e + 1);
+                if (e2 < nel) a_next = (uint32_t)lane < (uint32_t)el_plen[e2] ? g_paths[el_poff[e2] + lane] : 0u;
+                for (uint32_t c0 = 0; c0 < plen; c0 += 64) {
+                    const uint32_t c = c0 + lane;
+                    const bool act = c < plen;
+                    const uint32_t a = c0 == 0 ? a_cur : (act ? g_paths[poff + c] : 0u);
+                    uint32_t h = 0;
+                    if (act) {
+                        h = tid_find_or_claim(hent, THM, a);
+                    }
+                    const bool unreg = act && (hent[h] >> 16) == 0xFFFFu;
+                    const uint64_t nm_ = __ballot(unreg);
+                    const uint32_t newcnt = popc64(nm_);
+                    if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
+                    if (unreg) {
+                        const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+                        hent[h] = a | (s << 16);
+                        reg[s] = (uint16_t)a; stamp[s] = 0xFFFF;
+                    }
+                    nT += newcnt;
+                    WSYNC();
+                    if (act) {
+                        const uint32_t s = hent[h] >> 16;
+                        if (stamp[s] != (uint16_t)d) { stamp[s] = (uint16_t)d; cnt[s] += (uint16_t)m; }
+                    }
+                    WSYNC();
                 }
-                WSYNC();
+                e = e2;
             }
-            e = e2;
+    } else {
+        // T <= 64: registration slots map to lanes, and the chain-by-chain walk above (one LDS-latency-bound step
+        // per eligible id) becomes three wave-wide steps:
+        //  (1) every ancestor of every eligible id as one flat item list in the walk's order (element, then path
+        //      position), so new ids are registered in the same order with the lowest-lane rule of phase 1;
+        //  (2) the Euler interval of every registered slot, one gather;
+        //  (3) per slot a: count[a] += m_d for each position set d that has an eligible id below a and does not
+        //      keep a itself -- what the stamps compute -- with the elements broadcast from registers.
+        constexpr int EC = E / 64;
+        static_assert(E % 64 == 0 && T <= 64, "lane-parallel closure: one lane per registration slot");
+        uint32_t W = 0;
+#pragma unroll
+        for (int ch = 0; ch < EC; ++ch) {
+            if ((uint32_t)ch * 64 < nel) {
+                const uint32_t e = (uint32_t)ch * 64 + lane;
+                const bool el = e < nel && eligible(e);
+                const uint32_t w = el ? (uint32_t)el_plen[e] : 0u;
+                uint32_t incl = w;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                if (e < nel) {
+                    el_sp[e] = (uint16_t)(W + incl - w);  // species_of is dead once eligibility is known: item offset
+                    if (el) el_fl[e] |= 0x80;
+                }
+                W += __shfl(incl, 63);
+            }
+        }
+        WSYNC();
+        if (W > 65535u) overflow = true;  // item offsets are u16; such a read goes to the large-capacity kernel
+        for (uint32_t i0 = 0; i0 < W && !overflow; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool act = i < W;
+            uint32_t a = 0, h = 0;
+            if (act) {
+                uint32_t lo = 0, hi = nel;  // last element whose offset is <= i (offsets are non-decreasing)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint32_t)el_sp[mid] <= i) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t e = lo - 1;
+                a = g_paths[el_poff[e] + (i - (uint32_t)el_sp[e])];
+                h = tid_find_or_claim(hent, THM, a);
+                atomicMin(&hent[h], a | ((0x8000u | (uint32_t)lane) << 16));
+            }
+            WSYNC();
+            const bool isnew = act && (hent[h] >> 16) == (0x8000u | (uint32_t)lane);
+            const uint64_t nm_ = __ballot(isnew);
+            const uint32_t newcnt = popc64(nm_);
+            if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
+            if (isnew) {
+                const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+                hent[h] = a | (s << 16);
+                reg[s] = (uint16_t)a;
+            }
+            nT += newcnt;
+            WSYNC();
+        }
+        if (!overflow && W > 0) {
+            const bool sl_act = (uint32_t)lane < nT;
+            const uint32_t a_s = sl_act ? (uint32_t)reg[lane] : 0u;
+            uint32_t tin_s = 0xFFFF, tout_s = 0;
+            if (sl_act) { tin_s = g_tin[a_s]; tout_s = g_tout[a_s]; }
+            uint32_t add = 0, m_cur = 0;
+            int cur_d = -1;
+            bool member = false, hit = false;
+#pragma unroll
+            for (int ch = 0; ch < EC; ++ch) {
+                if ((uint32_t)ch * 64 < nel) {
+                    const uint32_t e = (uint32_t)ch * 64 + lane;
+                    uint32_t p0 = 0, p1 = 0, p2 = 0;
+                    if (e < nel) {
+                        const uint32_t d = el_d[e];
+                        p0 = (uint32_t)el_ta[e] | (d << 16);
+                        p1 = (uint32_t)el_tin[e] | ((uint32_t)el_tout[e] << 16);
+                        p2 = (uint32_t)(el_fl[e] >> 7) | ((uint32_t)dmult[d] << 1);
+                    }
+                    const int n_here = (int)(nel - (uint32_t)ch * 64 < 64u ? nel - (uint32_t)ch * 64 : 64u);
+                    for (int j = 0; j < n_here; ++j) {
+                        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, j);
+                        const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)p1, j);
+                        const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)p2, j);
+                        const int d = (int)(q0 >> 16);
+                        if (d != cur_d) {
+                            if (hit && !member) add += m_cur;
+                            cur_d = d; member = false; hit = false; m_cur = q2 >> 1;
+                        }
+                        member |= (q0 & 0xFFFFu) == a_s;
+                        if (q2 & 1u) hit |= tin_s < (q1 & 0xFFFFu) && (q1 >> 16) <= tout_s;
+                    }
+                }
+            }
+            if (hit && !member) add += m_cur;
+            if (sl_act && add) cnt[lane] = (uint16_t)(cnt[lane] + add);
+            WSYNC();
         }
     }
     if (overflow) {
