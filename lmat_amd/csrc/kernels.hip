@@ -26,6 +26,8 @@ namespace lmat {
 // (counted on lgkmcnt as well, so every LDS wait also waits for HBM).  The classify kernel therefore
 // re-types every device pointer into address space 1 (global) up front.
 #define GAS __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));              // 16-byte table records
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // list records are only 4-byte aligned
 #define G_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define G_OR(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 __device__ __forceinline__ void store_result(GAS uint64_t* dst, const lmat_read_result& r) {
@@ -725,12 +727,13 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
     const GAS uint16_t* g_fdepth = (const GAS uint16_t*)tb.fdepth;
     const GAS uint8_t* g_flags = (const GAS uint8_t*)tb.flags;
-    const GAS uint16_t* g_species_of = (const GAS uint16_t*)tb.species_of;
     const GAS uint32_t* g_path_off = (const GAS uint32_t*)tb.path_off;
     const GAS uint16_t* g_path_len = (const GAS uint16_t*)tb.path_len;
     const GAS uint16_t* g_paths = (const GAS uint16_t*)tb.paths;
     const GAS uint16_t* g_tin = (const GAS uint16_t*)tb.tin;
     const GAS uint16_t* g_tout = (const GAS uint16_t*)tb.tout;
+    const GAS uint64_t* g_paths8 = (const GAS uint64_t*)tb.paths8;
+    const GAS u32x4* g_facts16 = (const GAS u32x4*)tb.facts16;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
     // record words were prefetched by the caller: lane l holds word l + 64*j in wcur[j] (word 0 = length)
     const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)wcur[0]);
@@ -1037,20 +1040,27 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         return;
     }
     RELANE();
-    // ---- K3b stage 1: list headers of all distinct payloads in one round of loads; element offsets by scan
+    // ---- K3b stage 1: the first 16 bytes of every distinct payload's list record in one round of loads: header
+    //      and, for lists that keep at most two ids (most do), both id orders.  Singletons are their own element.
+    //      Each round trip to memory costs this kernel ~2 us whatever it carries, so the header and the ids come
+    //      together and the per-id facts below are one 16-byte record, not six gathers.
     const GAS uint16_t* arena = g_arena;
     uint32_t nel = 0, cand = nuniq, fnd = 0;
+    bool any_long = false;
     for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
         const uint32_t d = d0 + lane;
-        uint32_t n = 0, fl = 0, m = 0;
+        uint32_t n = 0, fl = 0, m = 0, pay = 0;
+        uint32_t w3 = 0, w4 = 0, w5 = 0, w6 = 0;
         if (d < ndist) {
-            const uint32_t pay = dpay[d];
+            pay = dpay[d];
             m = dmult[d];
             n = 1;
+            w3 = w4 = pay;
             if (pay >= kListBase) {
-                const uint32_t hdr = *(const GAS uint32_t*)(arena + 2 * (pay - kListBase));  // [flags][n_kept]
-                fl = hdr & 0xFFFFu;
-                n = hdr >> 16;
+                const u32x4_a4 ch = *(const GAS u32x4_a4*)(arena + 2 * (pay - kListBase));  // [flags][n_kept][n_raw][ids...]
+                fl = ch.x & 0xFFFFu;
+                n = ch.x >> 16;
+                w3 = ch.y >> 16; w4 = ch.z & 0xFFFFu; w5 = ch.z >> 16; w6 = ch.w & 0xFFFFu;
             }
         }
         // inclusive scan of n over the wave
@@ -1060,10 +1070,20 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             if (lane >= o) incl += v;
         }
         if (d < ndist) {
+            const uint32_t s0 = nel + incl - n;
             dn[d] = (uint16_t)n;
             dfl[d] = (uint8_t)fl;
-            dstart[d] = (uint16_t)(nel + incl - n);
+            dstart[d] = (uint16_t)s0;
+            if (s0 + n <= (uint32_t)E) {  // owner index of every element; ids of the short lists
+                for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (uint16_t)d;
+                if (n == 1) { el_t[s0] = (uint16_t)w3; el_ta[s0] = (uint16_t)w4; }
+                else if (n == 2) {
+                    el_t[s0] = (uint16_t)w3; el_t[s0 + 1] = (uint16_t)w4;
+                    el_ta[s0] = (uint16_t)w5; el_ta[s0 + 1] = (uint16_t)w6;
+                }
+            }
         }
+        any_long |= __ballot(n > 2) != 0;
         // label_vec.first < 0 positions leave the candidate count (quirk Q4); positions with a
         // non-empty set count as found (construct_labels :722-725)
         uint32_t negm = (fl & kListNegFirst) ? m : 0, fm = n ? m : 0;
@@ -1081,36 +1101,34 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
         return;
     }
-    WSYNC();
-    // owner index of every element (the d-lane writes its run; runs are short)
-    for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
-        const uint32_t d = d0 + lane;
-        if (d < ndist) {
-            const uint32_t s0 = dstart[d], n = dn[d];
-            for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (uint16_t)d;
-        }
-    }
     for (int i = lane; i < L::TH; i += 64) { hent[i] = 0; best[i] = 0; }
     WSYNC();
     RELANE();
-    // ---- K3b stage 2: the elements and the taxonomy facts of the ascending-order copy, two rounds of loads
+    // ---- K3b stage 2: ids of the longer lists (one more round, only when there are any), then one 16-byte
+    //      fact record per id of the ascending-order copy
+    if (any_long) {
+        for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < nel) {
+                const uint32_t d = el_d[e], n = dn[d];
+                if (n > 2) {
+                    const uint32_t eoff = 2 * (dpay[d] - kListBase) + kListHdr, j = e - dstart[d];
+                    el_t[e] = arena[eoff + j];
+                    el_ta[e] = arena[eoff + n + j];
+                }
+            }
+        }
+        WSYNC();
+    }
     for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
         const uint32_t e = e0 + lane;
         if (e < nel) {
-            const uint32_t d = el_d[e], pay = dpay[d], n = dn[d], j = e - dstart[d];
-            uint32_t t = pay, ta = pay;
-            if (pay >= kListBase) {
-                const uint32_t eoff = 2 * (pay - kListBase) + kListHdr;
-                t = arena[eoff + j];
-                ta = arena[eoff + n + j];
-            }
-            el_t[e] = (uint16_t)t;
-            el_ta[e] = (uint16_t)ta;
-            el_fl[e] = g_flags[ta];
-            el_sp[e] = g_species_of[ta];
-            el_plen[e] = g_path_len[ta];
-            el_poff[e] = g_path_off[ta];
-            if (!INK4) { el_tin[e] = g_tin[ta]; el_tout[e] = g_tout[ta]; }
+            const u32x4 f = g_facts16[el_ta[e]];
+            el_poff[e] = f.x;
+            el_plen[e] = (uint16_t)(f.y & 0xFFFFu);
+            el_sp[e] = (uint16_t)(f.y >> 16);
+            el_fl[e] = (uint8_t)(f.w >> 16);
+            if (!INK4) { el_tin[e] = (uint16_t)(f.z & 0xFFFFu); el_tout[e] = (uint16_t)(f.z >> 16); }
         }
     }
     WSYNC();
@@ -1253,6 +1271,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         //      keep a itself -- what the stamps compute -- with the elements broadcast from registers.
         constexpr int EC = E / 64;
         static_assert(E % 64 == 0 && T <= 64, "lane-parallel closure: one lane per registration slot");
+        uint16_t* s_tin = stamp;  // per-slot Euler interval; the stamps are not used on this path and the leaf
+        uint16_t* s_tout = leaf;  // counts are dead after the representative-strain pass
         uint32_t W = 0;
 #pragma unroll
         for (int ch = 0; ch < EC; ++ch) {
@@ -1268,6 +1288,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 if (e < nel) {
                     el_sp[e] = (uint16_t)(W + incl - w);  // species_of is dead once eligibility is known: item offset
                     if (el) el_fl[e] |= 0x80;
+                    const uint32_t s = hent[tid_find(hent, THM, el_ta[e])] >> 16;  // Euler interval of the id's slot
+                    s_tin[s] = el_tin[e];
+                    s_tout[s] = el_tout[e];
                 }
                 W += __shfl(incl, 63);
             }
@@ -1278,6 +1301,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const uint32_t i = i0 + lane;
             const bool act = i < W;
             uint32_t a = 0, h = 0;
+            uint64_t pe = 0;
             if (act) {
                 uint32_t lo = 0, hi = nel;  // last element whose offset is <= i (offsets are non-decreasing)
                 while (lo < hi) {
@@ -1285,7 +1309,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                     if ((uint32_t)el_sp[mid] <= i) lo = mid + 1; else hi = mid;
                 }
                 const uint32_t e = lo - 1;
-                a = g_paths[el_poff[e] + (i - (uint32_t)el_sp[e])];
+                pe = g_paths8[el_poff[e] + (i - (uint32_t)el_sp[e])];  // id | depth | tin | tout of that ancestor
+                a = (uint32_t)(pe & 0xFFFFu);
                 h = tid_find_or_claim(hent, THM, a);
                 atomicMin(&hent[h], a | ((0x8000u | (uint32_t)lane) << 16));
             }
@@ -1298,6 +1323,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
                 hent[h] = a | (s << 16);
                 reg[s] = (uint16_t)a;
+                s_tin[s] = (uint16_t)(pe >> 32);
+                s_tout[s] = (uint16_t)(pe >> 48);
             }
             nT += newcnt;
             WSYNC();
@@ -1306,7 +1333,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const bool sl_act = (uint32_t)lane < nT;
             const uint32_t a_s = sl_act ? (uint32_t)reg[lane] : 0u;
             uint32_t tin_s = 0xFFFF, tout_s = 0;
-            if (sl_act) { tin_s = g_tin[a_s]; tout_s = g_tout[a_s]; }
+            if (sl_act) { tin_s = s_tin[lane]; tout_s = s_tout[lane]; }
             uint32_t add = 0, m_cur = 0;
             int cur_d = -1;
             bool member = false, hit = false;
@@ -1426,7 +1453,6 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             high_tin = tin[highest];
             high_tout = tout[highest];
             const uint32_t alen = g_path_len[high_tid], aoff = g_path_off[high_tid];
-            const float fcand = (float)cand;
             uint32_t room = (uint32_t)L::LIN - (uint32_t)nlin;
             if (alen > room) { if (lane == 0) G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); }
             const uint32_t take = alen < room ? alen : room;
@@ -1482,13 +1508,8 @@ template <bool NM>
 __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     const DeviceTables& tb = A.tb;
     const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
-    const GAS uint16_t* g_fdepth = (const GAS uint16_t*)tb.fdepth;
-    const GAS uint8_t* g_flags = (const GAS uint8_t*)tb.flags;
-    const GAS uint32_t* g_path_off = (const GAS uint32_t*)tb.path_off;
-    const GAS uint16_t* g_path_len = (const GAS uint16_t*)tb.path_len;
-    const GAS uint16_t* g_paths = (const GAS uint16_t*)tb.paths;
-    const GAS uint16_t* g_tin = (const GAS uint16_t*)tb.tin;
-    const GAS uint16_t* g_tout = (const GAS uint16_t*)tb.tout;
+    const GAS uint64_t* g_paths8 = (const GAS uint64_t*)tb.paths8;
+    const GAS u32x4* g_facts16 = (const GAS u32x4*)tb.facts16;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
     GAS unsigned long long* tally_count = (GAS unsigned long long*)A.counts;
     GAS double* tally_score = (GAS double*)(tally_count + tb.n_ids);
@@ -1518,10 +1539,11 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
             const uint32_t t = w & 0xFFFFu;
             reg[s] = (uint16_t)t;
             cnt[s] = (uint16_t)(w >> 16);
-            dep[s] = g_fdepth[t];
-            sflags[s] = g_flags[t];
-            tin[s] = g_tin[t];
-            tout[s] = g_tout[t];
+            const u32x4 f = g_facts16[t];  // one record instead of four gathers
+            dep[s] = (uint16_t)(f.w & 0xFFFFu);
+            sflags[s] = (uint8_t)(f.w >> 16);
+            tin[s] = (uint16_t)(f.z & 0xFFFFu);
+            tout[s] = (uint16_t)(f.z >> 16);
             if (NM && nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
                 const size_t row = (size_t)nmt * tb.n_ids + t;
                 const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
@@ -1544,17 +1566,18 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
             if (have_add) {  // ancestors of the shallowest accepted node (:326-343)
                 high_tin = tin[S.highest];
                 high_tout = tout[S.highest];
-                const uint32_t alen = g_path_len[high_tid], aoff = g_path_off[high_tid];
-                const float fcand = (float)cand;
+                const u32x4 hf = g_facts16[high_tid];
+                const uint32_t alen = hf.y & 0xFFFFu, aoff = hf.x;
                 for (uint32_t j = 0; j < alen; ++j) {
                     if (nlin >= LIN) { G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); break; }
-                    const uint32_t a = g_paths[aoff + j];
+                    const uint64_t pe = g_paths8[aoff + j];
+                    const uint32_t a = (uint32_t)(pe & 0xFFFFu);
                     int sl = -1;
                     for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
                     LinEnt en;
                     en.tid = (uint16_t)a; en.flag = 0; en.pad = 0;
                     en.score = sl >= 0 ? score0[sl] : -10000.0f;
-                    en.dep = g_fdepth[a]; en.tin = g_tin[a]; en.tout = g_tout[a];
+                    en.dep = (uint16_t)(pe >> 16); en.tin = (uint16_t)(pe >> 32); en.tout = (uint16_t)(pe >> 48);
                     lin[nlin++] = en;
                 }
             }

@@ -40,6 +40,22 @@ int upload_taxonomy(lmat_ctx* c) {
     if ((rc = dev_upload(c, &c->dev.conv, T.conv))) return rc;
     if ((rc = dev_upload(c, &c->dev.tin, T.tin))) return rc;
     if ((rc = dev_upload(c, &c->dev.tout, T.tout))) return rc;
+    {
+        std::vector<uint64_t> p8(T.paths.size());
+        for (size_t i = 0; i < T.paths.size(); ++i) {
+            const uint16_t a = T.paths[i];
+            p8[i] = (uint64_t)a | ((uint64_t)T.fdepth[a] << 16) | ((uint64_t)T.tin[a] << 32) | ((uint64_t)T.tout[a] << 48);
+        }
+        std::vector<uint32_t> f16((size_t)(T.n + 1) * 4);
+        for (uint32_t i = 0; i <= T.n; ++i) {
+            f16[4 * i + 0] = T.path_off[i];
+            f16[4 * i + 1] = (uint32_t)T.path_len[i] | ((uint32_t)T.species_of[i] << 16);
+            f16[4 * i + 2] = (uint32_t)T.tin[i] | ((uint32_t)T.tout[i] << 16);
+            f16[4 * i + 3] = (uint32_t)T.fdepth[i] | ((uint32_t)T.flags[i] << 16);
+        }
+        if ((rc = dev_upload(c, &c->dev.paths8, p8))) return rc;
+        if ((rc = dev_upload(c, &c->dev.facts16, f16))) return rc;
+    }
     c->dev.n_ids = T.n + 1;
     // tallies: u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     if (c->d_counts) { hipFree(c->d_counts); c->d_counts = nullptr; }
@@ -86,7 +102,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
-                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
+                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
                     c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -253,8 +269,10 @@ static int build_device_db(lmat_ctx* c, Ingest& B, uint64_t table_bytes) {
     if (arena.size() / 2 + kListBase > kPayloadMask)
         return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
     int rc;
+    const size_t arena_words = arena.size();
+    arena.resize(arena_words + 8, 0);  // the kernels read a record's first 16 bytes in one load
     if ((rc = dev_upload(c, &c->dev.arena, arena))) return rc;
-    c->arena_words = arena.size();
+    c->arena_words = arena_words;
     const uint64_t n = B.kmers.size();
     if ((rc = alloc_table(c, n, table_bytes))) return rc;
     c->dev.k = B.k;
@@ -412,8 +430,10 @@ int lmat_synth_db_build(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t 
         }
     if (arena.size() / 2 + kListBase > kPayloadMask) return set_err(c, LMAT_E_CAPACITY, "arena too large");
     int rc;
+    const size_t arena_words = arena.size();
+    arena.resize(arena_words + 8, 0);  // the kernels read a record's first 16 bytes in one load
     if ((rc = dev_upload(c, &c->dev.arena, arena))) return rc;
-    c->arena_words = arena.size();
+    c->arena_words = arena_words;
     uint32_t* d_lp = nullptr;
     if ((rc = dev_upload(c, &d_lp, list_payload))) return rc;
     if ((rc = dev_upload(c, &c->d_synth_strain_idx, c->synth_strain_idx))) return rc;

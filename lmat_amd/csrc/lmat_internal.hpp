@@ -45,6 +45,9 @@ struct DeviceTables {
     uint16_t* paths = nullptr;
     uint16_t* tin = nullptr;
     uint16_t* tout = nullptr;
+    // packed copies for the classify kernels: one load instead of several gathers per id
+    uint64_t* paths8 = nullptr;   // parallel to paths: id | fdepth << 16 | tin << 32 | tout << 48
+    uint32_t* facts16 = nullptr;  // [n+1][4]: path_off | path_len, species_of << 16 | tin, tout << 16 | fdepth, flags << 16
     uint32_t* conv = nullptr;  // [65536] 16 -> 32, lookup API only
     uint32_t n_ids = 0;
     int k = 0;
