@@ -301,12 +301,16 @@ __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmer
 //   U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in
 //   registered taxids.  Regions are reused across phases (see classify_one).
 // ------------------------------------------------------------------------------------------
-struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351), 16 bytes
+struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351), 12 bytes
     uint16_t tid;
-    uint16_t flag;  // bit0: member of no_good
+    uint16_t dep;   // depth; bit 15 = member of no_good (set only after the depth sort; depths stay below 32768)
+    uint16_t tin, tout;
     float score;
-    uint16_t dep, tin, tout, pad;
 };
+static const uint16_t kLinNoGood = 0x8000;
+static const int kK4SmallT = 16;                     // registered taxids of a "small" read
+static const int kK4SmallLin = kK4SmallT + 3;        // its lineage: the candidates plus at most 3 appended ancestors
+static const int kK4SmallStride = 125;               // dwords per lane (odd): 6 x u16[16], u8[16], f32[16], LinEnt[19]; 5 waves per CU
 
 // U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in registered
 // taxids, E = capacity in kept-list elements summed over the read's distinct payloads.
@@ -326,7 +330,7 @@ struct WL {
     static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
     static constexpr int R2_K = 8 * U + 4 * U;                         // ukmer, ubucket
     static constexpr int R2_D = 4 * U + 2 * U + 2 * U + 2 * U + U;     // dpay, dmult, dn, dstart, dfl
-    static constexpr int R2_L = INK4 ? 16 * LIN : 0;                   // lineage (K4, after the d-arrays die)
+    static constexpr int R2_L = INK4 ? 12 * LIN : 0;                   // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
     static constexpr int R3_E = (INK4 ? 16 : 20) * E;                  // element staging (+ tin/tout when slots map to lanes)
@@ -411,7 +415,7 @@ struct TCmpDev {  // TCmp, read_label.cpp:475-485
     }
 };
 struct CmpDepthDev {  // CmpDepth, read_label.cpp:159-167
-    __device__ bool operator()(const LinEnt& a, const LinEnt& b) const { return (int)a.dep > (int)b.dep; }
+    __device__ bool operator()(const LinEnt& a, const LinEnt& b) const { return (int)(a.dep & 0x7FFF) > (int)(b.dep & 0x7FFF); }
 };
 
 // glibc's logf (sysdeps/ieee754/flt-32/e_logf.c, the ARM optimized-routines algorithm): 16-entry table on the
@@ -512,7 +516,7 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
             sc = glibc_logf(sc / denom);
         }
         score[s] = sc;
-        score0[s] = sc;  // all_cand_set keeps the pre-bias score (:821)
+        if (score0) score0[s] = sc;  // all_cand_set keeps the pre-bias score (:821)
         const uint8_t fl = sflags[s];
         if (fl & kFlagHuman) has_human = true;
         log_sum += sc;
@@ -576,7 +580,7 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
                 lin_done = true;
             } else {
                 LinEnt e;
-                e.tid = reg[s]; e.flag = 0; e.score = score[s]; e.dep = (uint16_t)cd; e.tin = (uint16_t)ti; e.tout = (uint16_t)to; e.pad = 0;
+                e.tid = reg[s]; e.score = score[s]; e.dep = (uint16_t)cd; e.tin = (uint16_t)ti; e.tout = (uint16_t)to;
                 lin[nlin++] = e;
                 if (cd > lowest_depth || i == nT - 1) { lowest = s; lowest_depth = cd; }
                 if (cd < highest_depth || i == nT - 1) { highest = s; highest_depth = cd; }
@@ -609,7 +613,7 @@ __device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_
             if (anc_iv(lin[j].tin, lin[j].tout, ti, to)) break;
             const float ls = lin[j].score;
             if (ls != -10000.0f && (ls - cs) > S.diff_thresh) { keep_going = false; break; }
-            if ((ls - cs) <= S.diff_thresh) { lin[j].flag |= 1; any_no_good = true; }
+            if ((ls - cs) <= S.diff_thresh) { lin[j].dep |= kLinNoGood; any_no_good = true; }
         }
         if (!keep_going) break;
     }
@@ -627,7 +631,7 @@ __device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_
         int root_idx = -1;
         for (int j = 0; j < nlin; ++j) {
             max_val = max_val < lin[j].score ? lin[j].score : max_val;  // std::max(cand, max_val)
-            if (!(lin[j].flag & 1)) { root_idx = j; break; }
+            if (!(lin[j].dep & kLinNoGood)) { root_idx = j; break; }
         }
         if (root_idx < 0) {
             match = LMAT_MT_LCA_ERROR;  // construct_labels leaves best_guess at (0,0), :931-936
@@ -1404,7 +1408,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane < (int)nT) krec[2 + lane] = (uint32_t)reg[lane] | ((uint32_t)cnt[lane] << 16);
         if (lane == 0) {
             krec[0] = nT | (cand << 16);
-            emit(254, cand);  // pending K4
+            emit(nT <= (uint32_t)kK4SmallT && !A.nm.active ? 254u : 253u, cand);  // pending K4, small / large tables
         }
         return;
     }
@@ -1462,7 +1466,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                     const uint32_t a = g_paths[aoff + j];
                     const int s = tid_slot(hent, THM, a);
                     LinEnt en;
-                    en.tid = (uint16_t)a; en.flag = 0; en.pad = 0;
+                    en.tid = (uint16_t)a;
                     en.score = s >= 0 ? score0[s] : -10000.0f;
                     en.dep = g_fdepth[a]; en.tin = g_tin[a]; en.tout = g_tout[a];
                     lin[nlin + j] = en;
@@ -1502,10 +1506,20 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
 }
 
-// K4 as its own kernel: one lane per read (64 reads per wave), per-read tables in private memory.
-// Runs the same k4_part1 / k4_part2 as the in-kernel lane-0 path of the large-capacity kernel.
-template <bool NM>
-__global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
+// ------------------------------------------------------------------------------------------
+// K4 as its own step: one lane per read (64 reads per wave), running k4_part1 / k4_part2 as the in-kernel
+// lane-0 path of the large-capacity kernel does.  The step is a chain of several hundred dependent accesses to
+// the per-read tables, so where those tables live decides its speed:
+//   k4_lds_kernel   reads with at most kK4SmallT registered taxids (three in four): tables in LDS, each lane's
+//                   block an odd number of dwords apart (conflict-free), ~100 cycles per access;
+//   k4_kernel       the rest, and everything when null models are loaded: tables in private (scratch)
+//                   memory, which at 4 KB per lane lives in HBM, ~2 us per access.
+// k4_compact_kernel splits the pending reads of a batch into the two lists (one atomic per wave).
+// ------------------------------------------------------------------------------------------
+template <int TT, int LIN, bool NM>
+__device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint16_t* reg, uint16_t* cnt, uint16_t* dep,
+                                        uint16_t* tin, uint16_t* tout, uint16_t* ord, uint8_t* sflags, float* score,
+                                        float* score0, uint8_t* nm_cl, float* nm_rp, LinEnt* lin, bool bail_on_long) {
     const DeviceTables& tb = A.tb;
     const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
     const GAS uint64_t* g_paths8 = (const GAS uint64_t*)tb.paths8;
@@ -1514,94 +1528,164 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     GAS unsigned long long* tally_count = (GAS unsigned long long*)A.counts;
     GAS double* tally_score = (GAS double*)(tally_count + tb.n_ids);
     GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + tb.n_ids);
-    constexpr int LIN = kK4T + 72;
+    const GAS uint32_t* krec = (const GAS uint32_t*)A.k4buf + it * kK4RecWords;
+    GAS uint64_t* out = (GAS uint64_t*)(A.results + it);
+    lmat_read_result res;
+    {
+        uint64_t w[5];
+        w[0] = out[0]; w[1] = out[1]; w[2] = out[2]; w[3] = out[3]; w[4] = out[4];
+        __builtin_memcpy(&res, w, 40);
+    }
+    if (res.status != 254 && res.status != 253) return true;
+    const uint32_t hdr = krec[0];
+    const int nT = (int)(hdr & 0xFFFFu);
+    const uint32_t cand = hdr >> 16;
+    if (nT > TT) return false;
+    const int nmt = NM ? nm_table_of(A.nm, cand) : -1;  // NM: compile-time, keeps the plain path free of the track[] scratch
+    for (int s = 0; s < nT; ++s) {
+        const uint32_t w = krec[2 + s];
+        const uint32_t t = w & 0xFFFFu;
+        reg[s] = (uint16_t)t;
+        cnt[s] = (uint16_t)(w >> 16);
+        const u32x4 f = g_facts16[t];  // one record instead of four gathers
+        dep[s] = (uint16_t)(f.w & 0xFFFFu);
+        sflags[s] = (uint8_t)(f.w >> 16);
+        tin[s] = (uint16_t)(f.z & 0xFFFFu);
+        tout[s] = (uint16_t)(f.z >> 16);
+        if (NM && nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
+            const size_t row = (size_t)nmt * tb.n_ids + t;
+            const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
+            const int nb = ((const GAS int*)A.nm.nbins)[nmt];
+            const int bin = res.bin_sel < nb ? res.bin_sel : nb - 1;
+            if (cl == 0xFF) G_OR(&g_cursor[1], (uint32_t)kErrNoNullModel);
+            nm_cl[s] = cl == 0xFF ? 0 : cl;
+            nm_rp[s] = (float)((double)((const GAS float*)A.nm.val)[row * A.nm.nb_max + bin] + 0.0001);
+        }
+    }
+    K4State S;
+    k4_part1<LIN>(A.prm, res, S, cnt, score, NM ? score0 : nullptr, dep, sflags, tin, tout, reg, ord, lin, nT, cand, NM && nmt >= 0,
+                  nm_rp, nm_cl, A.nm);
+    uint32_t call_idx = A.phix_call_idx, ncand = 0, coff = 0;
+    if (!S.done) {
+        int nlin = S.nlin;
+        const uint32_t high_tid = S.highest >= 0 ? reg[S.highest] : 0;
+        const bool have_add = S.highest_depth != 0 && high_tid != 0;
+        uint32_t high_tin = 0xFFFF, high_tout = 0xFFFF;
+        if (have_add) {  // ancestors of the shallowest accepted node (:326-343)
+            high_tin = tin[S.highest];
+            high_tout = tout[S.highest];
+            const u32x4 hf = g_facts16[high_tid];
+            const uint32_t alen = hf.y & 0xFFFFu, aoff = hf.x;
+            if (bail_on_long && (uint32_t)nlin + alen > (uint32_t)LIN) return false;
+            const float fcand = (float)cand;
+            for (uint32_t j = 0; j < alen; ++j) {
+                if (nlin >= LIN) { G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); break; }
+                const uint64_t pe = g_paths8[aoff + j];
+                const uint32_t a = (uint32_t)(pe & 0xFFFFu);
+                int sl = -1;
+                for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
+                LinEnt en;
+                en.tid = (uint16_t)a;
+                // pre-bias score of a registered ancestor (all_cand_set, :821), -10000 otherwise
+                en.score = sl >= 0 ? (NM ? score0[sl] : (float)cnt[sl] / fcand) : -10000.0f;
+                en.dep = (uint16_t)(pe >> 16); en.tin = (uint16_t)(pe >> 32); en.tout = (uint16_t)(pe >> 48);
+                lin[nlin++] = en;
+            }
+        }
+        GAS lmat_cand* cout_ = nullptr;
+        if (A.cands) {
+            const uint32_t reserve = A.prm.prn_all ? (uint32_t)nT : (uint32_t)LIN;
+            coff = G_ADD(&g_cursor[0], reserve);
+            if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
+            else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
+        }
+        k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, cout_,
+                 &ncand, &call_idx);
+    }
+    res.cand_off = coff;
+    res.n_cand = ncand;
+    store_result(out, res);
+    if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {
+        G_ADD(&tally_nomatch[1], 1ull);
+    } else if (res.call_score >= A.prm.min_score) {
+        G_ADD(&tally_count[call_idx], 1ull);
+        G_ADD(&tally_score[call_idx], (double)res.call_score);
+    } else if (res.call_score < A.prm.min_score) {
+        G_ADD(&tally_nomatch[2], 1ull);
+    }
+    return true;
+}
+
+// pending reads of the batch -> two index lists by table size (status 254: small, 253: large); counts in cursor[4], cursor[5]
+__global__ __launch_bounds__(256) void k4_compact_kernel(ClassifyArgs A) {
+    GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    const int lane = threadIdx.x & 63;
+    constexpr int K = 16;  // 64 x K reads per wave and pass: one atomic per class for 1024 reads
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave * 64 * K; base < A.count; base += nwaves * 64 * K) {
+        uint32_t st[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint64_t it = base + (uint64_t)j * 64 + lane;
+            st[j] = it < A.count ? (uint32_t)*(const GAS uint8_t*)(A.results + it) : 0u;  // status is the record's first byte
+        }
+        for (int cls = 0; cls < 2; ++cls) {
+            const uint32_t want = cls == 0 ? 254u : 253u;
+            uint32_t total = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) total += (uint32_t)popc64(__ballot(st[j] == want));
+            if (!total) continue;
+            uint32_t pos = 0;
+            if (lane == 0) pos = G_ADD(&g_cursor[4 + cls], total);
+            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+            GAS uint32_t* list = (GAS uint32_t*)(cls == 0 ? A.k4_small : A.k4_large);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const uint64_t m = __ballot(st[j] == want);
+                if (st[j] == want) list[pos + popc64(m & lt_mask(lane))] = (uint32_t)(base + (uint64_t)j * 64 + lane);
+                pos += (uint32_t)popc64(m);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k4_lds_kernel(ClassifyArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    static_assert(kK4SmallStride * 4 >= 12 * kK4SmallT + kK4SmallT + 4 * kK4SmallT + 12 * kK4SmallLin, "per-lane block");
+    unsigned char* blk = smem + (size_t)(threadIdx.x & 63) * kK4SmallStride * 4;
+    uint16_t* reg = (uint16_t*)blk;
+    uint16_t* cnt = reg + kK4SmallT;
+    uint16_t* dep = cnt + kK4SmallT;
+    uint16_t* tin = dep + kK4SmallT;
+    uint16_t* tout = tin + kK4SmallT;
+    uint16_t* ord = tout + kK4SmallT;
+    float* score = (float*)(ord + kK4SmallT);
+    LinEnt* lin = (LinEnt*)(score + kK4SmallT);
+    uint8_t* sflags = (uint8_t*)(lin + kK4SmallLin);
+    GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    const uint64_t n = *(const GAS uint32_t*)(g_cursor + 4);
     const uint64_t stride = (uint64_t)gridDim.x * 64;
-    for (uint64_t it = (uint64_t)blockIdx.x * 64 + threadIdx.x; it < A.count; it += stride) {
-        const GAS uint32_t* krec = (const GAS uint32_t*)A.k4buf + it * kK4RecWords;
-        GAS uint64_t* out = (GAS uint64_t*)(A.results + it);
-        lmat_read_result res;
-        {
-            uint64_t w[5];
-            w[0] = out[0]; w[1] = out[1]; w[2] = out[2]; w[3] = out[3]; w[4] = out[4];
-            __builtin_memcpy(&res, w, 40);
-        }
-        if (res.status != 254) continue;
-        const uint32_t hdr = krec[0];
-        const int nT = (int)(hdr & 0xFFFFu);
-        const uint32_t cand = hdr >> 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
+        const uint64_t it = ((const GAS uint32_t*)A.k4_small)[i];
+        if (!k4_read<kK4SmallT, kK4SmallLin, false>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, nullptr, nullptr, nullptr,
+                                                    lin, true))
+            ((GAS uint32_t*)A.k4_large)[G_ADD(&g_cursor[5], 1u)] = (uint32_t)it;  // lineage longer than the LDS block: scratch kernel
+    }
+}
+
+template <bool NM>
+__global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
+    constexpr int LIN = kK4T + 72;
+    GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    const uint64_t n = *(const GAS uint32_t*)(g_cursor + 5);
+    const uint64_t stride = (uint64_t)gridDim.x * 64;
+    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
+        const uint64_t it = ((const GAS uint32_t*)A.k4_large)[i];
         uint16_t reg[kK4T], cnt[kK4T], dep[kK4T], tin[kK4T], tout[kK4T], ord[kK4T];
-        uint8_t sflags[kK4T], nm_cl[kK4T];
-        float score[kK4T], score0[kK4T], nm_rp[kK4T];
+        uint8_t sflags[kK4T], nm_cl[NM ? kK4T : 1];
+        float score[kK4T], score0[NM ? kK4T : 1], nm_rp[NM ? kK4T : 1];
         LinEnt lin[LIN];
-        const int nmt = NM ? nm_table_of(A.nm, cand) : -1;  // NM: compile-time, keeps the plain path free of the track[] scratch
-        for (int s = 0; s < nT; ++s) {
-            const uint32_t w = krec[2 + s];
-            const uint32_t t = w & 0xFFFFu;
-            reg[s] = (uint16_t)t;
-            cnt[s] = (uint16_t)(w >> 16);
-            const u32x4 f = g_facts16[t];  // one record instead of four gathers
-            dep[s] = (uint16_t)(f.w & 0xFFFFu);
-            sflags[s] = (uint8_t)(f.w >> 16);
-            tin[s] = (uint16_t)(f.z & 0xFFFFu);
-            tout[s] = (uint16_t)(f.z >> 16);
-            if (NM && nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
-                const size_t row = (size_t)nmt * tb.n_ids + t;
-                const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
-                const int nb = ((const GAS int*)A.nm.nbins)[nmt];
-                const int bin = res.bin_sel < nb ? res.bin_sel : nb - 1;
-                if (cl == 0xFF) G_OR(&g_cursor[1], (uint32_t)kErrNoNullModel);
-                nm_cl[s] = cl == 0xFF ? 0 : cl;
-                nm_rp[s] = (float)((double)((const GAS float*)A.nm.val)[row * A.nm.nb_max + bin] + 0.0001);
-            }
-        }
-        K4State S;
-        k4_part1<LIN>(A.prm, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, nT, cand, NM && nmt >= 0, nm_rp, nm_cl,
-                      A.nm);
-        uint32_t call_idx = A.phix_call_idx, ncand = 0, coff = 0;
-        if (!S.done) {
-            int nlin = S.nlin;
-            const uint32_t high_tid = S.highest >= 0 ? reg[S.highest] : 0;
-            const bool have_add = S.highest_depth != 0 && high_tid != 0;
-            uint32_t high_tin = 0xFFFF, high_tout = 0xFFFF;
-            if (have_add) {  // ancestors of the shallowest accepted node (:326-343)
-                high_tin = tin[S.highest];
-                high_tout = tout[S.highest];
-                const u32x4 hf = g_facts16[high_tid];
-                const uint32_t alen = hf.y & 0xFFFFu, aoff = hf.x;
-                for (uint32_t j = 0; j < alen; ++j) {
-                    if (nlin >= LIN) { G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); break; }
-                    const uint64_t pe = g_paths8[aoff + j];
-                    const uint32_t a = (uint32_t)(pe & 0xFFFFu);
-                    int sl = -1;
-                    for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
-                    LinEnt en;
-                    en.tid = (uint16_t)a; en.flag = 0; en.pad = 0;
-                    en.score = sl >= 0 ? score0[sl] : -10000.0f;
-                    en.dep = (uint16_t)(pe >> 16); en.tin = (uint16_t)(pe >> 32); en.tout = (uint16_t)(pe >> 48);
-                    lin[nlin++] = en;
-                }
-            }
-            GAS lmat_cand* cout_ = nullptr;
-            if (A.cands) {
-                const uint32_t reserve = A.prm.prn_all ? (uint32_t)nT : (uint32_t)LIN;
-                coff = G_ADD(&g_cursor[0], reserve);
-                if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
-                else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
-            }
-            k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, cout_,
-                     &ncand, &call_idx);
-        }
-        res.cand_off = coff;
-        res.n_cand = ncand;
-        store_result(out, res);
-        if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {
-            G_ADD(&tally_nomatch[1], 1ull);
-        } else if (res.call_score >= A.prm.min_score) {
-            G_ADD(&tally_count[call_idx], 1ull);
-            G_ADD(&tally_score[call_idx], (double)res.call_score);
-        } else if (res.call_score < A.prm.min_score) {
-            G_ADD(&tally_nomatch[2], 1ull);
-        }
+        k4_read<kK4T, LIN, NM>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, score0, nm_cl, nm_rp, lin, false);
     }
 }
 
@@ -1748,11 +1832,24 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
 }
 
 void launch_k4(const ClassifyArgs& a, hipStream_t stream) {
-    uint64_t blocks = (a.count + 63) / 64;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    uint64_t blocks = (a.count + 4095) / 4096;  // a wave takes 1024 reads per pass
+    if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    if (a.nm.active) k4_kernel<true><<<dim3((unsigned)blocks), dim3(64), 0, stream>>>(a);
-    else k4_kernel<false><<<dim3((unsigned)blocks), dim3(64), 0, stream>>>(a);
+    k4_compact_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(a);
+    constexpr int lds_bytes = kK4SmallStride * 4 * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k4_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    uint64_t waves = (a.count + 63) / 64;
+    uint64_t g1 = waves < 256 * 5 ? waves : 256 * 5;  // 5 blocks of 31.25 KB fit a CU's LDS
+    if (g1 < 1) g1 = 1;
+    k4_lds_kernel<<<dim3((unsigned)g1), dim3(64), lds_bytes, stream>>>(a);
+    uint64_t g2 = waves < 256 * 32 ? waves : 256 * 32;
+    if (g2 < 1) g2 = 1;
+    if (a.nm.active) k4_kernel<true><<<dim3((unsigned)g2), dim3(64), 0, stream>>>(a);
+    else k4_kernel<false><<<dim3((unsigned)g2), dim3(64), 0, stream>>>(a);
 }
 
 template <int U, int T, int E, bool INK4, bool PERM>

@@ -20,7 +20,9 @@ struct ClassifyArgs {
     uint32_t phix_call_idx;    // internal index of 32630
     uint32_t* ovf_list;        // fast kernel: reads whose tables overflowed are appended here (count in cursor[2])
     const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
-    uint32_t* k4buf;           // per-read records handed from the fast classify kernel to k4_kernel
+    uint32_t* k4buf;           // per-read records handed from the fast classify kernel to the K4 kernels
+    uint32_t* k4_small;        // read indices awaiting K4, small tables (count in cursor[4])
+    uint32_t* k4_large;        // read indices awaiting K4, large tables (count in cursor[5])
     NullModelDev nm;           // -n null models (active == 0: scores are plain k-mer fractions)
 };
 

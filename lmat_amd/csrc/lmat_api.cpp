@@ -89,8 +89,8 @@ int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out) {
     lmat_params def = {1.0f, 3.0f, 0.0f, 35, 1, 0, 1};
     c->params = params ? *params : def;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
-    if (hipMalloc((void**)&c->d_cursor, 16) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
-    hipMemset(c->d_cursor, 0, 16);
+    if (hipMalloc((void**)&c->d_cursor, 64) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
+    hipMemset(c->d_cursor, 0, 64);
     *out = c;
     return LMAT_OK;
 }
@@ -103,7 +103,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf};
+                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf, c->d_k4small, c->d_k4large};
     for (void* p : ptrs)
         if (p) hipFree(p);
     free_null_models(c);
@@ -581,6 +581,11 @@ static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
         c->d_ovf = nullptr;
         c->d_k4buf = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_k4buf, count * (uint64_t)kK4RecWords * sizeof(uint32_t)));
+        if (c->d_k4small) hipFree(c->d_k4small);
+        if (c->d_k4large) hipFree(c->d_k4large);
+        c->d_k4small = c->d_k4large = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_k4small, count * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_k4large, count * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_ovf, count * sizeof(uint32_t)));
         c->ovf_cap = count;
     }
@@ -615,6 +620,8 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.ovf_list = c->d_ovf;
     a.count_ptr = nullptr;
     a.k4buf = c->d_k4buf;
+    a.k4_small = c->d_k4small;
+    a.k4_large = c->d_k4large;
     a.nm = c->nm;
     return a;
 }
@@ -628,7 +635,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     int rc = ensure_results(c, count, want_cands ? cand_cap : 0);
     if (rc) return rc;
     if (reads->n > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "read set above 2^32 reads");
-    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 12, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 64, c->stream));
     ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     if (timed) {

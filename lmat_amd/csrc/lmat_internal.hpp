@@ -118,7 +118,9 @@ struct lmat_ctx {
     uint64_t cands_cap = 0;
     uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags, [2] overflow-list length
     uint32_t* d_ovf = nullptr;     // reads to re-run with the large-capacity kernel
-    uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to k4_kernel
+    uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to the K4 kernels
+    uint32_t* d_k4small = nullptr; // index lists of the reads awaiting K4 (k4_compact_kernel)
+    uint32_t* d_k4large = nullptr;
     lmat::NullModelDev nm;         // device pointers owned by the context
     std::vector<void*> nm_allocs;
     uint64_t ovf_cap = 0;
