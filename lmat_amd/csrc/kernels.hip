@@ -1003,41 +1003,73 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     RELANE();
     // ---- K3a: distinct payloads in first-occurrence order with multiplicities.  Identical payload
     //      means identical taxid list, hence identical contribution at every such position.
-    for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
-    WSYNC();
-    for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const uint32_t pay = i < nuniq ? upay[i] : 0;
-        if (pay) lds_min_insert(hv, L::H - 1, pay, i);
-    }
-    WSYNC();
+    //      A read has few distinct payloads, so they are peeled off one per step with ballots (lane d keeps
+    //      payload d and its multiplicity in registers); the LDS hash is only for reads with more than 64.
     uint32_t ndist = 0;
-    for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // dpay/dmult overlay the (dead) k-mer arrays
-        const uint32_t i = i0 + lane;
-        const uint32_t pay = i < nuniq ? upay[i] : 0;
-        bool owner = false;
-        uint32_t h = 0;
-        if (pay) {
-            h = lds_find(hv, L::H - 1, pay);
-            owner = (uint32_t)(hv[h] & 0xFFFF) == i;
+    bool many = false;
+    {
+        uint32_t dp_reg = 0, dm_reg = 0;
+        for (uint32_t i0 = 0; i0 < nuniq && !many; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            uint64_t rem = __ballot(pay != 0);
+            while (rem) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pay, __builtin_ctzll(rem));
+                const uint64_t m = __ballot(pay == v);
+                const uint32_t c = (uint32_t)popc64(m);
+                const uint64_t ex = __ballot((uint32_t)lane < ndist && dp_reg == v);
+                if (ex) {
+                    if (lane == __builtin_ctzll(ex)) dm_reg += c;
+                } else {
+                    if (ndist >= 64) { many = true; break; }
+                    if ((uint32_t)lane == ndist) { dp_reg = v; dm_reg = c; }
+                    ++ndist;
+                }
+                rem &= ~m;
+            }
         }
-        const uint64_t bm = __ballot(owner);
+        if (!many) {
+            if ((uint32_t)lane < ndist) { dpay[lane] = dp_reg; dmult[lane] = (uint16_t)dm_reg; }  // overlay the (dead) k-mer arrays
+            WSYNC();
+        }
+    }
+    if (many) {
+        for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
         WSYNC();
-        if (owner) {
-            const uint32_t rk = ndist + popc64(bm & lt_mask(lane));
-            dpay[rk] = pay;
-            hv[h] = ((unsigned long long)pay << 16) | (0x8000u | rk);  // first index -> rank (bit 15 marks it)
+        for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            if (pay) lds_min_insert(hv, L::H - 1, pay, i);
         }
-        ndist += popc64(bm);
+        WSYNC();
+        ndist = 0;
+        for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // dpay/dmult overlay the (dead) k-mer arrays
+            const uint32_t i = i0 + lane;
+            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            bool owner = false;
+            uint32_t h = 0;
+            if (pay) {
+                h = lds_find(hv, L::H - 1, pay);
+                owner = (uint32_t)(hv[h] & 0xFFFF) == i;
+            }
+            const uint64_t bm = __ballot(owner);
+            WSYNC();
+            if (owner) {
+                const uint32_t rk = ndist + popc64(bm & lt_mask(lane));
+                dpay[rk] = pay;
+                hv[h] = ((unsigned long long)pay << 16) | (0x8000u | rk);  // first index -> rank (bit 15 marks it)
+            }
+            ndist += popc64(bm);
+        }
+        for (uint32_t d = lane; d < (ndist + 1) / 2; d += 64) ((unsigned int*)dmult)[d] = 0;
+        WSYNC();
+        for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // multiplicity = number of distinct k-mers carrying the payload
+            const uint32_t i = i0 + lane;
+            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            if (pay) add_u16(dmult, (uint32_t)(hv[lds_find(hv, L::H - 1, pay)] & 0x7FFFu), 1u);
+        }
+        WSYNC();
     }
-    for (uint32_t d = lane; d < (ndist + 1) / 2; d += 64) ((unsigned int*)dmult)[d] = 0;
-    WSYNC();
-    for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // multiplicity = number of distinct k-mers carrying the payload
-        const uint32_t i = i0 + lane;
-        const uint32_t pay = i < nuniq ? upay[i] : 0;
-        if (pay) add_u16(dmult, (uint32_t)(hv[lds_find(hv, L::H - 1, pay)] & 0x7FFFu), 1u);
-    }
-    WSYNC();
     if (A.prm.stop_after == 4) { if (lane == 0) { emit(250, ndist); } return; }
     if (ndist == 0) {  // taxid_lst empty: NoDbHits record, proc_line :1270-1277
         if (lane == 0) { emit(LMAT_ST_NODBHITS, 0); nmacc[1]++; }
