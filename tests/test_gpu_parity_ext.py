@@ -167,6 +167,36 @@ def test_taxid_table_overflow_rerun(tmp_path):
     eng.close()
 
 
+def test_many_distinct_lists_in_one_read(tmp_path):
+    """More than 64 distinct taxid lists in one read (but few taxids): the fast kernel leaves its
+    ballot-peeling of distinct payloads for the LDS-hash path; the result still matches the oracle."""
+    import itertools
+    from lmat_amd import synth
+    tax = synth.make_taxonomy((3, 4, 4, 4, 4, 3), specials=False)
+    p = synth.write_aux_files(str(tmp_path), tax)
+    tax.leaves = tax.leaves[:6]
+    genomes = synth.make_genomes(tax, 400, 2002)
+    kmers, lists = synth.build_kmer_table(tax, genomes, 20, extra_lists=False)
+    strains = [t for t in tax.ids if tax.rank[t] == "strain"][:12]
+    reads = synth.make_reads(tax, genomes, 40, 150, 3003, err=0.0, frac_random=0.0, frac_n=0.0, frac_lowc=0.0)
+    orc_tmp = __import__("oracle_py").Oracle(p["tree"], p["depth"], p["rank"], p["idmap"])
+    km = [orc_tmp.extract(reads[i][1].encode(), 20)[0] for i in (0, 1)]
+    orc_tmp.close()
+    idx = {int(k): i for i, k in enumerate(kmers.tolist())}
+    combos = [[s] for s in strains] + [list(c) for c in itertools.combinations(strains, 2)]
+    for j, k in enumerate(km[0][:67].tolist()):       # 12 singletons + 55 pairs: 67 payloads, 122 kept ids
+        lists[idx[k]] = combos[j]
+    for j, k in enumerate(km[1][:100].tolist()):      # 100 payloads, 188 kept ids: also overflows E=128 -> large kernel
+        lists[idx[k]] = combos[j % len(combos)] if j < len(combos) else list(strains[:3]) + [strains[3 + j % 8]]
+    p["db"] = os.path.join(str(tmp_path), "th.bin")
+    synth.write_taxhisto(p["db"], kmers, lists, 20)
+    eng = _engine(p)
+    orc = _oracle(p)
+    _compare(eng, orc, [r for _, r in reads], cand_per_read=2048)
+    eng.close()
+    orc.close()
+
+
 def test_async_and_calls_only_agree_with_full_output(config1):
     from lmat_amd import Params
     eng = _engine(config1)
