@@ -84,7 +84,8 @@ int lmat_set_params(lmat_ctx* ctx, const lmat_params* params);
 /* ---- taxonomy + id maps ---------------------------------------------------
  * Replaces TaxTree<uint32_t>(file) + getPathToRoot (src/kmerdb/TaxTree.hpp:24-91),
  * the depth map (read_label.cpp:1574-1582), gRank_table (:1560-1567), conv_map
- * (:1585-1602) and gLowNumPlasmid (:499-510).  rank_fn / plasmid_fn may be NULL. */
+ * (:1585-1602) and gLowNumPlasmid (:499-510).  rank_fn / plasmid_fn may be NULL.
+ * idmap_fn NULL = a database of 32-bit taxids (TID_SIZE=32 build): see lmat_ingest_idmap_from_tree. */
 int lmat_taxonomy_load_files(lmat_ctx* ctx, const char* tree_fn, const char* depth_fn, const char* rank_fn,
                              const char* idmap_fn, const char* plasmid_fn);
 
@@ -183,7 +184,11 @@ int lmat_counts_get(lmat_ctx* ctx, uint32_t* tid32, uint64_t* count, double* sco
 /* ---- GPU-free ingest (the make_db_image tool; also usable without any device) ----------------------
  * Same parsing and options as above, producing the canonical (k-mer, 16-bit taxid list) form;
  * lmat_ingest_lookup returns the stored list of one k-mer (16-bit DB ids, stored order; 0 = absent). */
-int lmat_ingest_create(int k, const char* idmap_fn, lmat_ingest** out);
+int lmat_ingest_create(int k, const char* idmap_fn, lmat_ingest** out);   /* idmap_fn NULL: call lmat_ingest_idmap_from_tree */
+/* A database of 32-bit taxids (the reference's TID_SIZE=32 build, CMakeLists.txt:92-105; make_db_table without -f):
+ * the storage code of a taxid is its rank among the taxonomy tree's node ids (at most 65534 nodes).
+ * lmat_taxonomy_load_files with idmap_fn NULL derives the same codes. */
+int lmat_ingest_idmap_from_tree(lmat_ingest* ing, const char* tree_fn);
 void lmat_ingest_destroy(lmat_ingest* ing);
 const char* lmat_ingest_error(const lmat_ingest* ing);
 int lmat_ingest_set_options(lmat_ingest* ing, int tid_cutoff, const char* rank_map_fn, const char* human_kmers_fn,

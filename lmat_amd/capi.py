@@ -60,6 +60,7 @@ def load_library(path: str | None = None):
         "lmat_db_save_image": (i32, [vp, cp]),
         "lmat_db_load_image": (i32, [vp, cp, u64]),
         "lmat_ingest_create": (i32, [i32, cp, P(vp)]),
+        "lmat_ingest_idmap_from_tree": (i32, [vp, cp]),
         "lmat_ingest_destroy": (None, [vp]),
         "lmat_ingest_error": (cp, [vp]),
         "lmat_ingest_set_options": (i32, [vp, i32, cp, cp, cp, u32]),
@@ -108,7 +109,7 @@ def load_library(path: str | None = None):
 
 EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
             "lmat_db_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
-            "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create",
+            "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create", "lmat_ingest_idmap_from_tree",
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
             "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
             "lmat_ingest_lookup", "lmat_db_from_ingest", "lmat_nullmodel_load", "lmat_nullmodel_clear", "lmat_set_label_modes",
@@ -152,14 +153,17 @@ class Reads:
 class Ingest:
     """GPU-free ingest (lmat_ingest): make_db_table's parsing and options, canonical 16-bit lists."""
 
-    def __init__(self, k=None, idmap=None, image=None):
+    def __init__(self, k=None, idmap=None, image=None, tree=None):
+        """idmap: the 32->16 map file; or tree (no map): a database of 32-bit taxids, codes from the tree."""
         self.lib = load_library()
         h = C.c_void_p()
         rc = self.lib.lmat_ingest_load_image(image.encode(), C.byref(h)) if image else \
-            self.lib.lmat_ingest_create(k, idmap.encode(), C.byref(h))
+            self.lib.lmat_ingest_create(k, idmap.encode() if idmap else None, C.byref(h))
         if rc != 0:
             raise LmatError(rc, "cannot create ingest")
         self.h = h
+        if not image and not idmap:
+            self._chk(self.lib.lmat_ingest_idmap_from_tree(self.h, tree.encode()))
 
     def _chk(self, rc):
         if rc != 0:

@@ -35,6 +35,39 @@ bool Ingest::load_idmap(const char* fn) {
     return true;
 }
 
+bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string& err) {
+    FILE* f = fopen(tree_fn, "r");
+    if (!f) { err = std::string("failed to open ") + tree_fn + " for reading"; return false; }
+    // two comment lines, one count line, then "id nchild child.. parent" / name line pairs (TaxTree.hpp:24-57)
+    char* line = nullptr;
+    size_t cap = 0;
+    for (int i = 0; i < 3; ++i) if (getline(&line, &cap, f) < 0) break;
+    ids.clear();
+    while (getline(&line, &cap, f) >= 0) {
+        char* e = nullptr;
+        const unsigned long long v = strtoull(line, &e, 10);
+        if (e != line) ids.push_back((uint32_t)v);
+        if (getline(&line, &cap, f) < 0) break;  // name
+    }
+    free(line);
+    fclose(f);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    if (ids.size() > 65534) {
+        err = "the taxonomy has " + std::to_string(ids.size()) + " nodes; without a 32->16 map (-f) the engine takes at most 65534";
+        return false;
+    }
+    return true;
+}
+
+bool Ingest::idmap_from_tree(const char* tree_fn) {
+    std::vector<uint32_t> ids;
+    if (!tree_node_ids(tree_fn, ids, err)) return false;
+    br.clear();
+    for (size_t i = 0; i < ids.size(); ++i) br[ids[i]] = (uint16_t)(i + 1);
+    return true;
+}
+
 bool Ingest::set_options(int cutoff, const char* species_map_fn, const char* human_fn, const char* adaptor_fn,
                          uint32_t adaptor) {
     tid_cutoff = cutoff;

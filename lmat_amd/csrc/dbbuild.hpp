@@ -20,6 +20,8 @@
 namespace lmat {
 
 // canonical payload: 1..65535 = the 16-bit DB taxid of a one-element list; 65536 + i = lists[i]
+bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string& err);  // sorted, unique, <= 65534
+
 struct Ingest {
     int k = 0;
     std::unordered_map<uint32_t, uint16_t> br;  // 32 -> 16
@@ -45,6 +47,9 @@ struct Ingest {
 
     ~Ingest() { if (human_fp) fclose(human_fp); }
     bool load_idmap(const char* fn);
+    // Databases built without a 32->16 map (the reference's TID_SIZE=32 builds): the storage code of a taxid is
+    // its rank among the taxonomy tree's node ids, derived identically by the ingest and by the classifier.
+    bool idmap_from_tree(const char* tree_fn);
     bool set_options(int cutoff, const char* species_map_fn, const char* human_fn, const char* adaptor_fn, uint32_t adaptor);
     bool add_taxhisto(const char* fn);
     bool save_image(const char* fn) const;

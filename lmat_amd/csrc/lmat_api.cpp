@@ -130,12 +130,16 @@ int lmat_taxonomy_load_files(lmat_ctx* c, const char* tree_fn, const char* depth
 // ---------------------------------------------------------------------------------- DB
 // GPU-free ingest objects (dbbuild.cpp): what make_db_table does up to the in-memory table
 int lmat_ingest_create(int k, const char* idmap_fn, lmat_ingest** out) {
-    if (!out || !idmap_fn || k < 1 || k > 20) return LMAT_E_ARG;
+    if (!out || k < 1 || k > 20) return LMAT_E_ARG;
     lmat_ingest* g = new lmat_ingest();
     g->ing.k = k;
-    if (!g->ing.load_idmap(idmap_fn)) { delete g; *out = nullptr; return LMAT_E_IO; }
+    if (idmap_fn && *idmap_fn && !g->ing.load_idmap(idmap_fn)) { delete g; *out = nullptr; return LMAT_E_IO; }
     *out = g;
     return LMAT_OK;
+}
+int lmat_ingest_idmap_from_tree(lmat_ingest* g, const char* tree_fn) {
+    if (!g || !tree_fn) return LMAT_E_ARG;
+    return g->ing.idmap_from_tree(tree_fn) ? LMAT_OK : LMAT_E_IO;
 }
 void lmat_ingest_destroy(lmat_ingest* g) { delete g; }
 const char* lmat_ingest_error(const lmat_ingest* g) { return g ? g->ing.err.c_str() : "null ingest"; }

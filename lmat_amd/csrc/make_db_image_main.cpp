@@ -12,18 +12,19 @@
 #include "dbbuild.hpp"
 
 int main(int argc, char* argv[]) {
-    std::string inputfn, outputfn, species_map_fn, id_bit_conv_fn, human_kmer_fn, illu_kmer_fn;
+    std::string inputfn, outputfn, species_map_fn, id_bit_conv_fn, human_kmer_fn, illu_kmer_fn, tree_fn;
     bool list = false;
     int kmer_len = 0, tid_cut = 0, count = 0, c;
     std::cout << "invocation: ";
     for (int j = 0; j < argc; j++) std::cout << argv[j] << " ";
     std::cout << std::endl;
-    while ((c = getopt(argc, argv, "g:q:k:i:o:s:lhm:f:wj:c:u:V")) != -1) {
+    while ((c = getopt(argc, argv, "g:q:k:i:o:s:lhm:f:wj:c:u:Vt:")) != -1) {
         switch (c) {
             case 'j': human_kmer_fn = optarg; break;
             case 'u': illu_kmer_fn = optarg; break;
             case 'w': std::cout << "functionality disabled!\n"; return 1;
             case 'f': id_bit_conv_fn = optarg; break;
+            case 't': tree_fn = optarg; break;  // taxonomy tree: gives the id codes of a 32-bit-taxid database (no -f)
             case 'k': ++count; kmer_len = atoi(optarg); break;
             case 'l': list = true; break;
             case 'i': ++count; inputfn = optarg; break;
@@ -33,16 +34,16 @@ int main(int argc, char* argv[]) {
             case 'q': case 's': case 'c': break;  // stopper / mmap size / extra k-mers: not needed for an image
             case 'h': std::cerr << "only the tax_histo input format is supported\n"; return 1;
             case 'V': std::cout << "LMAT version 1.2.4_2018a\n"; return 0;
-            default: std::cerr << "usage: make_db_image -i <tax_histo|list> [-l] -o <image> -k <k> -f <32to16 map> [-g N -m rankmap] [-j human] [-u adaptors]\n"; return 1;
+            default: std::cerr << "usage: make_db_image -i <tax_histo|list> [-l] -o <image> -k <k> (-f <32to16 map> | -t <taxonomy tree>) [-g N -m rankmap] [-j human] [-u adaptors]\n"; return 1;
         }
     }
-    if (count != 3 || id_bit_conv_fn.empty()) {
-        std::cerr << "usage: make_db_image -i <tax_histo|list> [-l] -o <image> -k <k> -f <32to16 map> [-g N -m rankmap] [-j human] [-u adaptors]\n";
+    if (count != 3 || (id_bit_conv_fn.empty() && tree_fn.empty())) {
+        std::cerr << "usage: make_db_image -i <tax_histo|list> [-l] -o <image> -k <k> (-f <32to16 map> | -t <taxonomy tree>) [-g N -m rankmap] [-j human] [-u adaptors]\n";
         return 1;
     }
     lmat::Ingest ing;
     ing.k = kmer_len;
-    if (!ing.load_idmap(id_bit_conv_fn.c_str()) ||
+    if (!(id_bit_conv_fn.empty() ? ing.idmap_from_tree(tree_fn.c_str()) : ing.load_idmap(id_bit_conv_fn.c_str())) ||
         !ing.set_options(tid_cut, species_map_fn.c_str(), human_kmer_fn.c_str(), illu_kmer_fn.c_str(), 32630)) {
         std::cerr << ing.err << std::endl;
         return 1;

@@ -78,7 +78,6 @@ int main(int argc, char* argv[]) {
     bool fastq = false, prn_read = true;
     int permissive = 0, max_count = 0;
     std::string rank_table_file;
-    std::string unsupported;
     while ((c = getopt(argc, argv, "u:ahn:j:b:ye:w:pk:c:v:k:i:d:l:t:r:sm:o:x:f:g:z:qVH")) != -1) {
         switch (c) {
             case 'h': prm.screen_phix = 0; break;
@@ -122,15 +121,7 @@ int main(int argc, char* argv[]) {
         usage(argv[0]);
         return -1;
     }
-    if (!unsupported.empty()) {
-        std::cerr << "ERROR! option(s)" << unsupported << " (permissive match / run-time pruning) are not "
-                  << "implemented by the MI355X engine yet; refusing to run without them" << std::endl;
-        return -2;
-    }
-    if (id_bit_conv_fn.empty()) {
-        std::cerr << "ERROR! the 16-bit taxid map (-f) is required (TID_SIZE=16 database)" << std::endl;
-        return -1;
-    }
+    // no -f: a database of 32-bit taxids (upstream's TID_SIZE=32 build); storage codes come from the tree
     prm.min_score = min_score;
     prm.min_kmer = min_kmer;
     prm.min_fnd_kmer = min_fnd_kmer;
@@ -152,7 +143,7 @@ int main(int argc, char* argv[]) {
     std::cout << "Reading taxonomy tree " << tax_tree_fn << std::endl;
     std::cout << "Reading taxonomy depth " << depth_file << std::endl;
     if (lmat_taxonomy_load_files(ctx, tax_tree_fn.c_str(), depth_file.c_str(), rank_map_file.empty() ? nullptr : rank_map_file.c_str(),
-                                 id_bit_conv_fn.c_str(), plasmid_file.empty() ? nullptr : plasmid_file.c_str()) != LMAT_OK)
+                                 id_bit_conv_fn.empty() ? nullptr : id_bit_conv_fn.c_str(), plasmid_file.empty() ? nullptr : plasmid_file.c_str()) != LMAT_OK)
         return fail("taxonomy");
     std::cout << "OK!" << std::endl;
     if (!rand_hits_file.empty() && lmat_nullmodel_load(ctx, rand_hits_file.c_str()) != LMAT_OK) return fail("null models");

@@ -12,6 +12,7 @@
 #include <queue>
 #include <sstream>
 #include "lmat_internal.hpp"
+#include "dbbuild.hpp"
 
 namespace lmat {
 
@@ -27,7 +28,7 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
                         const char* idmap_fn, const char* plasmid_fn) {
     HostTaxonomy& T = c->tax;
     T = HostTaxonomy();
-    if (!tree_fn || !depth_fn || !idmap_fn) return set_err(c, LMAT_E_ARG, "tree, depth and 32->16 map files are required");
+    if (!tree_fn || !depth_fn) return set_err(c, LMAT_E_ARG, "tree and depth files are required");
 
     // --- tree: two comment lines, one count line, then "id nchild child.. parent" / name pairs
     std::unordered_map<uint32_t, uint32_t> parent;
@@ -71,7 +72,7 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
     }
     // --- 32 -> 16 map; later lines overwrite (operator[])
     T.conv.assign(65536, 0);
-    {
+    if (idmap_fn && *idmap_fn) {
         FILE* f = fopen(idmap_fn, "r");
         if (!f) return set_err(c, LMAT_E_IO, std::string("ERROR! Unable to read 16-bit map file:") + idmap_fn);
         int src;
@@ -81,6 +82,16 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
             T.br[(uint32_t)src] = (uint16_t)dest;
         }
         fclose(f);
+    } else {
+        // no map: a database of 32-bit taxids (TID_SIZE=32 builds, CMakeLists.txt:92-105).  Storage codes are the
+        // ranks of the tree's node ids, the same rule the ingest uses (dbbuild.cpp:idmap_from_tree).
+        std::vector<uint32_t> ids;
+        std::string e;
+        if (!tree_node_ids(tree_fn, ids, e)) return set_err(c, ids.size() > 65534 ? LMAT_E_CAPACITY : LMAT_E_IO, e);
+        for (size_t i = 0; i < ids.size(); ++i) {
+            T.conv[i + 1] = ids[i];
+            T.br[ids[i]] = (uint16_t)(i + 1);
+        }
     }
     std::unordered_set<uint32_t> low_plasmid;
     if (plasmid_fn && *plasmid_fn) {
@@ -140,7 +151,9 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
     for (uint32_t i = 1; i <= T.n; ++i) {
         const uint32_t t = T.tid32[i];
         auto d = fdepth.find(t);
-        T.fdepth[i] = d == fdepth.end() ? 0 : (uint16_t)std::min<uint32_t>(d->second, 65535);
+        if (d != fdepth.end() && d->second > 32767)
+            return set_err(c, LMAT_E_TAXONOMY, "depth of taxid " + std::to_string(t) + " above 32767");  // bit 15 is the lineage flag
+        T.fdepth[i] = d == fdepth.end() ? 0 : (uint16_t)d->second;
         uint8_t f = 0;
         auto r = rank.find(t);
         if (r != rank.end() && r->second == "strain") f |= kFlagStrain;

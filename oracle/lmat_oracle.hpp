@@ -119,6 +119,17 @@ struct Taxonomy {
         }
         return true;
     }
+    // No -f map: a TID_SIZE=32 build stores the 32-bit ids themselves (CMakeLists.txt:92-105, SortedDb.cpp:503-511 not
+    // taken).  The oracle keeps its 16-bit list storage and uses a bijective code instead -- the rank of the id among
+    // the tree's node ids -- which no result depends on.
+    bool idmap_from_tree() {
+        std::vector<tid_t> ids;
+        for (auto& kv : parent) ids.push_back(kv.first);
+        std::sort(ids.begin(), ids.end());
+        if (ids.size() > 65534) return false;
+        for (size_t i = 0; i < ids.size(); ++i) { br[ids[i]] = (uint16_t)(i + 1); conv[(uint16_t)(i + 1)] = ids[i]; }
+        return true;
+    }
     bool load_depth(const std::string& fn) {  // read_label.cpp:1574-1582
         std::ifstream in(fn.c_str());
         if (!in) return false;

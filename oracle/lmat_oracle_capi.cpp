@@ -23,6 +23,7 @@ orc_ctx* orc_create(const char* tree, const char* depth, const char* rank, const
     if (rank && *rank) c->tax.load_rank(rank);
     if (plasmids && *plasmids) c->tax.load_plasmids(plasmids);
     if (!c->tax.load_tree(tree) || !c->tax.load_depth(depth)) { delete c; return nullptr; }
+    if (!(idmap && *idmap) && !c->tax.idmap_from_tree()) { delete c; return nullptr; }
     return c;
 }
 void orc_destroy(orc_ctx* c) { delete c; }

@@ -68,6 +68,7 @@ int main(int argc, char* argv[]) {
     if (!rank_map_file.empty()) tax.load_rank(rank_map_file);
     if (!plasmid_fn.empty()) tax.load_plasmids(plasmid_fn);
     if (!tax.load_tree(tax_tree_fn)) return -1;
+    if (id_map_fn.empty() && !tax.idmap_from_tree()) { std::cerr << "tree too large for a run without -f\n"; return -1; }
     if (!tax.load_depth(depth_file)) { std::cerr << "ERROR! Unable to open: " << depth_file << std::endl; return -1; }
 
     KmerDb db;

@@ -58,6 +58,32 @@ def test_ingest_matches_reference_add_data(with_opts, tmp_path):
     back.close()
 
 
+def _tree_codes():
+    ids = []
+    with open(os.path.join(DS, "tax.dat")) as f:
+        lines = f.read().split("\n")[3:]
+    for i in range(0, len(lines) - 1, 2):
+        if lines[i].strip():
+            ids.append(int(lines[i].split()[0]))
+    ids = sorted(set(ids))
+    return {i + 1: t for i, t in enumerate(ids)}
+
+
+@pytest.mark.parametrize("with_opts", [False, True])
+def test_ingest_without_id_map_stores_the_same_lists(with_opts):
+    """A database of 32-bit taxids (make_db_table without -f, TID_SIZE=32): storage codes come from the tree;
+    decoded, the stored lists are the ones the reference's add_data stores."""
+    from lmat_amd import Ingest
+    ing = Ingest(20, tree=os.path.join(DS, "tax.dat"))
+    if with_opts:
+        ing.set_options(**OPTS)
+    ing.add_taxhisto(os.path.join(DS, "th.bin"))
+    code = _tree_codes()
+    for km, want in _golden("ref_lookup_opts.txt" if with_opts else "ref_lookup.txt"):
+        assert [code[t] for t in ing.lookup(km)] == want, km
+    ing.close()
+
+
 def test_oracle_matches_reference_add_data_with_options():
     import oracle_py
     o = oracle_py.Oracle(os.path.join(DS, "tax.dat"), os.path.join(DS, "depth.dat"), os.path.join(DS, "rank.txt"),

@@ -454,3 +454,28 @@ def _engine_k(ds, k):
     e.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
     e.build_db(ds["db"], k=k)
     return e
+
+
+def test_database_of_32bit_taxids_without_id_map():
+    """No -f map (upstream's TID_SIZE=32 build): engine and oracle derive storage codes from the tree; the
+    text output equals the oracle's and equals the run that uses the 16-bit map."""
+    from lmat_amd import Engine, Params
+    import oracle_py
+    ds = dict(tree=os.path.join(DS, "tax.dat"), depth=os.path.join(DS, "depth.dat"), rank=os.path.join(DS, "rank.txt"),
+              idmap=None, db=os.path.join(DS, "th.bin"))
+    reads = [l.strip() for l in open(os.path.join(DS, "reads.fa")) if not l.startswith(">")]
+    eng = _engine(ds)
+    orc = _oracle(ds)
+    _compare(eng, orc, reads)
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    res, cands = eng.classify(dr, cand_cap=256 * len(reads))
+    text_nomap = eng.format_out(res, cands, (blob, off), 0)
+    eng.close()
+    orc.close()
+    ds["idmap"] = os.path.join(DS, "map32to16.txt")
+    eng = _engine(ds)
+    dr = eng.upload_reads((blob, off))
+    res, cands = eng.classify(dr, cand_cap=256 * len(reads))
+    assert eng.format_out(res, cands, (blob, off), 0) == text_nomap
+    eng.close()
