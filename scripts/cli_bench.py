@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the read_label-compatible CLI (reported separately from the kernel rate).
+
+BASELINE config 1 shape scaled up in reads: ~1 M-k-mer database (tax_histo -> make_db_image), N 150 bp reads in a
+FASTA file, run_rl.sh flags.  Timed by the CLI's own "Total query time" (FASTA parse + pack + H2D + kernels + D2H +
+text formatting + file writes; database load excluded, as upstream's timer) and by wall clock of the process."""
+import argparse, json, os, re, subprocess, sys, tempfile, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=2000000)
+    ap.add_argument("--threads", type=int, default=8, help="-t: output shards / formatting threads")
+    ap.add_argument("--keep", default=None)
+    a = ap.parse_args()
+    from lmat_amd import synth
+    d = a.keep or tempfile.mkdtemp(prefix="lmat_cli_", dir=os.environ.get("TMPDIR", "/tmp"))
+    os.makedirs(d, exist_ok=True)
+    t0 = time.time()
+    info = synth.generate_dataset(d, (2, 2, 2, 2, 3, 3), 13400, a.reads, L=150)
+    gen_s = time.time() - t0
+    csrc = os.path.join(ROOT, "lmat_amd", "csrc")
+    img = os.path.join(d, "db.img")
+    subprocess.run([os.path.join(csrc, "make_db_image"), "-i", info["db"], "-o", img, "-k", "20", "-f", info["idmap"]],
+                   check=True, stdout=subprocess.DEVNULL)
+    out = {"reads": info["n_reads"], "db_kmers": info["n_kmers"], "generate_s": round(gen_s, 1), "runs": []}
+    for label, extra in (("-p, reads echoed", ["-p"]), ("-p -a (calls + candidates, no echo)", ["-p", "-a"]), ("-a (calls only)", ["-a"])):
+        cmd = [os.path.join(csrc, "read_label"), "-f", info["idmap"], "-u", info["names"], "-w", info["rank"], "-x", "0", "-j", "30",
+               "-l", "0", "-b", "1.0", "-e", info["depth"], "-t", str(a.threads), "-i", info["fasta"], "-d", img,
+               "-c", info["tree"], "-o", os.path.join(d, "out")] + extra
+        t0 = time.time()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        wall = time.time() - t0
+        if p.returncode != 0:
+            print(p.stdout[-2000:], file=sys.stderr)
+            raise SystemExit(p.returncode)
+        m = re.search(r"Total query time: ([0-9.eE+-]+) sec", p.stdout)
+        q = float(m.group(1)) if m else None
+        size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("out") and f.endswith(".out"))
+        out["runs"].append({"flags": label, "query_s": q, "wall_s": round(wall, 2), "reads_per_s_query": round(info["n_reads"] / q) if q else None,
+                            "reads_per_s_wall": round(info["n_reads"] / wall), "out_bytes": size})
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
