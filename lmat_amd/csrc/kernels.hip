@@ -22,6 +22,17 @@ namespace lmat {
         __builtin_amdgcn_wave_barrier();                     \
     } while (0)
 
+// Inside the classify kernels WSYNC is scope-aware: the class for very long reads keeps its per-read tables in
+// global memory, where lanes of the wave order their accesses with a workgroup-scope fence.
+template <bool GMEM>
+__device__ __forceinline__ void wsync() {
+    if (GMEM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+static const int kGmemU = 32768;   // k-mer capacity of the global-memory class (reads up to 32787 bp)
+static const int kGmemGrid = 128;  // its workgroups (one per-read table set of ~1.2 MB each)
+
 // Pointers that arrive inside a by-value struct are "generic" to the compiler, which then emits flat_load
 // (counted on lgkmcnt as well, so every LDS wait also waits for HBM).  The classify kernel therefore
 // re-types every device pointer into address space 1 (global) up front.
@@ -674,6 +685,10 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
     lo |= nl;
 }
 
+#define WSYNC_WAVE WSYNC
+#pragma push_macro("WSYNC")
+#undef WSYNC
+#define WSYNC() wsync<(U > 2048)>()
 template <int U, int T, int E, bool INK4, bool PERM>
 __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane,
                                              const uint32_t* wcur, uint32_t (&nmacc)[2]) {
@@ -764,7 +779,11 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
     const uint32_t P = len - k + 1;
     if (P > (uint32_t)U) {  // the host sizes U from the batch's longest read
-        if (lane == 0) { emit(255, 0); G_OR(&g_cursor[1], (uint32_t)kErrReadTooLong); }
+        if (lane == 0) {
+            emit(255, 0);
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by a larger class
+            else G_OR(&g_cursor[1], (uint32_t)kErrReadTooLong);
+        }
         return;
     }
     // ---- packed record -> LDS (coalesced), zero tail so windows past the end are invalid
@@ -1538,6 +1557,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
 }
 
+#pragma pop_macro("WSYNC")
+
 // ------------------------------------------------------------------------------------------
 // K4 as its own step: one lane per read (64 reads per wave), running k4_part1 / k4_part2 as the in-kernel
 // lane-0 path of the large-capacity kernel does.  The step is a chain of several hundred dependent accesses to
@@ -1770,9 +1791,14 @@ __global__ __launch_bounds__(64) void gather_bench2_kernel(const uint64_t* __res
     if (acc == 0x123456789ull) atomicAdd(sink, acc);
 }
 
+#pragma push_macro("WSYNC")
+#undef WSYNC
+#define WSYNC() wsync<(U > 2048)>()
 template <int U, int T, int E, bool INK4, bool PERM>
 __global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs A) {
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char lds_smem[];
+    // U > 2048: the per-read tables of this workgroup live in global memory
+    unsigned char* smem = U > 2048 ? A.gscratch + (size_t)blockIdx.x * WL<U, T, E, INK4>::BYTES : lds_smem;
     const int lane = threadIdx.x & 63;
     const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
     const GAS uint32_t* index = (const GAS uint32_t*)A.index;
@@ -1808,6 +1834,8 @@ __global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs
         if (nmacc[1]) G_ADD(&tally_nomatch[1], (unsigned long long)nmacc[1]);
     }
 }
+
+#pragma pop_macro("WSYNC")
 
 // ------------------------------------------------------------------------------------------
 // launchers
@@ -1886,6 +1914,12 @@ void launch_k4(const ClassifyArgs& a, hipStream_t stream) {
 
 template <int U, int T, int E, bool INK4, bool PERM>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
+    if (U > 2048) {  // tables in global memory: few workgroups, no LDS
+        int grid = kGmemGrid;
+        if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)(a.count ? a.count : 1);
+        classify_kernel<U, T, E, INK4, PERM><<<dim3(grid), dim3(64), 0, stream>>>(a);
+        return;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         constexpr int lds_bytes0 = WL<U, T, E, INK4>::BYTES;
@@ -1902,7 +1936,8 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     classify_kernel<U, T, E, INK4, PERM><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
 
-int classify_max_read_len() { return 2048 + 19; }
+int classify_max_read_len() { return kGmemU + 19; }
+size_t classify_gmem_scratch_bytes() { return (size_t)kGmemGrid * WL<kGmemU, 4096, 16384, true>::BYTES; }
 
 // permissive match (-s) is a compile-time variant: a run-time test of it inside the closure loops cost 22%
 #define LC(U, T, E, K) (a.prm.permissive ? launch_classify_t<U, T, E, K, true>(a, stream) : launch_classify_t<U, T, E, K, false>(a, stream))
@@ -1917,6 +1952,8 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
         if (tcap_class == 0) LC(512, 64, 128, false); else LC(512, 1024, 4096, true);
     } else if (P <= 2048) {
         LC(2048, 1024, 4096, true);
+    } else if (P <= (uint32_t)kGmemU && a.gscratch) {
+        LC(kGmemU, 4096, 16384, true);
     } else {
         return false;
     }

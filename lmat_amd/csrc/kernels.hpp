@@ -23,6 +23,7 @@ struct ClassifyArgs {
     uint32_t* k4buf;           // per-read records handed from the fast classify kernel to the K4 kernels
     uint32_t* k4_small;        // read indices awaiting K4, small tables (count in cursor[4])
     uint32_t* k4_large;        // read indices awaiting K4, large tables (count in cursor[5])
+    unsigned char* gscratch;   // per-workgroup tables of the global-memory class (reads beyond the LDS classes), or null
     NullModelDev nm;           // -n null models (active == 0: scores are plain k-mer fractions)
 };
 
@@ -49,6 +50,7 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
 void launch_k4(const ClassifyArgs& a, hipStream_t stream);
 int classify_max_read_len();
+size_t classify_gmem_scratch_bytes();
 // issues ~n_probes random bucket reads (rounded up to 64 per wave x 4096 waves)
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,
                          unsigned long long* sink, hipStream_t stream);

@@ -103,7 +103,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf, c->d_k4small, c->d_k4large};
+                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_gscratch};
     for (void* p : ptrs)
         if (p) hipFree(p);
     free_null_models(c);
@@ -469,12 +469,21 @@ int lmat_synth_db_build(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t 
 }
 
 // ---------------------------------------------------------------------------------- reads
+// The fast kernel's capacity class follows the bulk of the batch, not its longest read: the length below which
+// 99 % of the reads fall; longer ones are re-run by a larger class through the device-side overflow list.
+static uint32_t bulk_length(std::vector<uint32_t>& lens) {
+    if (lens.empty()) return 0;
+    const size_t kth = (size_t)((lens.size() - 1) * 0.99);
+    std::nth_element(lens.begin(), lens.begin() + kth, lens.end());
+    return lens[kth];
+}
+
 static int reads_alloc(lmat_ctx* c, const std::vector<uint64_t>& rec_off, uint32_t max_len, lmat_reads** out) {
     lmat_reads* r = new lmat_reads();
     r->n = rec_off.size() - 1;
     r->n_words = rec_off.back();
     r->max_len = max_len;
-    if (hipMalloc((void**)&r->words, std::max<uint64_t>(r->n_words, 1) * 4 + 4096) != hipSuccess ||  // kernels read whole-record tiles: pad
+    if (hipMalloc((void**)&r->words, std::max<uint64_t>(r->n_words, 1) * 4 + 16384) != hipSuccess ||  // kernels read whole-record tiles: pad
         hipMalloc((void**)&r->rec_off, rec_off.size() * 8) != hipSuccess) {
         if (r->words) hipFree(r->words);
         delete r;
@@ -490,14 +499,17 @@ int lmat_reads_upload(lmat_ctx* c, const uint8_t* bases, const uint64_t* off, ui
     hipSetDevice(c->device);
     std::vector<uint64_t> rec_off(n + 1, 0);
     uint32_t max_len = 0;
+    std::vector<uint32_t> lens(n);
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t len = off[i + 1] - off[i];
         if (len > 0x7FFFFFFF) return set_err(c, LMAT_E_ARG, "read too long");
         max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+        lens[i] = (uint32_t)len;
         rec_off[i + 1] = rec_off[i] + rec_words((uint32_t)len);
     }
     int rc = reads_alloc(c, rec_off, max_len, out);
     if (rc) return rc;
+    (*out)->class_len = bulk_length(lens);
     if (!n) return LMAT_OK;
     uint8_t* d_b = nullptr;
     uint64_t* d_o = nullptr;
@@ -526,6 +538,7 @@ int lmat_reads_synth(lmat_ctx* c, uint64_t n, const uint32_t* lengths, uint32_t 
     }
     int rc = reads_alloc(c, rec_off, max_len, out);
     if (rc) return rc;
+    (*out)->class_len = max_len;  // a handful of configured lengths: no tail to cut
     uint32_t* d_len = nullptr;
     HIPCHK(c, hipMalloc((void**)&d_len, n_lengths * 4));
     HIPCHK(c, hipMemcpyAsync(d_len, lengths, n_lengths * 4, hipMemcpyHostToDevice, c->stream));
@@ -624,6 +637,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.ovf_list = c->d_ovf;
     a.count_ptr = nullptr;
     a.k4buf = c->d_k4buf;
+    a.gscratch = nullptr;
     a.k4_small = c->d_k4small;
     a.k4_large = c->d_k4large;
     a.nm = c->nm;
@@ -649,7 +663,11 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         HIPCHK(c, hipEventCreate(&e3));
         HIPCHK(c, hipEventRecord(e0, c->stream));
     }
-    if (!launch_classify(a, reads->max_len, 0, c->stream))
+    if ((int)reads->max_len > classify_max_read_len())
+        return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+    if (reads->max_len > 2048 + 19 && !c->d_gscratch)  // very long reads: per-read tables in global memory
+        HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
+    if (!launch_classify(a, std::min<uint32_t>(reads->class_len, 2048 + 19), 0, c->stream))
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
@@ -663,6 +681,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         b.count_ptr = c->d_cursor + 2;
         b.ovf_list = nullptr;
         b.count = 0;
+        b.gscratch = c->d_gscratch;
         launch_classify(b, reads->max_len, 1, c->stream);
     }
     if (timed) {

@@ -82,6 +82,7 @@ struct lmat_reads {
     uint64_t n = 0;
     uint64_t n_words = 0;
     uint32_t max_len = 0;
+    uint32_t class_len = 0;       // length that all but the longest 1 % of the reads stay under: picks the fast kernel class
 };
 
 struct lmat_ingest {
@@ -119,6 +120,7 @@ struct lmat_ctx {
     uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags, [2] overflow-list length
     uint32_t* d_ovf = nullptr;     // reads to re-run with the large-capacity kernel
     uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to the K4 kernels
+    unsigned char* d_gscratch = nullptr;  // tables of the global-memory class, allocated on first use
     uint32_t* d_k4small = nullptr; // index lists of the reads awaiting K4 (k4_compact_kernel)
     uint32_t* d_k4large = nullptr;
     lmat::NullModelDev nm;         // device pointers owned by the context

@@ -479,3 +479,26 @@ def test_database_of_32bit_taxids_without_id_map():
     res, cands = eng.classify(dr, cand_cap=256 * len(reads))
     assert eng.format_out(res, cands, (blob, off), 0) == text_nomap
     eng.close()
+
+
+def test_long_reads_use_the_global_memory_class(tmp_path):
+    """Reads beyond the LDS classes (> 2067 bp, up to 32787 bp) are re-run by the class that keeps its per-read
+    tables in global memory; a batch of mostly short reads keeps its fast class.  Longer still: a loud error."""
+    from lmat_amd import synth, LmatError
+    info = synth.generate_dataset(str(tmp_path), (2, 2, 2, 1, 2, 2), 35000, 60, L=(150, 150, 150, 3000, 12000, 30000))
+    reads = [l.rstrip("\n") for l in open(info["fasta"]) if not l.startswith(">")]
+    assert max(len(r) for r in reads) > 20000 and sum(len(r) < 200 for r in reads) > 10
+    eng = _engine(info)
+    orc = _oracle(info)
+    res, _, _ = _compare(eng, orc, reads, cand_per_read=4096)
+    assert (res["status"] == 0).sum() > 40
+    # many short reads and one long one: the long one rides the overflow list
+    mixed = [r for r in reads if len(r) < 200] * 20 + [max(reads, key=len)]
+    _compare(eng, orc, mixed, cand_per_read=512)
+    blob, off = _blob(["ACGT" * 10000])
+    dr = eng.upload_reads((blob, off))
+    with pytest.raises(LmatError) as ei:
+        eng.classify(dr)
+    assert ei.value.code == -4
+    eng.close()
+    orc.close()
