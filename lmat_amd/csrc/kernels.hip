@@ -781,7 +781,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     if (P > (uint32_t)U) {  // the host sizes U from the batch's longest read
         if (lane == 0) {
             emit(255, 0);
-            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by a larger class
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by a larger class
             else G_OR(&g_cursor[1], (uint32_t)kErrReadTooLong);
         }
         return;
@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     if (overflow) {
         if (lane == 0) {
             emit(255, 0);
-            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
             else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
         }
         return;
@@ -1217,7 +1217,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     if (overflow) {
         if (lane == 0) {
             emit(255, 0);
-            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
             else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
         }
         return;
@@ -1426,7 +1426,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     if (overflow) {
         if (lane == 0) {
             emit(255, 0);
-            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
             else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
         }
         return;
@@ -1451,7 +1451,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (nT > (uint32_t)kK4T) {
             if (lane == 0) {
                 emit(255, 0);
-                ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[2], 1u)] = (uint32_t)r;
+                ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;
             }
             return;
         }

@@ -18,7 +18,8 @@ struct ClassifyArgs {
     uint32_t* cursor;          // [0] candidate bump cursor, [1] error flags
     void* counts;              // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint32_t phix_call_idx;    // internal index of 32630
-    uint32_t* ovf_list;        // fast kernel: reads whose tables overflowed are appended here (count in cursor[2])
+    uint32_t* ovf_list;        // reads that exceed this launch's capacities are appended here (count in cursor[ovf_slot])
+    uint32_t ovf_slot;         // 2: fast class -> large LDS class; 3: large LDS class -> global-memory class
     const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
     uint32_t* k4buf;           // per-read records handed from the fast classify kernel to the K4 kernels
     uint32_t* k4_small;        // read indices awaiting K4, small tables (count in cursor[4])

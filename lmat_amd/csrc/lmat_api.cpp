@@ -103,7 +103,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_gscratch};
+                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_gscratch};
     for (void* p : ptrs)
         if (p) hipFree(p);
     free_null_models(c);
@@ -604,6 +604,9 @@ static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
         HIPCHK(c, hipMalloc((void**)&c->d_k4small, count * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_k4large, count * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_ovf, count * sizeof(uint32_t)));
+        if (c->d_ovf2) hipFree(c->d_ovf2);
+        c->d_ovf2 = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_ovf2, count * sizeof(uint32_t)));
         c->ovf_cap = count;
     }
     if (cand_cap > c->cands_cap) {
@@ -635,6 +638,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     auto it = c->tax.index_of.find(32630);
     a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
     a.ovf_list = c->d_ovf;
+    a.ovf_slot = 2;
     a.count_ptr = nullptr;
     a.k4buf = c->d_k4buf;
     a.gscratch = nullptr;
@@ -665,7 +669,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     }
     if ((int)reads->max_len > classify_max_read_len())
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
-    if (reads->max_len > 2048 + 19 && !c->d_gscratch)  // very long reads: per-read tables in global memory
+    if (!c->d_gscratch)  // per-read tables of the global-memory class (very long reads, very large taxid tables)
         HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
     if (!launch_classify(a, std::min<uint32_t>(reads->class_len, 2048 + 19), 0, c->stream))
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
@@ -675,14 +679,23 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         c->pending_events.push_back(std::make_pair(e0, e1));
     }
     if (a.prm.stop_after == 0) launch_k4(a, c->stream);  // score + LCA decision, one lane per read
-    {   // last launch on the same stream: reads that overflowed the fast kernel's LDS tables, listed on the device
+    {   // reads that exceeded the fast class (length, taxids, list elements), listed on the device: the large LDS class,
+        // or directly the global-memory class when the batch holds reads beyond 2067 bp
         ClassifyArgs b = a;
         b.index = c->d_ovf;
         b.count_ptr = c->d_cursor + 2;
-        b.ovf_list = nullptr;
+        b.ovf_list = reads->max_len <= 2048 + 19 ? c->d_ovf2 : nullptr;  // the global-memory class is the last resort
+        b.ovf_slot = 3;
         b.count = 0;
         b.gscratch = c->d_gscratch;
         launch_classify(b, reads->max_len, 1, c->stream);
+        if (reads->max_len <= 2048 + 19) {  // what even that class cannot hold goes to the global-memory class
+            ClassifyArgs g = b;
+            g.index = c->d_ovf2;
+            g.count_ptr = c->d_cursor + 3;
+            g.ovf_list = nullptr;
+            launch_classify(g, 2048 + 20, 1, c->stream);
+        }
     }
     if (timed) {
         HIPCHK(c, hipEventRecord(e3, c->stream));
@@ -710,7 +723,7 @@ int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t
         std::vector<lmat_read_result> host(count);
         HIPCHK(c, hipMemcpy(host.data(), c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
         if (cur[1] & kErrTidOverflow)
-            return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
+            return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
         memcpy(results, host.data(), count * sizeof(lmat_read_result));
         if (want) {
             const uint64_t used = std::min<uint64_t>(cur[0], cand_cap);
@@ -758,7 +771,7 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     HIPCHK(c, hipMemcpy(cur, c->d_cursor, 12, hipMemcpyDeviceToHost));
     if (getenv("LMAT_DEBUG")) fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags %u, reads re-run by the large kernel %u\n", cur[0], cur[1], cur[2]);
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
-    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the large kernel's tables (1024 taxids / 4096 list elements)");
+    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
     if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
     return LMAT_OK;
 }

@@ -120,6 +120,7 @@ struct lmat_ctx {
     uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags, [2] overflow-list length
     uint32_t* d_ovf = nullptr;     // reads to re-run with the large-capacity kernel
     uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to the K4 kernels
+    uint32_t* d_ovf2 = nullptr;    // second overflow list: reads beyond the large LDS class
     unsigned char* d_gscratch = nullptr;  // tables of the global-memory class, allocated on first use
     uint32_t* d_k4small = nullptr; // index lists of the reads awaiting K4 (k4_compact_kernel)
     uint32_t* d_k4large = nullptr;
