@@ -887,7 +887,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint64_t bm = __ballot(first);
         if (first) {
             const uint32_t rk = nuniq + popc64(bm & lt_mask(lane));
-            ukmer[rk] = km;
+            ukmer[rk] = (km << kPayloadBits) + 1;  // pre-shifted for the probe's slot compare
             ubucket[rk] = bucket_of(km, tb.nbuckets);
             upay[rk] = 0;
         }
@@ -912,66 +912,35 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     WSYNC();
     if (A.prm.stop_after == 2) { if (lane == 0) { emit(250, nuniq); } return; }
     RELANE();
-    // ---- K2: probe in rounds.  8 lanes read one 64-byte bucket; one wave-instruction covers 8 buckets; all
-    //      wave-loads of a group (a whole 150 bp read) are issued before the first is consumed.  K-mers whose
-    //      bucket is full and does not hold the key (31 % of buckets are full at load 0.8) go on a pending
-    //      list and are probed together, one bucket further, in the next round.
+    // ---- K2: probe in rounds.  FOUR lanes read one 64-byte bucket, 16 B (two slots) each: one wave-instruction
+    //      covers 16 buckets, still one request per 64-byte line, and a 150 bp read's nine wave-loads are all in
+    //      flight before the first is consumed.  (Half the steps of an 8-lane layout: the kernel is bound by
+    //      instruction issue.  One lane per bucket is slower: its four 16-byte loads are four requests per line.)
+    //      Slots fill a bucket front to back (hash_insert), so "has a free slot" is "the last slot is empty".
+    //      A k-mer whose bucket is full without the key (31 % at load 0.8) goes on a pending list; round 1 reads
+    //      its next two buckets at once, later rounds four: nearly every read is done after three round trips.
     {
-        const int g = lane >> 3, sub = lane & 7;
-        const GAS uint64_t* slots = g_slots;
-        constexpr int NL = U / 8 < 17 ? U / 8 : 17;
-        uint16_t* plist = (uint16_t*)hv;                               // two lists of U entries; the k-mer hash is dead
-        unsigned int* pcnt = (unsigned int*)((uint16_t*)hv + 2 * U);   // [2] lengths of the two lists
-        // round 0: every distinct k-mer's home bucket, NL wave-loads in flight (8 lanes per bucket, 8 k-mers per load)
-        auto probe_home = [&](uint32_t np, uint16_t* pnext, unsigned int* ncnt) {
-            for (uint32_t base = 0; base < np; base += NL * 8) {
-                unsigned long long sl[NL];
-#pragma unroll
-                for (int i = 0; i < NL; ++i) {
-                    const uint32_t li = base + i * 8 + g;
-                    unsigned long long v = 0;
-                    if (li < np) v = slots[(uint64_t)ubucket[li] * kSlotsPerBucket + sub];
-                    sl[i] = v;
-                }
-#pragma unroll
-                for (int i = 0; i < NL; ++i) {
-                    if (base + i * 8 >= np) break;
-                    const uint32_t li = base + i * 8 + g;
-                    const bool act = li < np;
-                    const uint32_t idx = act ? li : 0u;
-                    const uint64_t km = act ? ukmer[idx] : 0;
-                    const unsigned long long sv = sl[i];
-                    const bool match = act && sv != 0 && (sv >> kPayloadBits) == km;
-                    const bool empty = act && sv == 0;
-                    const uint64_t me = __ballot(match || empty);
-                    if (match) upay[idx] = (uint32_t)(sv & kPayloadMask);
-                    if (act && sub == 0 && ((uint32_t)(me >> (g * 8)) & 0xFF) == 0) {
-                        const uint32_t b = ubucket[idx] + 1;
-                        ubucket[idx] = b == tb.nbuckets ? 0u : b;
-                        pnext[atomicAdd(ncnt, 1u)] = (uint16_t)idx;
-                    }
-                }
-            }
-        };
-        // later rounds: the pending k-mers' next NB buckets at once (8*NB lanes per k-mer).  The chain of dependent
-        // HBM round trips per read is what bounds this kernel: round 1 reads two buckets per k-mer (~25 % more
-        // bucket reads in that round), later rounds four, which ends nearly every read by the third round.
-        auto probe_next = [&](auto nb_tag, uint32_t np, const uint16_t* pcur, uint16_t* pnext, unsigned int* ncnt) {
-            constexpr int NB = decltype(nb_tag)::value;       // buckets per k-mer: 2 or 4
-            constexpr int KPL = 8 / NB;                       // k-mers per wave-load
-            constexpr int NLX = NB == 2 ? 10 : 4;
-            constexpr uint32_t GM = NB == 2 ? 0xFFFFu : 0xFFFFFFFFu;
-            const int gk = lane / (8 * NB), bi = (lane >> 3) & (NB - 1);
+        const GAS u32x4* quarters = (const GAS u32x4*)g_slots;  // 4 per bucket
+        uint16_t* plist = (uint16_t*)hv;                        // two lists of U entries; the k-mer hash is dead
+        uint32_t npend = 0;                                     // wave-uniform length of the list being written
+        auto probe = [&](auto nb_tag, auto nl_tag, auto ident_tag, uint32_t np, const uint16_t* pcur, uint16_t* pnext) {
+            constexpr int NB = decltype(nb_tag)::value;     // buckets per k-mer: 1 (home), 2 or 4
+            constexpr int NLX = decltype(nl_tag)::value;    // wave-loads in flight
+            constexpr bool IDENT = decltype(ident_tag)::value;
+            constexpr int LPK = 4 * NB;                     // lanes per k-mer
+            constexpr int KPL = 64 / LPK;                   // k-mers per wave-load
+            constexpr uint32_t GM = NB == 4 ? 0xFFFFu : (NB == 2 ? 0xFFu : 0xFu);
+            const int gk = lane / LPK, bi = (lane >> 2) & (NB - 1), q4 = lane & 3;
             for (uint32_t base = 0; base < np; base += NLX * KPL) {
-                unsigned long long sl[NLX];
+                u32x4 sl[NLX];
 #pragma unroll
                 for (int i = 0; i < NLX; ++i) {
                     const uint32_t li = base + i * KPL + gk;
-                    unsigned long long v = 0;
+                    u32x4 v = {0u, 0u, 0u, 0u};
                     if (li < np) {
-                        uint32_t b = ubucket[pcur[li]] + bi;
+                        uint32_t b = ubucket[IDENT ? li : (uint32_t)pcur[li]] + bi;
                         if (b >= tb.nbuckets) b -= tb.nbuckets;
-                        v = slots[(uint64_t)b * kSlotsPerBucket + sub];
+                        v = quarters[(uint64_t)b * 4 + q4];
                     }
                     sl[i] = v;
                 }
@@ -980,40 +949,41 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                     if (base + i * KPL >= np) break;
                     const uint32_t li = base + i * KPL + gk;
                     const bool act = li < np;
-                    const uint32_t idx = act ? (uint32_t)pcur[li] : 0u;
-                    const uint64_t km = act ? ukmer[idx] : 0;
-                    const unsigned long long sv = sl[i];
-                    const bool match = act && sv != 0 && (sv >> kPayloadBits) == km;
-                    const bool empty = act && sv == 0;
-                    const uint32_t se = (uint32_t)(__ballot(match || empty) >> (gk * 8 * NB)) & GM;  // byte j = bucket j
-                    // the first bucket (in probe order) that matches or has a free slot settles the k-mer
-                    const int settle = se ? (__builtin_ctz(se) >> 3) : NB;
-                    if (match && bi == settle) upay[idx] = (uint32_t)(sv & kPayloadMask);
-                    if (act && (lane & (8 * NB - 1)) == 0 && settle == NB) {
+                    const uint32_t idx = act ? (IDENT ? li : (uint32_t)pcur[li]) : 0u;
+                    const uint64_t kmsh1 = act ? ukmer[idx] : 0ull;  // (k-mer << 24) + 1
+                    // slot of key K with payload p is K << 24 | p: match <=> slot - ((K << 24) + 1) < 0xFFFFFF, p = that + 1
+                    const uint64_t t0 = (((uint64_t)sl[i].y << 32) | sl[i].x) - kmsh1;
+                    const uint64_t t1 = (((uint64_t)sl[i].w << 32) | sl[i].z) - kmsh1;
+                    const bool m0 = act && t0 < 0xFFFFFFull, m1 = act && t1 < 0xFFFFFFull;
+                    const bool free_slot = act && q4 == 3 && (sl[i].z | sl[i].w) == 0u;
+                    const uint32_t se = (uint32_t)(__ballot(m0 || m1 || free_slot) >> (gk * LPK)) & GM;  // nibble j = bucket j
+                    // the first bucket (in probe order) that holds the key or has a free slot settles the k-mer
+                    const int settle = se ? (__builtin_ctz(se) >> 2) : NB;
+                    if ((m0 || m1) && bi == settle) upay[idx] = (uint32_t)(m0 ? t0 : t1) + 1u;
+                    const bool pend = act && (lane & (LPK - 1)) == 0 && settle == NB;
+                    const uint64_t pm = __ballot(pend);
+                    if (pend) {
                         uint32_t b = ubucket[idx] + NB;
                         if (b >= tb.nbuckets) b -= tb.nbuckets;
                         ubucket[idx] = b;
-                        pnext[atomicAdd(ncnt, 1u)] = (uint16_t)idx;
+                        pnext[npend + (uint32_t)popc64(pm & lt_mask(lane))] = (uint16_t)idx;
                     }
+                    npend += (uint32_t)popc64(pm);
                 }
             }
         };
-        if (lane < 2) pcnt[lane] = 0;
+        constexpr int NL = (U + 15) / 16 < 9 ? (U + 15) / 16 : 9;
+        probe(std::integral_constant<int, 1>{}, std::integral_constant<int, NL>{}, std::true_type{}, nuniq, plist, plist + U);
         WSYNC();
-        probe_home(nuniq, plist + U, pcnt + 1);
-        WSYNC();
-        uint32_t np = pcnt[1];
         int round = 1;
-        while (np > 0) {
+        while (npend > 0) {
             const uint16_t* pcur = plist + ((round & 1) ? U : 0);
             uint16_t* pnext = plist + ((round & 1) ? 0 : U);
-            unsigned int* ncnt = pcnt + ((round & 1) ^ 1);
-            if (lane == 0) *ncnt = 0;
+            const uint32_t np = npend;
+            npend = 0;
+            if (round == 1) probe(std::integral_constant<int, 2>{}, std::integral_constant<int, 5>{}, std::false_type{}, np, pcur, pnext);
+            else probe(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, std::false_type{}, np, pcur, pnext);
             WSYNC();
-            if (round == 1) probe_next(std::integral_constant<int, 2>{}, np, pcur, pnext, ncnt);
-            else probe_next(std::integral_constant<int, 4>{}, np, pcur, pnext, ncnt);
-            WSYNC();
-            np = *ncnt;
             ++round;
         }
     }
