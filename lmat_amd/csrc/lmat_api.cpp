@@ -767,9 +767,11 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     c->kernel_ms_total = 0;
     c->kernel2_ms_total = 0;
     c->kernel_launches = 0;
-    uint32_t cur[3];
-    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 12, hipMemcpyDeviceToHost));
-    if (getenv("LMAT_DEBUG")) fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags %u, reads re-run by the large kernel %u\n", cur[0], cur[1], cur[2]);
+    uint32_t cur[6];
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 24, hipMemcpyDeviceToHost));
+    if (getenv("LMAT_DEBUG"))
+        fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags %u, reads re-run by the large class %u, by the global-memory class %u; "
+                        "K4 with small tables %u, with large tables %u\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
     if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
     if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
