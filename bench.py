@@ -118,12 +118,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    # LMAT_BENCH_REHEARSE=1: N ranks on ONE GPU over gloo, to rehearse the multi-rank control flow on a 1-GPU box
+    rehearse = os.environ.get("LMAT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from lmat_amd import Engine, Params
     k = 20
@@ -177,11 +184,17 @@ def main():
     kernel_ms, launches = eng.sync()
     classify_ms, decide_ms, _ = eng.last_timing()
     from lmat_amd.shard import allreduce_tallies
-    allreduce_tallies(t_cnt, t_sc, t_nm, dist)  # merge step of read_label.cpp:1760-1800
+    if rehearse and dist is not None:  # gloo: stage through host copies
+        host = [x.cpu() for x in (t_cnt, t_sc, t_nm)]
+        allreduce_tallies(host[0], host[1], host[2], dist)
+        for d_, h_ in zip((t_cnt, t_sc, t_nm), host):
+            d_.copy_(h_)
+    else:
+        allreduce_tallies(t_cnt, t_sc, t_nm, dist)  # merge step of read_label.cpp:1760-1800
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
