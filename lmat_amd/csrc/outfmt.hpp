@@ -8,21 +8,25 @@
 // Floats go through the same "%g" (precision 6) formatting as operator<<(float), applied to
 // the exact float bits the device produced.
 #pragma once
+#include <charconv>
 #include <cstdio>
 #include <string>
 #include "../../include/lmat_hip.h"
 
 namespace lmat {
 
+// std::to_chars(general, 6) is specified as printf's "%.6g" in the C locale, i.e. operator<<(float) with the default
+// precision; it is several times faster than snprintf, which dominated the CLI's run time (tests/test_host_logic.py
+// checks it against "%g" on a sweep of bit patterns).
 inline void put_float(std::string& s, float f) {
     char b[48];
-    snprintf(b, sizeof b, "%g", (double)f);
-    s += b;
+    const auto r = std::to_chars(b, b + sizeof b, f, std::chars_format::general, 6);
+    s.append(b, r.ptr);
 }
 inline void put_int(std::string& s, long long v) {
     char b[32];
-    snprintf(b, sizeof b, "%lld", v);
-    s += b;
+    const auto r = std::to_chars(b, b + sizeof b, v);
+    s.append(b, r.ptr);
 }
 inline const char* match_name(int m) {
     switch (m) {

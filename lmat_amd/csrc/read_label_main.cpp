@@ -25,6 +25,10 @@
 #include <map>
 #include <set>
 #include <sstream>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <queue>
 #include <thread>
 #include <vector>
 #include "../../include/lmat_hip.h"
@@ -66,6 +70,40 @@ struct Batch {
     std::vector<std::string> hdrs;
     size_t n() const { return hdrs.size(); }
     void clear() { bases.clear(); off.assign(1, 0); hdrs.clear(); }
+};
+
+// One batch on its way through the three stages: parse (reader thread) -> classify (main thread, GPU) ->
+// format + write + tally (writer thread).  The stages of consecutive batches overlap.
+struct Work {
+    Batch b;
+    std::vector<lmat_read_result> res;
+    std::vector<lmat_cand> cands;
+};
+class WorkQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::queue<std::unique_ptr<Work>> q;
+    bool closed = false;
+    size_t cap;
+public:
+    explicit WorkQueue(size_t c) : cap(c) {}
+    void push(std::unique_ptr<Work> w) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return q.size() < cap || closed; });
+        if (closed) return;
+        q.push(std::move(w));
+        cv.notify_all();
+    }
+    std::unique_ptr<Work> pop() {  // null = the producer is done
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        std::unique_ptr<Work> w = std::move(q.front());
+        q.pop();
+        cv.notify_all();
+        return w;
+    }
+    void close() { std::lock_guard<std::mutex> l(m); closed = true; cv.notify_all(); }
 };
 
 int main(int argc, char* argv[]) {
@@ -206,79 +244,123 @@ int main(int argc, char* argv[]) {
     std::map<uint32_t, int> merge_count;
     std::map<uint32_t, float> merge_score;
     std::map<int, int> nomatch_merge;
-    FastxReader rd(*in, fastq);
     const size_t kBatch = 1u << 20;
-    Batch b;
     size_t read_count = 0;
-    std::vector<lmat_read_result> res;
-    std::vector<lmat_cand> cands;
-    bool more = true;
-    std::string read, hdr;
-    while (more) {
-        b.clear();
-        while (b.n() < kBatch) {
-            if (!rd.next(read, hdr)) { more = false; break; }
-            ++read_count;
-            if (hdr.empty() || hdr[0] == '\0') {
-                std::ostringstream o;
-                o << "unknown_hdr:" << read_count;
-                hdr = o.str();
+    double t_parse = 0, t_gpu = 0, t_fmt = 0, t_write = 0, t_tally = 0;  // LMAT_CLI_TIMING=1 prints the busy time of each stage
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b_) { return std::chrono::duration<double>(b_ - a).count(); };
+    WorkQueue parsed(2), classified(2);
+    std::thread reader([&]() {  // stage 1: FASTA/FASTQ -> batches
+        FastxReader rd(*in, fastq);
+        std::string read, hdr;
+        bool more = true;
+        while (more) {
+            auto tp0 = now();
+            std::unique_ptr<Work> w(new Work());
+            Batch& b = w->b;
+            while (b.n() < kBatch) {
+                if (!rd.next(read, hdr)) { more = false; break; }
+                ++read_count;
+                if (hdr.empty() || hdr[0] == '\0') {
+                    std::ostringstream o;
+                    o << "unknown_hdr:" << read_count;
+                    hdr = o.str();
+                }
+                b.hdrs.push_back(hdr);
+                b.bases.insert(b.bases.end(), read.begin(), read.end());
+                b.off.push_back(b.bases.size());
             }
-            b.hdrs.push_back(hdr);
-            b.bases.insert(b.bases.end(), read.begin(), read.end());
-            b.off.push_back(b.bases.size());
+            if (!more) std::cout << "Total reads loaded: " << read_count << std::endl;
+            t_parse += secs(tp0, now());
+            if (b.n()) { b.bases.push_back(0); parsed.push(std::move(w)); }
         }
-        if (!more) std::cout << "Total reads loaded: " << read_count << std::endl;
-        const size_t n = b.n();
-        if (!n) break;
+        parsed.close();
+    });
+    const int n_fmt = std::max<int>(n_threads, (int)std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+    std::thread writer([&]() {  // stage 3: text, files, tallies
+        while (std::unique_ptr<Work> w = classified.pop()) {
+            auto tp2 = now();
+            const Batch& b = w->b;
+            const std::vector<lmat_read_result>& res = w->res;
+            const lmat_cand* cands = w->cands.data();
+            const size_t n = b.n();
+            // shard t holds a contiguous block of every batch; a block is formatted in slices by several threads
+            const size_t per = (n + n_threads - 1) / n_threads;
+            const int slices = std::max(1, n_fmt / n_threads);
+            std::vector<std::string> text((size_t)n_threads * slices);
+            std::vector<std::thread> th;
+            for (int j = 0; j < n_threads * slices; ++j) {
+                th.emplace_back([&, j]() {
+                    const int t = j / slices, sl = j % slices;
+                    const size_t lo0 = std::min(n, t * per), hi0 = std::min(n, lo0 + per);
+                    const size_t sper = (hi0 - lo0 + slices - 1) / slices;
+                    const size_t lo = std::min(hi0, lo0 + sl * sper), hi = std::min(hi0, lo + sper);
+                    std::string& s = text[j];
+                    s.reserve((hi - lo) * (prn_read ? 384 : 200));
+                    for (size_t i = lo; i < hi; ++i) {
+                        s += b.hdrs[i];
+                        s += '\t';
+                        if (prn_read) s.append((const char*)b.bases.data() + b.off[i], b.off[i + 1] - b.off[i]);
+                        else s += 'X';
+                        s += '\t';
+                        format_call(s, prm, k_size, res[i], cands);
+                    }
+                });
+            }
+            for (auto& x : th) x.join();
+            auto tp3 = now();
+            t_fmt += secs(tp2, tp3);
+            for (int j = 0; j < n_threads * slices; ++j) ofs[j / slices] << text[j];
+            auto tp4 = now();
+            t_write += secs(tp3, tp4);
+            // tallies in read order (proc_line :1241-1276), float sums like a -t 1 run
+            for (size_t i = 0; i < n; ++i) {
+                const lmat_read_result& r = res[i];
+                if (r.status == LMAT_ST_SHORT_LEN || r.status == LMAT_ST_SHORT_VALID) nomatch_merge[0] += 1;
+                else if (r.status == LMAT_ST_NODBHITS || r.status == LMAT_ST_SILENT) nomatch_merge[1] += 1;
+                else if (r.status != LMAT_ST_PHIX && r.match_type == LMAT_MT_NOMATCH) nomatch_merge[1] += 1;
+                else if (r.call_score >= min_score) {
+                    if (merge_count.find(r.call_tid) == merge_count.end()) { merge_count[r.call_tid] = 1; merge_score[r.call_tid] = r.call_score; }
+                    else { merge_count[r.call_tid] += 1; merge_score[r.call_tid] += r.call_score; }
+                } else if (r.call_score < min_score) nomatch_merge[2] += 1;
+            }
+            t_tally += secs(tp4, now());
+        }
+    });
+    bool failed = false;
+    while (std::unique_ptr<Work> w = parsed.pop()) {  // stage 2: the GPU
+        auto tp1 = now();
+        const size_t n = w->b.n();
         lmat_reads* dr = nullptr;
-        b.bases.push_back(0);
-        if (lmat_reads_upload(ctx, b.bases.data(), b.off.data(), n, &dr) != LMAT_OK) return fail("read upload");
-        res.resize(n);
+        if (lmat_reads_upload(ctx, w->b.bases.data(), w->b.off.data(), n, &dr) != LMAT_OK) { failed = true; break; }
+        w->res.resize(n);
         uint64_t ncand = 0;
         size_t cap = std::max<size_t>(64 * n, 4096);
         for (;;) {  // grow the candidate buffer until the batch fits
-            cands.resize(cap);
-            int rc = lmat_classify(ctx, dr, 0, n, res.data(), cands.data(), cap, &ncand);
+            w->cands.resize(cap);
+            int rc = lmat_classify(ctx, dr, 0, n, w->res.data(), w->cands.data(), cap, &ncand);
             if (rc == LMAT_OK) break;
             if (rc == LMAT_E_CAPACITY && strstr(lmat_last_error(ctx), "cand_cap") && cap < (size_t)1 << 31) { cap *= 4; continue; }
-            return fail("classify");
+            failed = true;
+            break;
         }
         lmat_reads_free(ctx, dr);
-        // format: contiguous blocks per shard, one thread each
-        std::vector<std::string> text(n_threads);
-        std::vector<std::thread> th;
-        const size_t per = (n + n_threads - 1) / n_threads;
-        for (int t = 0; t < n_threads; ++t) {
-            th.emplace_back([&, t]() {
-                std::string& s = text[t];
-                const size_t lo = std::min(n, t * per), hi = std::min(n, lo + per);
-                s.reserve((hi - lo) * 256);
-                for (size_t i = lo; i < hi; ++i) {
-                    s += b.hdrs[i];
-                    s += '\t';
-                    if (prn_read) s.append((const char*)b.bases.data() + b.off[i], b.off[i + 1] - b.off[i]);
-                    else s += 'X';
-                    s += '\t';
-                    format_call(s, prm, k_size, res[i], cands.data());
-                }
-            });
-        }
-        for (auto& x : th) x.join();
-        for (int t = 0; t < n_threads; ++t) ofs[t] << text[t];
-        // tallies in read order (proc_line :1241-1276), float sums like a -t 1 run
-        for (size_t i = 0; i < n; ++i) {
-            const lmat_read_result& r = res[i];
-            if (r.status == LMAT_ST_SHORT_LEN || r.status == LMAT_ST_SHORT_VALID) nomatch_merge[0] += 1;
-            else if (r.status == LMAT_ST_NODBHITS || r.status == LMAT_ST_SILENT) nomatch_merge[1] += 1;
-            else if (r.status != LMAT_ST_PHIX && r.match_type == LMAT_MT_NOMATCH) nomatch_merge[1] += 1;
-            else if (r.call_score >= min_score) {
-                if (merge_count.find(r.call_tid) == merge_count.end()) { merge_count[r.call_tid] = 1; merge_score[r.call_tid] = r.call_score; }
-                else { merge_count[r.call_tid] += 1; merge_score[r.call_tid] += r.call_score; }
-            } else if (r.call_score < min_score) nomatch_merge[2] += 1;
-        }
+        if (failed) break;
+        t_gpu += secs(tp1, now());
+        classified.push(std::move(w));
     }
+    if (failed) parsed.close();
+    classified.close();
+    reader.join();
+    writer.join();
+    if (failed) return fail("classify");
+    if (getenv("LMAT_CLI_TIMING"))
+        std::cerr << "[read_label] stage busy time: parse " << t_parse << " s, upload+classify+fetch " << t_gpu << " s, format " << t_fmt
+                  << " s, write " << t_write << " s, tally " << t_tally << " s" << std::endl;
     for (auto& o : ofs) o.close();
+    if (getenv("LMAT_CLI_TIMING"))
+        std::cerr << "[read_label] parse " << t_parse << " s, upload+classify+fetch " << t_gpu << " s, format " << t_fmt << " s, write "
+                  << t_write << " s, tally " << t_tally << " s" << std::endl;
     std::cout << "Finished classifing reads, doing final steps sequentially..." << std::endl;
 
     // names for the called taxids from the -u file (:1812-1835)

@@ -32,7 +32,7 @@ def main():
                "-l", "0", "-b", "1.0", "-e", info["depth"], "-t", str(a.threads), "-i", info["fasta"], "-d", img,
                "-c", info["tree"], "-o", os.path.join(d, "out")] + extra
         t0 = time.time()
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, LMAT_CLI_TIMING="1"))
         wall = time.time() - t0
         if p.returncode != 0:
             print(p.stdout[-2000:], file=sys.stderr)
@@ -40,7 +40,8 @@ def main():
         m = re.search(r"Total query time: ([0-9.eE+-]+) sec", p.stdout)
         q = float(m.group(1)) if m else None
         size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("out") and f.endswith(".out"))
-        out["runs"].append({"flags": label, "query_s": q, "wall_s": round(wall, 2), "reads_per_s_query": round(info["n_reads"] / q) if q else None,
+        tm = re.search(r"\[read_label\] (.*)", p.stdout)
+        out["runs"].append({"flags": label, "split": tm.group(1) if tm else None, "query_s": q, "wall_s": round(wall, 2), "reads_per_s_query": round(info["n_reads"] / q) if q else None,
                             "reads_per_s_wall": round(info["n_reads"] / wall), "out_bytes": size})
     print(json.dumps(out))
 

@@ -169,3 +169,27 @@ int main() {
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
     assert int(r.stdout.split()[0]) > 1e8
+
+
+def test_float_text_matches_printf_g():
+    """The .out writer formats floats with std::to_chars(general, 6); it must be printf's "%g" (what the
+    reference's operator<<(float) prints) for every value: random bit patterns, score-like fractions, edge cases."""
+    import struct
+    import subprocess
+    exe = os.path.join(ROOT, "lmat_amd", "csrc", "fmt_check")
+    rng = np.random.default_rng(7)
+    bits = list(rng.integers(0, 2**32, size=200000, dtype=np.uint64).astype(np.uint32))
+    fr = [np.float32(a) / np.float32(b) for b in range(1, 140) for a in range(0, b + 1)]
+    fr += [np.float32(x) for x in (0.0, -0.0, 1.0, 1e-5, 9.99999e-5, 1e-4, 123456.5, 999999.5, 999999.4, 1e6, 1.5e-45, 3.4e38, -10000.0,
+                                   0.0009999995, 0.001, 99999.95, 0.5, 2.5, 1234565.0, 0.1234565)]
+    bits += [np.frombuffer(np.float32(x).tobytes(), dtype=np.uint32)[0] for x in fr]
+    inp = "".join("%08x\n" % int(b) for b in bits)
+    got = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.split("\n")[:-1]
+    assert len(got) == len(bits)
+    for b, g in zip(bits, got):
+        f = struct.unpack("<f", struct.pack("<I", int(b)))[0]
+        want = "%g" % f
+        if f != f:  # NaN: sign spelling is irrelevant to the path (scores are never NaN)
+            assert "nan" in g
+            continue
+        assert g == want, (hex(int(b)), g, want)
