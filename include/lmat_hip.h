@@ -67,7 +67,7 @@ typedef struct {
     float call_score;
     uint32_t cand_off;     /* first candidate of this read in the cands array   */
     uint32_t n_cand;       /* candidates to print, best first                   */
-    int32_t bin_sel;       /* GC decile (read_label.cpp:1205-1206); null-model input */
+    int32_t bin_sel;       /* GC decile (read_label.cpp:1205-1206), the null-model input: 0 unless null models are loaded */
 } lmat_read_result;
 
 typedef struct {

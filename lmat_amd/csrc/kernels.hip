@@ -833,6 +833,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     for (int c = 0; c < (CACHE ? CH : 1); ++c) {
         if (CACHE) { kreg[c] = 0; hreg[c] = 0; okm[c] = 0; }
     }
+    const bool want_gc = A.nm.active != 0;
     auto pass1_chunk = [&](uint32_t p0, uint64_t& km_out, uint32_t& h_out, uint64_t& V_out) {
         const uint32_t p = p0 + lane;
         uint64_t km = 0;
@@ -842,20 +843,22 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         uint32_t h = 0;
         if (ok) h = lds_min_insert(hv, L::H - 1, km, p);
         // bases covered by at least one valid k-mer (read_label.cpp:987-1008): base b is covered
-        // iff some window start in [b-k+1, b] is valid
-        uint64_t lo = prevV, hi = V;
-        int span = 1;
-        while (span * 2 <= k) { spread_left(lo, hi, span); span *= 2; }
-        if (k - span > 0) spread_left(lo, hi, k - span);
-        bool isgc = false;
-        if (p < len) {
-            const uint32_t code = (codes[p >> 4] >> (2 * (p & 15))) & 3u;
-            isgc = code == 1 || code == 2;
+        // iff some window start in [b-k+1, b] is valid.  Only the null-model scores consume the GC decile.
+        if (want_gc) {
+            uint64_t lo = prevV, hi = V;
+            int span = 1;
+            while (span * 2 <= k) { spread_left(lo, hi, span); span *= 2; }
+            if (k - span > 0) spread_left(lo, hi, k - span);
+            bool isgc = false;
+            if (p < len) {
+                const uint32_t code = (codes[p >> 4] >> (2 * (p & 15))) & 3u;
+                isgc = code == 1 || code == 2;
+            }
+            const bool covered = (hi >> lane) & 1ull;
+            gc += popc64(__ballot(covered && isgc));
+            tot += popc64(hi);
+            prevV = V;
         }
-        const bool covered = (hi >> lane) & 1ull;
-        gc += popc64(__ballot(covered && isgc));
-        tot += popc64(hi);
-        prevV = V;
         km_out = km; h_out = h; V_out = V;
     };
     if (CACHE) {
