@@ -1505,7 +1505,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         GAS lmat_cand* cout_ = nullptr;
         if (!done) {
             if (A.cands) {
-                const uint32_t reserve = A.prm.prn_all ? nT : (uint32_t)L::LIN;
+                const uint32_t reserve = A.prm.prn_all ? nT : (uint32_t)nlin;  // -p: the candidates; else the lineage as built (:917-927)
                 coff = G_ADD(&g_cursor[0], reserve);
                 if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
                 else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
@@ -1620,7 +1620,7 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
         }
         GAS lmat_cand* cout_ = nullptr;
         if (A.cands) {
-            const uint32_t reserve = A.prm.prn_all ? (uint32_t)nT : (uint32_t)LIN;
+            const uint32_t reserve = A.prm.prn_all ? (uint32_t)nT : (uint32_t)nlin;  // -p: the candidates; else the lineage as built
             coff = G_ADD(&g_cursor[0], reserve);
             if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
             else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
