@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(64) void k4_lds_kernel(ClassifyArgs A) {
         const uint64_t it = ((const GAS uint32_t*)A.k4_small)[i];
         if (!k4_read<kK4SmallT, kK4SmallLin, false>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, nullptr, nullptr, nullptr,
                                                     lin, true))
-            ((GAS uint32_t*)A.k4_large)[G_ADD(&g_cursor[5], 1u)] = (uint32_t)it;  // lineage longer than the LDS block: scratch kernel
+            ((GAS uint32_t*)A.k4_bail)[G_ADD(&g_cursor[6], 1u)] = (uint32_t)it;  // lineage longer than the LDS block: scratch kernel, last launch
     }
 }
 
@@ -1703,10 +1703,11 @@ template <bool NM>
 __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     constexpr int LIN = kK4T + 72;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
-    const uint64_t n = *(const GAS uint32_t*)(g_cursor + 5);
+    const uint64_t n = *(const GAS uint32_t*)(g_cursor + A.k4_slot);  // 5: the large-table list, 6: reads the LDS kernel passed on
+    const GAS uint32_t* list = (const GAS uint32_t*)(A.k4_slot == 5 ? A.k4_large : A.k4_bail);
     const uint64_t stride = (uint64_t)gridDim.x * 64;
     for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
-        const uint64_t it = ((const GAS uint32_t*)A.k4_large)[i];
+        const uint64_t it = list[i];
         uint16_t reg[kK4T], cnt[kK4T], dep[kK4T], tin[kK4T], tout[kK4T], ord[kK4T];
         uint8_t sflags[kK4T], nm_cl[NM ? kK4T : 1];
         float score[kK4T], score0[NM ? kK4T : 1], nm_rp[NM ? kK4T : 1];
@@ -1864,11 +1865,15 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
     gather_bench_kernel<<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
 }
 
-void launch_k4(const ClassifyArgs& a, hipStream_t stream) {
+// The LDS kernel (5 waves per CU, LDS-bound) and the scratch kernel (64 VGPRs, latency-bound on HBM) fit a CU side by
+// side, so they run concurrently on two streams; `joined` is recorded when both are done.
+void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipEvent_t forked, hipEvent_t joined) {
     uint64_t blocks = (a.count + 4095) / 4096;  // a wave takes 1024 reads per pass
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     k4_compact_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(a);
+    hipEventRecord(forked, stream);
+    hipStreamWaitEvent(stream2, forked, 0);
     constexpr int lds_bytes = kK4SmallStride * 4 * 64;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1876,13 +1881,20 @@ void launch_k4(const ClassifyArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     uint64_t waves = (a.count + 63) / 64;
+    uint64_t g2 = waves < 256 * 32 ? waves : 256 * 32;
+    if (g2 < 1) g2 = 1;
+    ClassifyArgs b = a;
+    b.k4_slot = 5;
+    if (a.nm.active) k4_kernel<true><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+    else k4_kernel<false><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+    hipEventRecord(joined, stream2);
     uint64_t g1 = waves < 256 * 5 ? waves : 256 * 5;  // 5 blocks of 31.25 KB fit a CU's LDS
     if (g1 < 1) g1 = 1;
     k4_lds_kernel<<<dim3((unsigned)g1), dim3(64), lds_bytes, stream>>>(a);
-    uint64_t g2 = waves < 256 * 32 ? waves : 256 * 32;
-    if (g2 < 1) g2 = 1;
-    if (a.nm.active) k4_kernel<true><<<dim3((unsigned)g2), dim3(64), 0, stream>>>(a);
-    else k4_kernel<false><<<dim3((unsigned)g2), dim3(64), 0, stream>>>(a);
+    hipStreamWaitEvent(stream, joined, 0);
+    b.k4_slot = 6;  // the few reads whose lineage outgrew the LDS block
+    if (a.nm.active) k4_kernel<true><<<dim3(64), dim3(64), 0, stream>>>(b);
+    else k4_kernel<false><<<dim3(64), dim3(64), 0, stream>>>(b);
 }
 
 template <int U, int T, int E, bool INK4, bool PERM>

@@ -103,10 +103,13 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_gscratch};
+                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch};
     for (void* p : ptrs)
         if (p) hipFree(p);
     free_null_models(c);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c->ingest;
     delete c;
@@ -603,6 +606,9 @@ static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
         c->d_k4small = c->d_k4large = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_k4small, count * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_k4large, count * sizeof(uint32_t)));
+        if (c->d_k4bail) hipFree(c->d_k4bail);
+        c->d_k4bail = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_k4bail, count * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_ovf, count * sizeof(uint32_t)));
         if (c->d_ovf2) hipFree(c->d_ovf2);
         c->d_ovf2 = nullptr;
@@ -644,6 +650,8 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.gscratch = nullptr;
     a.k4_small = c->d_k4small;
     a.k4_large = c->d_k4large;
+    a.k4_bail = c->d_k4bail;
+    a.k4_slot = 5;
     a.nm = c->nm;
     return a;
 }
@@ -678,7 +686,14 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         HIPCHK(c, hipEventRecord(e2, c->stream));
         c->pending_events.push_back(std::make_pair(e0, e1));
     }
-    if (a.prm.stop_after == 0) launch_k4(a, c->stream);  // score + LCA decision, one lane per read
+    if (a.prm.stop_after == 0) {  // score + LCA decision, one lane per read
+        if (!c->stream2) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        launch_k4(a, c->stream, c->stream2, c->ev_fork, c->ev_join);
+    }
     {   // reads that exceeded the fast class (length, taxids, list elements), listed on the device: the large LDS class,
         // or directly the global-memory class when the batch holds reads beyond 2067 bp
         ClassifyArgs b = a;

@@ -124,6 +124,9 @@ struct lmat_ctx {
     unsigned char* d_gscratch = nullptr;  // tables of the global-memory class, allocated on first use
     uint32_t* d_k4small = nullptr; // index lists of the reads awaiting K4 (k4_compact_kernel)
     uint32_t* d_k4large = nullptr;
+    uint32_t* d_k4bail = nullptr;
+    hipStream_t stream2 = nullptr;  // the scratch K4 kernel runs beside the LDS one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     lmat::NullModelDev nm;         // device pointers owned by the context
     std::vector<void*> nm_allocs;
     uint64_t ovf_cap = 0;
