@@ -181,6 +181,19 @@ void* lmat_counts_device_ptr(lmat_ctx* ctx);
 int lmat_counts_get(lmat_ctx* ctx, uint32_t* tid32, uint64_t* count, double* score, uint32_t cap, uint32_t* n_nonzero,
                     uint64_t nomatch3[3]);
 
+/* ---- rand_read_label: the null-model generator (src/rand_read_label.cpp) on the same kernels -----------
+ * Replaces its proc_line/construct_labels (:185-213, :372-398) over src/rkmer.hpp's retrieve_kmer_labels, which is
+ * read_label's without the human folding.  Per (taxid, GC bucket): the largest fraction label_prob =
+ * count / valid_kmers over the reads given, and the number of reads that hit the taxid -- the two columns of
+ * the .rand_lst file (:741-754).  lmat_rand_mode(ctx, 1) before lmat_db_finalize; lmat_rand_reset sizes and
+ * clears the tables; lmat_rand_label adds a range of reads, gc_bucket[i] (host) being the bucket of read
+ * first + i; lmat_rand_get returns the rows with any hit, ascending taxid, row-major [n_rows][n_buckets]
+ * (call with cap 0 for the row count). */
+int lmat_rand_mode(lmat_ctx* ctx, int on);
+int lmat_rand_reset(lmat_ctx* ctx, uint32_t n_buckets);
+int lmat_rand_label(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count, const uint8_t* gc_bucket);
+int lmat_rand_get(lmat_ctx* ctx, uint32_t* tid32, float* max_prob, uint32_t* count, uint32_t cap, uint32_t* n_rows);
+
 /* ---- GPU-free ingest (the make_db_image tool; also usable without any device) ----------------------
  * Same parsing and options as above, producing the canonical (k-mer, 16-bit taxid list) form;
  * lmat_ingest_lookup returns the stored list of one k-mer (16-bit DB ids, stored order; 0 = absent). */

@@ -72,6 +72,10 @@ def load_library(path: str | None = None):
         "lmat_ingest_lookup": (i32, [vp, u64, vp, i32]),
         "lmat_db_from_ingest": (i32, [vp, vp, u64]),
         "lmat_set_label_modes": (i32, [vp, i32, i32, cp]),
+        "lmat_rand_mode": (i32, [vp, i32]),
+        "lmat_rand_reset": (i32, [vp, u32]),
+        "lmat_rand_label": (i32, [vp, vp, u64, u64, vp]),
+        "lmat_rand_get": (i32, [vp, vp, vp, vp, u32, P(u32)]),
         "lmat_nullmodel_load": (i32, [vp, cp]),
         "lmat_nullmodel_clear": (i32, [vp]),
         "lmat_db_kmer_length": (i32, [vp]),
@@ -109,7 +113,7 @@ def load_library(path: str | None = None):
 
 EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
             "lmat_db_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
-            "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create", "lmat_ingest_idmap_from_tree",
+            "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create", "lmat_ingest_idmap_from_tree", "lmat_rand_mode", "lmat_rand_reset", "lmat_rand_label", "lmat_rand_get",
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
             "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
             "lmat_ingest_lookup", "lmat_db_from_ingest", "lmat_nullmodel_load", "lmat_nullmodel_clear", "lmat_set_label_modes",
@@ -247,6 +251,31 @@ class Engine:
     def set_label_modes(self, permissive=False, tid_cutoff=0, rank_map=None):
         """-s / -g N -m ranks; call before build_db / load_image."""
         self._chk(self.lib.lmat_set_label_modes(self.ctx, int(permissive), tid_cutoff, rank_map.encode() if rank_map else None))
+
+    # rand_read_label (null-model generation) -------------------------------------
+    def rand_mode(self, on=True):
+        self._chk(self.lib.lmat_rand_mode(self.ctx, int(on)))
+
+    def rand_reset(self, n_buckets=10):
+        self._chk(self.lib.lmat_rand_reset(self.ctx, n_buckets))
+        self._rand_nb = n_buckets
+
+    def rand_label(self, reads, gc_bucket, first=0, count=None):
+        n = len(reads) - first if count is None else count
+        gb = np.ascontiguousarray(gc_bucket, dtype=np.uint8)
+        assert gb.size == n
+        self._chk(self.lib.lmat_rand_label(self.ctx, reads.h, first, n, _ptr(gb)))
+
+    def rand_table(self):
+        """-> {taxid: ([max label_prob per bucket], [hit count per bucket])}"""
+        n = C.c_uint32(0)
+        self._chk(self.lib.lmat_rand_get(self.ctx, None, None, None, 0, C.byref(n)))
+        rows, nb = int(n.value), self._rand_nb
+        tid = np.zeros(max(rows, 1), dtype=np.uint32)
+        mx = np.zeros((max(rows, 1), nb), dtype=np.float32)
+        ct = np.zeros((max(rows, 1), nb), dtype=np.uint32)
+        self._chk(self.lib.lmat_rand_get(self.ctx, _ptr(tid), _ptr(mx), _ptr(ct), rows, C.byref(n)))
+        return {int(tid[i]): (mx[i].copy(), ct[i].copy()) for i in range(rows)}
 
     def load_null_models(self, list_fn):
         """-n: null-model list file (gz tables resolved against $LMAT_DIR like the reference)."""

@@ -1405,6 +1405,19 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         return;
     }
     if (A.prm.stop_after == 6) { if (lane == 0) { emit(250, nT); } return; }
+    if (A.rand_max) {  // rand_read_label: proc_line + construct_labels of src/rand_read_label.cpp:185-213,372-398
+        const uint32_t gcb = ((const GAS uint8_t*)A.rand_gc)[r - A.result_base];
+        GAS uint32_t* rmax = (GAS uint32_t*)A.rand_max;
+        GAS uint32_t* rcnt = (GAS uint32_t*)A.rand_cnt;
+        for (uint32_t s = lane; s < nT; s += 64) {
+            const float label_prob = (float)cnt[s] / (float)valid_kmers;
+            const size_t at = (size_t)reg[s] * A.rand_nb + gcb;
+            __hip_atomic_fetch_max(&rmax[at], __float_as_uint(label_prob), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // non-negative floats order like their bits
+            G_ADD(&rcnt[at], 1u);
+        }
+        if (lane == 0) emit(LMAT_ST_SILENT, nT);
+        return;
+    }
     RELANE();
     cand &= 0xFFFF;  // uint16_t cand_kmer_cnt (:699)
     // ---- construct_labels early exits (:727-733): nothing is written (quirk Q1), tallied NoDbHits

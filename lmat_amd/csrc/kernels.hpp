@@ -26,6 +26,12 @@ struct ClassifyArgs {
     uint32_t* k4_large;        // read indices awaiting K4, large tables (count in cursor[5])
     uint32_t* k4_bail;         // reads the LDS K4 kernel could not hold after all (count in cursor[6])
     uint32_t k4_slot;          // which of the two lists a k4_kernel launch takes (5 or 6)
+    // rand_read_label mode (null-model generation): per (taxid, GC bucket) the largest k-mer fraction over the reads and
+    // the number of reads that hit the taxid; the decision step is skipped
+    uint32_t* rand_max;        // [n_ids][rand_nb] float bits, or null
+    uint32_t* rand_cnt;        // [n_ids][rand_nb]
+    const uint8_t* rand_gc;    // GC bucket of read r - result_base
+    uint32_t rand_nb;
     unsigned char* gscratch;   // per-workgroup tables of the global-memory class (reads beyond the LDS classes), or null
     NullModelDev nm;           // -n null models (active == 0: scores are plain k-mer fractions)
 };

@@ -103,7 +103,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch};
+                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
     for (void* p : ptrs)
         if (p) hipFree(p);
     free_null_models(c);
@@ -648,6 +648,11 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.count_ptr = nullptr;
     a.k4buf = c->d_k4buf;
     a.gscratch = nullptr;
+    a.rand_max = nullptr;
+    a.rand_cnt = nullptr;
+    a.rand_gc = nullptr;
+    a.rand_nb = 0;
+    if (c->rand_launch) { a.rand_max = c->d_rand_max; a.rand_cnt = c->d_rand_cnt; a.rand_gc = c->d_rand_gc; a.rand_nb = c->rand_nb; }
     a.k4_small = c->d_k4small;
     a.k4_large = c->d_k4large;
     a.k4_bail = c->d_k4bail;
@@ -806,6 +811,83 @@ int lmat_set_label_modes(lmat_ctx* c, int permissive, int tid_cutoff, const char
         while (fscanf(f, "%d%d", &s, &d) > 0) c->rt_rank_map[(uint32_t)s] = (uint32_t)d;
         fclose(f);
     }
+    return LMAT_OK;
+}
+
+// ---- rand_read_label (src/rand_read_label.cpp): the null-model generator on the same kernels ------------------
+int lmat_rand_mode(lmat_ctx* c, int on) {
+    if (!c) return LMAT_E_ARG;
+    if (c->db_ready) return set_err(c, LMAT_E_ARG, "rand mode shapes the database records: set it before lmat_db_finalize");
+    c->rand_mode = on ? 1 : 0;
+    return LMAT_OK;
+}
+int lmat_rand_reset(lmat_ctx* c, uint32_t n_buckets) {
+    if (!c || !n_buckets || n_buckets > 255) return LMAT_E_ARG;
+    if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy first");
+    hipSetDevice(c->device);
+    if (c->d_rand_max) { hipFree(c->d_rand_max); c->d_rand_max = nullptr; }
+    if (c->d_rand_cnt) { hipFree(c->d_rand_cnt); c->d_rand_cnt = nullptr; }
+    const size_t bytes = (size_t)c->dev.n_ids * n_buckets * 4;
+    HIPCHK(c, hipMalloc((void**)&c->d_rand_max, bytes));
+    HIPCHK(c, hipMalloc((void**)&c->d_rand_cnt, bytes));
+    HIPCHK(c, hipMemset(c->d_rand_max, 0, bytes));
+    HIPCHK(c, hipMemset(c->d_rand_cnt, 0, bytes));
+    c->rand_nb = n_buckets;
+    return LMAT_OK;
+}
+int lmat_rand_label(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, const uint8_t* gc_bucket) {
+    if (!c || !reads || (count && !gc_bucket)) return LMAT_E_ARG;
+    if (!c->rand_mode) return set_err(c, LMAT_E_ARG, "lmat_rand_mode(ctx, 1) before the database is finalized");
+    if (!c->d_rand_max) return set_err(c, LMAT_E_ARG, "lmat_rand_reset first");
+    if (!count) return LMAT_OK;
+    hipSetDevice(c->device);
+    for (uint64_t i = 0; i < count; ++i)
+        if (gc_bucket[i] >= c->rand_nb) return set_err(c, LMAT_E_ARG, "GC bucket out of range");
+    if (count > c->rand_gc_cap) {
+        if (c->d_rand_gc) hipFree(c->d_rand_gc);
+        c->d_rand_gc = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_rand_gc, count));
+        c->rand_gc_cap = count;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_rand_gc, gc_bucket, count, hipMemcpyHostToDevice, c->stream));
+    const lmat_params keep = c->params;
+    c->params.min_kmer = 1;      // "if (valid_kmers > 0)", rand_read_label.cpp:382
+    c->params.min_fnd_kmer = 0;
+    c->rand_launch = true;
+    int rc = run_classify(c, reads, first, count, false, 0, false);
+    c->rand_launch = false;
+    c->params = keep;
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t cur[2];
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
+    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
+    return LMAT_OK;
+}
+int lmat_rand_get(lmat_ctx* c, uint32_t* tid32, float* max_prob, uint32_t* cnt, uint32_t cap, uint32_t* n_rows) {
+    if (!c || !n_rows) return LMAT_E_ARG;
+    if (!c->d_rand_max) return set_err(c, LMAT_E_ARG, "lmat_rand_reset first");
+    hipSetDevice(c->device);
+    const uint32_t nb = c->rand_nb, n_ids = c->dev.n_ids;
+    std::vector<uint32_t> mx((size_t)n_ids * nb), ct((size_t)n_ids * nb);
+    HIPCHK(c, hipMemcpy(mx.data(), c->d_rand_max, mx.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ct.data(), c->d_rand_cnt, ct.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    for (uint32_t i = 1; i < n_ids; ++i) {  // internal index order = ascending taxid = the std::map order of the output file
+        bool any = false;
+        for (uint32_t b = 0; b < nb; ++b) any |= ct[(size_t)i * nb + b] != 0;
+        if (!any) continue;
+        if (n < cap && tid32 && max_prob && cnt) {
+            tid32[n] = c->tax.tid32[i];
+            for (uint32_t b = 0; b < nb; ++b) {
+                memcpy(&max_prob[(size_t)n * nb + b], &mx[(size_t)i * nb + b], 4);
+                cnt[(size_t)n * nb + b] = ct[(size_t)i * nb + b];
+            }
+        }
+        ++n;
+    }
+    *n_rows = n;
     return LMAT_OK;
 }
 

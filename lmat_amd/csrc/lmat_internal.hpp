@@ -105,6 +105,13 @@ struct lmat_ctx {
     int rt_tid_cut = 0;                                  // -g: run-time pruning threshold (TaxNodeStat.hpp:76)
     std::unordered_map<uint32_t, uint32_t> rt_rank_map;  // -m: taxid -> numeric rank (read_label.cpp:1547-1553)
     int permissive = 0;                                  // -s (gPERMISSIVE_MATCH)
+    int rand_mode = 0;                                   // list records as src/rkmer.hpp builds them (no human folding)
+    uint32_t* d_rand_max = nullptr;                      // rand_read_label tables [n_ids][rand_nb]
+    uint32_t* d_rand_cnt = nullptr;
+    uint8_t* d_rand_gc = nullptr;
+    uint64_t rand_gc_cap = 0;
+    uint32_t rand_nb = 0;
+    bool rand_launch = false;
     // synthetic generator state
     uint32_t synth_branching[6] = {0, 0, 0, 0, 0, 0};
     uint32_t synth_n_species = 0, synth_strains_per_species = 0;

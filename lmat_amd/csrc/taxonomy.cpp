@@ -285,7 +285,7 @@ bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vecto
     unsigned dcnt = 0;
     for (size_t i = 0; i < seq.size(); ++i) {  // read_label.cpp:1031-1066
         uint32_t tid = seq[i];
-        if (is_human32(tid)) {
+        if (is_human32(tid) && !c->rand_mode) {  // rkmer.hpp:121-123 has no human folding
             if (seen_human) continue;
             tid = 9606;
             seen_human = true;

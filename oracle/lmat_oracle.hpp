@@ -507,6 +507,7 @@ struct Options {
     bool prn_read = true;        // -a turns off
     bool fastq = false;          // -q
     bool permissive = false;     // -s  gPERMISSIVE_MATCH
+    bool rand_mode = false;      // src/rkmer.hpp's retrieve_kmer_labels (rand_read_label): no human folding
     uint16_t max_count = 0xFFFF; // -g  run-time pruning threshold (uint16_t max_count = ~0, :1346)
     std::unordered_map<uint32_t, uint32_t> tid_rank_map;  // -m  (read_label.cpp:1547-1553)
 };
@@ -778,8 +779,10 @@ struct Classifier {
                 bool seen_human = false;
                 for (unsigned li = 0; li < seq.size(); ++li) {  // while(h->next()), read_label.cpp:1031-1066
                     tid_t tid = seq[li];
-                    if (is_human(tid) && seen_human) continue;
-                    else if (is_human(tid) && !seen_human) { tid = kHumanTid; seen_human = true; }
+                    if (!opt.rand_mode) {  // rkmer.hpp:121-123 has neither branch
+                        if (is_human(tid) && seen_human) continue;
+                        else if (is_human(tid) && !seen_human) { tid = kHumanTid; seen_human = true; }
+                    }
                     if (tid == 20999999 || bad_genome(tid)) continue;
                     uint16_t ng = taxid_count;
                     if (dcnt == 0) label_vec[pos].first = (int16_t)ng;  // int16 store of a u16 (quirk Q4)
@@ -1065,6 +1068,37 @@ struct Classifier {
             mtype = res.second;
         }
         return std::make_pair(best_guess, mtype);
+    }
+
+    // rand_read_label's proc_line + construct_labels (src/rand_read_label.cpp:372-398, 185-213): per taxid the number of
+    // positions whose set holds it, over valid_kmers; the table keeps the maximum and the number of reads per GC bucket
+    typedef std::map<tid_t, std::pair<std::vector<float>, std::vector<int>>> RandTable;
+    void rand_proc_line(const std::string& line, int k_size, unsigned gcbucket, unsigned num_gcbuckets, RandTable& tab) const {
+        const int ri_len = (int)line.length();
+        if (ri_len < k_size) return;
+        std::vector<label_info_t> label_vec(ri_len - k_size + 1, std::make_pair((int16_t)-1, tax_data_t()));
+        std::list<tid_t> taxid_lst;
+        hmap_t tax2idx, idx2tax;
+        const int valid_kmers = retrieve_kmer_labels(line.c_str(), ri_len, k_size, label_vec, taxid_lst, tax2idx, idx2tax, nullptr).first;
+        if (valid_kmers <= 0) return;
+        std::map<tid_t, int> cnt_tids;
+        for (unsigned pos = 0; pos < label_vec.size(); ++pos)
+            for (auto& el : label_vec[pos].second) cnt_tids[el.first] += 1;
+        for (auto& kv : cnt_tids) {
+            const float label_prob = (float)kv.second / (float)valid_kmers;
+            auto it = tab.find(kv.first);
+            if (it == tab.end()) {
+                std::vector<float> b(num_gcbuckets, 0.0f);
+                std::vector<int> c(num_gcbuckets, 0);
+                b[gcbucket] = label_prob;
+                c[gcbucket] = 1;
+                tab.insert(std::make_pair(kv.first, std::make_pair(b, c)));
+            } else {
+                const float cur = it->second.first[gcbucket];
+                it->second.first[gcbucket] = (cur < label_prob) ? label_prob : cur;
+                it->second.second[gcbucket] += 1;
+            }
+        }
     }
 
     // tally rule of proc_line, src/read_label.cpp:1248-1268

@@ -32,6 +32,28 @@ const char* orc_error(orc_ctx* c) { return c->err.c_str(); }
 int orc_set_build_options(orc_ctx* c, int tid_cutoff, const char* rank_map, const char* human, const char* adaptors) {
     return c->db.set_options(tid_cutoff, rank_map ? rank_map : "", human ? human : "", adaptors ? adaptors : "") ? 0 : -1;
 }
+// rand_read_label over the given reads: rows (ascending taxid) of max label_prob and hit count per GC bucket
+int orc_rand_label(orc_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, int k, const uint8_t* gc_bucket, uint32_t nb,
+                   uint32_t* tid, float* mx, int32_t* ct, uint32_t cap) {
+    Options o = c->opt;
+    o.rand_mode = true;
+    Classifier cls(c->tax, c->db, o, nullptr);
+    Classifier::RandTable tab;
+    for (uint64_t i = 0; i < n; ++i) {
+        std::string read((const char*)bases + off[i], (size_t)(off[i + 1] - off[i]));
+        cls.rand_proc_line(read, k, gc_bucket[i], nb, tab);
+    }
+    uint32_t r = 0;
+    for (auto& kv : tab) {
+        if (r < cap) {
+            tid[r] = kv.first;
+            for (uint32_t b = 0; b < nb; ++b) { mx[(size_t)r * nb + b] = kv.second.first[b]; ct[(size_t)r * nb + b] = kv.second.second[b]; }
+        }
+        ++r;
+    }
+    return (int)r;
+}
+
 int orc_set_label_modes(orc_ctx* c, int permissive, int tid_cutoff, const char* rank_map) {
     c->opt.permissive = permissive != 0;
     c->opt.max_count = tid_cutoff > 0 ? (uint16_t)tid_cutoff : 0xFFFF;

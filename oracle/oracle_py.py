@@ -52,6 +52,8 @@ def _load():
     L.orc_text.argtypes = [vp]
     L.orc_summaries_from_calls.restype = C.c_long
     L.orc_summaries_from_calls.argtypes = [vp, vp, vp, vp, C.c_long, i32, i32, vp, C.c_long, vp, C.c_long]
+    L.orc_rand_label.restype = i32
+    L.orc_rand_label.argtypes = [vp, vp, vp, u64, i32, vp, C.c_uint32, vp, vp, vp, C.c_uint32]
     L.orc_run_file.restype = C.c_long
     L.orc_run_file.argtypes = [vp, cp, i32, cp, vp, C.c_long, vp, C.c_long]
     return L
@@ -78,6 +80,19 @@ class Oracle:
     def set_label_modes(self, permissive=False, tid_cutoff=0, rank_map=None):
         if self.L.orc_set_label_modes(self.h, int(permissive), tid_cutoff, (rank_map or "").encode()) != 0:
             raise RuntimeError("oracle: cannot read rank map")
+
+    def rand_label(self, blob, off, k, gc_bucket, nb=10, cap=70000):
+        """rand_read_label over these reads -> {taxid: ([max label_prob per bucket], [hit count per bucket])}"""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        gb = np.ascontiguousarray(gc_bucket, dtype=np.uint8)
+        tid = np.zeros(cap, dtype=np.uint32)
+        mx = np.zeros((cap, nb), dtype=np.float32)
+        ct = np.zeros((cap, nb), dtype=np.int32)
+        n = self.L.orc_rand_label(self.h, blob.ctypes.data, off.ctypes.data, off.size - 1, k, gb.ctypes.data, nb, tid.ctypes.data,
+                                  mx.ctypes.data, ct.ctypes.data, cap)
+        assert 0 <= n <= cap
+        return {int(tid[i]): (mx[i].copy(), ct[i].copy()) for i in range(n)}
 
     def load_null_models(self, list_fn):
         if self.L.orc_load_null_models(self.h, list_fn.encode()) != 0:

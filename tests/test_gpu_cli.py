@@ -55,3 +55,50 @@ def test_cli_refuses_unsupported_and_missing_args(small_dataset, tmp_path):
     r = subprocess.run([EXE, "-f", ds["idmap"], "-e", ds["depth"], "-t", "1", "-i", ds["fasta"], "-d", ds["db"], "-c", ds["tree"],
                         "-o", str(tmp_path / "x"), "-n", "no_such_list.txt"], capture_output=True, text=True)
     assert r.returncode != 0 and "RandHits file list" in r.stderr
+
+
+def test_rand_read_label_cli(tmp_path):
+    """The null-model generator's command line: random reads in ten GC buckets against a 12-mer database (so random
+    reads do hit); the .rand_lst rows equal the oracle's restatement of rand_read_label on the dumped reads."""
+    import numpy as np
+    import oracle_py
+    from lmat_amd import synth
+    tax = synth.make_taxonomy((2, 2, 2, 2, 3, 3), specials=True)
+    p = synth.write_aux_files(str(tmp_path), tax)
+    genomes = synth.make_genomes(tax, 2000, 2002)
+    kmers, lists = synth.build_kmer_table(tax, genomes, 12)
+    p["db"] = os.path.join(str(tmp_path), "th.bin")
+    synth.write_taxhisto(p["db"], kmers, lists, 12)
+    out = os.path.join(str(tmp_path), "nm")
+    dump = os.path.join(str(tmp_path), "reads.fa")
+    exe = os.path.join(ROOT, "lmat_amd", "csrc", "rand_read_label")
+    r = subprocess.run([exe, "-d", p["db"], "-c", p["tree"], "-e", p["depth"], "-f", p["idmap"], "-w", p["rank"], "-t", "2", "-g", "1500",
+                        "-i", "80", "-o", out, "-S", "42", "-O", dump], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Total reads to evaluate: 3000" in r.stdout
+    reads, gc = [], []
+    for line in open(dump):
+        if line.startswith(">"):
+            gc.append(int(line.split("gc=")[1]))
+        else:
+            reads.append(line.strip())
+    assert len(reads) == 3000 and all(len(x) == 80 for x in reads)
+    # bucket b holds reads with b*10 .. b*10+9 percent G+C (genRandRead)
+    for x, b in zip(reads[:200], gc[:200]):
+        frac = sum(ch in "gc" for ch in x) / 80.0
+        assert b * 0.10 - 0.02 <= frac <= b * 0.10 + 0.10
+    bs = [x.encode() for x in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    orc = oracle_py.Oracle(p["tree"], p["depth"], p["rank"], p["idmap"])
+    orc.add_taxhisto(p["db"])
+    want = orc.rand_label(np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8), off, 12, np.array(gc, dtype=np.uint8))
+    orc.close()
+    rows = [l.split() for l in open(out + ".rand_lst")]
+    assert len(rows) == len(want) > 20
+    assert [int(x[0]) for x in rows] == sorted(want)
+    for x in rows:
+        mx, ct = want[int(x[0])]
+        assert len(x) == 21
+        for b in range(10):
+            assert x[1 + 2 * b] == "%g" % float(mx[b]) and int(x[2 + 2 * b]) == int(ct[b])

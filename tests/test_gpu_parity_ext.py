@@ -501,3 +501,36 @@ def test_long_reads_use_the_global_memory_class(tmp_path):
     assert ei.value.code == -4
     eng.close()
     orc.close()
+
+
+def test_rand_read_label_tables_match_oracle(tmp_path):
+    """rand_read_label (null-model generation): per (taxid, GC bucket) max label_prob and hit count over a read set,
+    engine vs the oracle's restatement of src/rand_read_label.cpp + src/rkmer.hpp (no human folding), bit for bit."""
+    from lmat_amd import Engine, Params, synth
+    import oracle_py
+    info = synth.generate_dataset(str(tmp_path), (2, 2, 2, 2, 3, 3), 3000, 3000, L=(100, 150, 150, 250))
+    reads = [l.rstrip("\n") for l in open(info["fasta"]) if not l.startswith(">")]
+    rng = np.random.default_rng(5)
+    reads += ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(500)]   # unrelated reads: mostly no hits
+    gc = rng.integers(0, 10, size=len(reads)).astype(np.uint8)
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(info["tree"], info["depth"], info["rank"], info["idmap"])
+    eng.rand_mode(True)
+    eng.build_db(info["db"], k=20)
+    eng.rand_reset(10)
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    half = len(reads) // 2
+    eng.rand_label(dr, gc[:half], 0, half)              # two calls accumulate
+    eng.rand_label(dr, gc[half:], half, len(reads) - half)
+    got = eng.rand_table()
+    orc = oracle_py.Oracle(info["tree"], info["depth"], info["rank"], info["idmap"])
+    orc.add_taxhisto(info["db"])
+    want = orc.rand_label(blob, off, 20, gc)
+    assert len(want) > 50 and set(got) == set(want)
+    for t in want:
+        assert (got[t][1] == want[t][1]).all(), t
+        assert (got[t][0].view(np.uint32) == want[t][0].view(np.uint32)).all(), t
+    # the human variants keep their own rows in this mode when they occur
+    eng.close()
+    orc.close()
