@@ -1729,24 +1729,25 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     }
 }
 
-// Random 64-byte bucket gather with the probe's access shape (8 lanes x 8 B per bucket, 8 wave-loads
-// in flight): the practical ceiling of K2 on this table, and a known byte count to calibrate
-// the FETCH_SIZE counter against.
+// Random 64-byte bucket gather with the probe's access shape (4 lanes x 16 B per bucket, 9 wave-loads = 144 buckets
+// in flight per wave): the practical ceiling of K2 on this table, and a known byte count to calibrate the
+// FETCH_SIZE counter against.
 __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __restrict__ slots, uint32_t nbuckets,
                                                           uint64_t probes_per_wave, uint64_t seed,
                                                           unsigned long long* sink) {
-    const int lane = threadIdx.x & 63, g = lane >> 3, sub = lane & 7;
+    const int lane = threadIdx.x & 63, g4 = lane >> 2, q4 = lane & 3;
+    const GAS u32x4* quarters = (const GAS u32x4*)slots;
     unsigned long long acc = 0;
     uint64_t ctr = (uint64_t)blockIdx.x * probes_per_wave;
-    for (uint64_t i = 0; i < probes_per_wave; i += 64) {
-        unsigned long long sl[8];
+    for (uint64_t i = 0; i < probes_per_wave; i += 144) {
+        u32x4 sl[9];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t b = bucket_of(seed + ctr + i + j * 8 + g, nbuckets);
-            sl[j] = slots[(uint64_t)b * kSlotsPerBucket + sub];
+        for (int j = 0; j < 9; ++j) {
+            const uint32_t b = bucket_of(seed + ctr + i + j * 16 + g4, nbuckets);
+            sl[j] = quarters[(uint64_t)b * 4 + q4];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += sl[j] >> 13;
+        for (int j = 0; j < 9; ++j) acc += (sl[j].x >> 13) + sl[j].w;
     }
     if (acc == 0x123456789ull) atomicAdd(sink, acc);
 }
@@ -1874,7 +1875,7 @@ void launch_gather_bench2(const uint64_t* slots, uint32_t nbuckets, uint32_t gri
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,
                          unsigned long long* sink, hipStream_t stream) {
     const int grid = 256 * 16;
-    const uint64_t per_wave = (n_probes / grid + 63) / 64 * 64;
+    const uint64_t per_wave = (n_probes / grid + 143) / 144 * 144;
     gather_bench_kernel<<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
 }
 

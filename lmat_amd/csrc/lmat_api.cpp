@@ -982,7 +982,7 @@ int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, 
     HIPCHK(c, hipEventElapsedTime(&t, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
     if (ms) *ms = t;
-    const uint64_t per_wave = (n_probes / 4096 + 63) / 64 * 64;
+    const uint64_t per_wave = (n_probes / 4096 + 143) / 144 * 144;
     if (bytes) *bytes = per_wave * 4096 * 64;
     return LMAT_OK;
 }

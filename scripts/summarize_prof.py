@@ -34,10 +34,10 @@ out = {
     "calibration": None, "pmc": pmc,
 }
 if gat:
-    known = (1 << 28) * 64
+    known = (((1 << 28) // 4096 + 143) // 144 * 144) * 4096 * 64  # lmat_gather_bench rounds the probes per wave up to 144
     meas = pmc["FETCH_SIZE"][gat[0]]["mean_KiB_per_dispatch"] * 1024
     out["calibration"] = {"kernel": gat[0], "known_bytes": known, "FETCH_SIZE_bytes": meas, "ratio": meas / known,
-                          "note": "random 64-B bucket gather, 8 lanes x 8 B: FETCH_SIZE x 1024 equals the byte count "
+                          "note": "random 64-B bucket gather, 4 lanes x 16 B (8 x 8 B up to r01e): FETCH_SIZE x 1024 equals the byte count "
                                   "(the x2 correction of the guide applies to 16-B/lane streaming reads, not to this shape)"}
 json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 json.dump({"hbm_bytes_per_launch": fetch + write, "from": f"profiles/{tag}_traffic.json"}, open("profiles/traffic_latest.json", "w"))
