@@ -1752,33 +1752,6 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
     if (acc == 0x123456789ull) atomicAdd(sink, acc);
 }
 
-// Variant of the gather microbenchmark with the classify kernel's probe structure: bucket indices staged in
-// LDS, `burst` wave-loads issued back to back, then consumed, `pad_lds` bytes of LDS per wave to set occupancy.
-__global__ __launch_bounds__(64) void gather_bench2_kernel(const uint64_t* __restrict__ slots_, uint32_t nbuckets,
-                                                           uint32_t bursts_per_wave, uint32_t burst, uint64_t seed,
-                                                           unsigned long long* sink) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* lb = (uint32_t*)smem;
-    const GAS uint64_t* slots = (const GAS uint64_t*)slots_;
-    const int lane = threadIdx.x & 63, g = lane >> 3, sub = lane & 7;
-    unsigned long long acc = 0;
-    uint64_t ctr = ((uint64_t)blockIdx.x * bursts_per_wave) * 256;
-    for (uint32_t it = 0; it < bursts_per_wave; ++it) {
-        for (uint32_t i = lane; i < burst * 8; i += 64) lb[i] = bucket_of(seed + ctr + i, nbuckets);
-        ctr += 256;
-        WSYNC();
-        unsigned long long sl[24];
-#pragma unroll
-        for (int j = 0; j < 24; ++j) {
-            sl[j] = (uint32_t)j < burst ? slots[(uint64_t)lb[j * 8 + g] * kSlotsPerBucket + sub] : 0ull;
-        }
-#pragma unroll
-        for (int j = 0; j < 24; ++j) acc += sl[j] >> 13;
-        WSYNC();
-    }
-    if (acc == 0x123456789ull) atomicAdd(sink, acc);
-}
-
 #pragma push_macro("WSYNC")
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
@@ -1864,12 +1837,6 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
     if (!n) return;
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tb, kmers, n, counts, tids,
                        stride);
-}
-
-void launch_gather_bench2(const uint64_t* slots, uint32_t nbuckets, uint32_t grid, uint32_t bursts_per_wave, uint32_t burst,
-                          uint32_t lds_bytes, uint64_t seed, unsigned long long* sink, hipStream_t stream) {
-    hipFuncSetAttribute((const void*)gather_bench2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    gather_bench2_kernel<<<dim3(grid), dim3(64), lds_bytes, stream>>>(slots, nbuckets, bursts_per_wave, burst, seed, sink);
 }
 
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,

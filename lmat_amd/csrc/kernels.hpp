@@ -60,12 +60,10 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
 void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipEvent_t forked, hipEvent_t joined);
 int classify_max_read_len();
 size_t classify_gmem_scratch_bytes();
-// issues ~n_probes random bucket reads (rounded up to 64 per wave x 4096 waves)
+// issues ~n_probes random bucket reads (rounded up to 144 per wave x 4096 waves)
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,
                          unsigned long long* sink, hipStream_t stream);
 
-void launch_gather_bench2(const uint64_t* slots, uint32_t nbuckets, uint32_t grid, uint32_t bursts_per_wave, uint32_t burst,
-                          uint32_t lds_bytes, uint64_t seed, unsigned long long* sink, hipStream_t stream);
 
 // host-callable copies of the synthetic genome functions (tests / oracle cross-checks)
 uint32_t synth_strain_base_host(uint64_t seed, uint32_t species, uint32_t strain_global, uint64_t pos);

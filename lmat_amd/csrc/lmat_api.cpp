@@ -988,26 +988,6 @@ int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, 
 }
 
 // experiment hook (not in the public header): burst-structured gather
-extern "C" int lmat_gather_bench2(lmat_ctx* c, uint32_t grid, uint32_t bursts_per_wave, uint32_t burst, uint32_t lds_bytes,
-                                  float* ms, uint64_t* bytes) {
-    if (!c || !c->db_ready || burst > 24) return LMAT_E_ARG;
-    hipSetDevice(c->device);
-    unsigned long long* sink = nullptr;
-    HIPCHK(c, hipMalloc((void**)&sink, 8));
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
-    HIPCHK(c, hipEventRecord(e0, c->stream));
-    launch_gather_bench2(c->dev.slots, c->dev.nbuckets, grid, bursts_per_wave, burst, lds_bytes, 99, sink, c->stream);
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    float t = 0;
-    HIPCHK(c, hipEventElapsedTime(&t, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
-    if (ms) *ms = t;
-    if (bytes) *bytes = (uint64_t)grid * bursts_per_wave * burst * 8 * 64;
-    return LMAT_OK;
-}
 
 int64_t lmat_format_out(const lmat_ctx* c, const lmat_read_result* results, uint64_t n, const lmat_cand* cands,
                         const uint8_t* bases, const uint64_t* off, int prn_read, uint64_t first_index, char* buf,
