@@ -95,7 +95,11 @@ int lmat_taxonomy_load_files(lmat_ctx* ctx, const char* tree_fn, const char* dep
  * TaxNodeStat::begin/next/taxid/taxidCount, src/kmerdb/TaxNodeStat.hpp:60,208,258,262)
  * by an open-addressed hash in HBM.  Ingest format = make_db_table's input
  * (tax_histo binary, SortedDb::add_data src/kmerdb/SortedDb.cpp:84-751, un-pruned path).
- * table_bytes == 0 sizes the table for a 0.8 load factor. */
+ * table_bytes == 0 sizes the table for a 0.8 load factor.
+ * n_kmers_hint or table_bytes non-zero: the table is allocated at once and the files stream through the insert
+ * kernel in chunks (only the distinct lists stay on the host); then n_kmers_hint must not be below the real
+ * count, the label / rand modes must be set before lmat_db_begin, and lmat_db_save_image is unavailable.
+ * Both zero: the k-mers are buffered on the host until lmat_db_finalize. */
 int lmat_db_begin(lmat_ctx* ctx, int k, uint64_t n_kmers_hint, uint64_t table_bytes);
 int lmat_db_add_taxhisto(lmat_ctx* ctx, const char* fn);
 int lmat_db_finalize(lmat_ctx* ctx);

@@ -232,10 +232,12 @@ class Engine:
         self._chk(self.lib.lmat_taxonomy_load_files(self.ctx, e(tree), e(depth), e(rank), e(idmap), e(plasmids)))
 
     def build_db(self, files, k=20, table_bytes=0, tid_cutoff=0, rank_map=None, human_kmers=None, adaptor_kmers=None,
-                 save_image=None):
-        """make_db_table's job: tax_histo files (+ its -g/-m, -j, -u options) -> device table."""
+                 save_image=None, n_kmers_hint=0):
+        """make_db_table's job: tax_histo files (+ its -g/-m, -j, -u options) -> device table.
+        With n_kmers_hint or table_bytes the table is sized up front and the files stream through the GPU insert
+        kernel in chunks (nothing but the distinct lists stays on the host; save_image is then unavailable)."""
         e = lambda s: s.encode() if s else None
-        self._chk(self.lib.lmat_db_begin(self.ctx, k, 0, table_bytes))
+        self._chk(self.lib.lmat_db_begin(self.ctx, k, n_kmers_hint, table_bytes))
         if tid_cutoff or human_kmers or adaptor_kmers:
             self._chk(self.lib.lmat_db_set_build_options(self.ctx, tid_cutoff, e(rank_map), e(human_kmers), e(adaptor_kmers), 0))
         for f in ([files] if isinstance(files, str) else files):

@@ -128,6 +128,7 @@ void Ingest::push(uint64_t kmer, const std::vector<uint16_t>& lst) {
     }
     kmers.push_back(kmer);
     payload.push_back(p);
+    if (flush && flush_every && kmers.size() >= flush_every && !flush(*this)) stream_failed = true;
 }
 
 bool Ingest::add_taxhisto(const char* fn) {
@@ -295,6 +296,40 @@ bool Ingest::load_image(const char* fn) {
     fclose(f);
     if (!ok) err = "malformed database image";
     else if (n) last_kmer = kmers.back();
+    return ok;
+}
+
+bool Ingest::load_image_streaming(const char* fn, uint64_t* n_kmers) {
+    FILE* f = fopen(fn, "rb");
+    if (!f) { err = std::string("cannot open image ") + fn; return false; }
+    char magic[8];
+    uint32_t kk;
+    uint64_t n = 0, nl = 0;
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "LMATIMG1", 8) == 0 && fread(&kk, 4, 1, f) == 1 &&
+              fread(&n, 8, 1, f) == 1 && fread(&nl, 8, 1, f) == 1;
+    const long base = 28;
+    if (ok) {
+        k = (int)kk;
+        ok = fseek(f, base + (long)(12 * n), SEEK_SET) == 0;  // the lists sit behind the two arrays
+        lists.resize(nl);
+        for (uint64_t i = 0; i < nl && ok; ++i) {
+            uint32_t m;
+            ok = fread(&m, 4, 1, f) == 1;
+            if (ok) { lists[i].resize(m); ok = m == 0 || fread(lists[i].data(), 2, m, f) == m; }
+        }
+    }
+    const uint64_t chunk = flush_every ? flush_every : (1ull << 24);
+    for (uint64_t s = 0; s < n && ok; s += chunk) {
+        const uint64_t m = std::min(chunk, n - s);
+        kmers.resize(m);
+        payload.resize(m);
+        ok = fseek(f, base + (long)(8 * s), SEEK_SET) == 0 && fread(kmers.data(), 8, m, f) == m &&
+             fseek(f, base + (long)(8 * n + 4 * s), SEEK_SET) == 0 && fread(payload.data(), 4, m, f) == m;
+        if (ok && flush) ok = flush(*this);
+    }
+    fclose(f);
+    if (!ok && err.empty()) err = "malformed database image";
+    if (n_kmers) *n_kmers = n;
     return ok;
 }
 

@@ -11,6 +11,7 @@
 #pragma once
 #include <stdint.h>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -44,6 +45,12 @@ struct Ingest {
     // counters printed by add_data
     uint64_t singletons = 0, doubles = 0, reduced_kmers = 0, cut_kmers = 0, new_human = 0, matched_in = 0, new_isect = 0;
     std::string err;
+    // streaming: when set, called whenever flush_every k-mers have accumulated (and by the owner at the end); it consumes
+    // kmers/payload (the callee clears them), lists keep growing.  lookup()/save_image() then see only the unflushed tail.
+    std::function<bool(Ingest&)> flush;
+    size_t flush_every = 0;
+    uint64_t flushed = 0;
+    bool stream_failed = false;
 
     ~Ingest() { if (human_fp) fclose(human_fp); }
     bool load_idmap(const char* fn);
@@ -54,6 +61,8 @@ struct Ingest {
     bool add_taxhisto(const char* fn);
     bool save_image(const char* fn) const;
     bool load_image(const char* fn);
+    // image -> flush callback in chunks of flush_every k-mers (lists are read first); nothing is kept in memory
+    bool load_image_streaming(const char* fn, uint64_t* n_kmers);
     // stored list of a k-mer (16-bit ids, stored order); returns false when absent
     bool lookup(uint64_t kmer, std::vector<uint16_t>& out) const;
 

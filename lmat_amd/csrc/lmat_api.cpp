@@ -78,6 +78,10 @@ static KernelParams kparams(const lmat_params& p) {
 
 extern "C" {
 
+static void sb_free(lmat_ctx* c);
+static int sb_begin(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k);
+static int sb_push(lmat_ctx* c, Ingest& B);
+
 int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out) {
     if (!out) return LMAT_E_ARG;
     *out = nullptr;
@@ -106,6 +110,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
                     c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    sb_free(c);
     free_null_models(c);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -185,8 +190,16 @@ int lmat_db_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_byte
     c->ingest->k = k;
     c->ingest->br = c->tax.br;
     c->ingest_table_bytes = table_bytes;
-    if (n_kmers_hint) { c->ingest->kmers.reserve(n_kmers_hint); c->ingest->payload.reserve(n_kmers_hint); }
     c->db_ready = false;
+    sb_free(c);
+    if (n_kmers_hint || table_bytes) {
+        // the caller sized the table: stream -- every 16 M k-mers go straight into the GPU table and leave the host
+        int rc = sb_begin(c, n_kmers_hint, table_bytes, k);
+        if (rc) return rc;
+        c->ingest->flush_every = 1ull << 24;
+        if (const char* e = getenv("LMAT_INGEST_CHUNK")) c->ingest->flush_every = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        c->ingest->flush = [c](Ingest& B) { return sb_push(c, B) == LMAT_OK; };
+    }
     return LMAT_OK;
 }
 
@@ -205,12 +218,14 @@ int lmat_db_add_taxhisto(lmat_ctx* c, const char* fn) {
         const bool tax = c->ingest->err.compare(0, 3, "bad") == 0;
         return set_err(c, tax ? LMAT_E_TAXONOMY : LMAT_E_IO, c->ingest->err);
     }
+    if (c->ingest->stream_failed) return c->last_rc ? c->last_rc : LMAT_E_DEVICE;  // the message is already set
     return LMAT_OK;
 }
 
 int lmat_db_save_image(lmat_ctx* c, const char* fn) {
     if (!c || !fn) return LMAT_E_ARG;
     if (!c->ingest) return set_err(c, LMAT_E_ARG, "no open ingest: save the image between lmat_db_begin and lmat_db_finalize");
+    if (c->ingest->flush) return set_err(c, LMAT_E_ARG, "a streamed build (n_kmers_hint / table_bytes given) keeps no copy to save: use make_db_image");
     return c->ingest->save_image(fn) ? LMAT_OK : set_err(c, LMAT_E_IO, std::string("cannot write ") + fn);
 }
 
@@ -221,8 +236,26 @@ int lmat_db_load_image(lmat_ctx* c, const char* fn, uint64_t table_bytes) {
     c->ingest = new Ingest();
     c->ingest_table_bytes = table_bytes;
     c->db_ready = false;
-    if (!c->ingest->load_image(fn)) return set_err(c, LMAT_E_IO, c->ingest->err);
-    if (c->ingest->k < 1 || c->ingest->k > 20) return set_err(c, LMAT_E_IO, "image holds an unsupported k-mer length");
+    sb_free(c);
+    {   // header first: the table is sized from the image's k-mer count, then the arrays stream through in chunks
+        FILE* f = fopen(fn, "rb");
+        char magic[8];
+        uint32_t kk = 0;
+        uint64_t n = 0;
+        const bool ok = f && fread(magic, 8, 1, f) == 1 && memcmp(magic, "LMATIMG1", 8) == 0 && fread(&kk, 4, 1, f) == 1 && fread(&n, 8, 1, f) == 1;
+        if (f) fclose(f);
+        if (!ok) return set_err(c, LMAT_E_IO, std::string("cannot read database image ") + fn);
+        if (kk < 1 || kk > 20) return set_err(c, LMAT_E_IO, "image holds an unsupported k-mer length");
+        int rc = sb_begin(c, n, table_bytes, (int)kk);
+        if (rc) return rc;
+    }
+    c->ingest->flush_every = 1ull << 24;
+    if (const char* e = getenv("LMAT_INGEST_CHUNK")) c->ingest->flush_every = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    c->ingest->flush = [c](Ingest& B) { return sb_push(c, B) == LMAT_OK; };
+    if (!c->ingest->load_image_streaming(fn, nullptr)) {
+        sb_free(c);
+        return c->ingest->err.empty() ? (c->last_rc ? c->last_rc : LMAT_E_DEVICE) : set_err(c, LMAT_E_IO, c->ingest->err);
+    }
     return LMAT_OK;
 }
 
@@ -241,81 +274,148 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes) {
     return LMAT_OK;
 }
 
-// canonical payloads (16-bit DB id / list number) -> device payloads (internal taxid index / arena offset)
-static int build_device_db(lmat_ctx* c, Ingest& B, uint64_t table_bytes) {
-    hipSetDevice(c->device);
-    const HostTaxonomy& T = c->tax;
-    std::vector<uint16_t> arena(2, 0);  // offset 0 reserved
-    std::vector<uint32_t> list_pay(B.lists.size());
-    std::vector<uint16_t> rec;
-    for (size_t i = 0; i < B.lists.size(); ++i) {
-        if (!build_list_record(c, B.lists[i], rec)) return LMAT_E_TAXONOMY;
-        list_pay[i] = kListBase + (uint32_t)(arena.size() / 2);
-        arena.insert(arena.end(), rec.begin(), rec.end());
-    }
-    // one-element lists: a plain taxid index unless the id needs per-list treatment (unmapped, human
-    // variants folded to 9606, ignored ids): those get a one-element list record
-    std::vector<uint32_t> single_pay(65536, 0);
-    std::vector<uint16_t> one(1);
-    for (size_t i = 0; i < B.payload.size(); ++i) {
-        const uint32_t p = B.payload[i];
-        if (p >= kListBase || single_pay[p]) continue;
-        const uint32_t t32 = T.conv[p];
-        // (-s: even a lone taxid brings its lineage into the position set, so it needs a record too)
-        const bool special = c->permissive || t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
-        auto it = T.index_of.find(t32);
-        if (!special && it != T.index_of.end()) {
-            single_pay[p] = it->second;
-        } else {
-            one[0] = (uint16_t)p;
-            if (!build_list_record(c, one, rec)) return LMAT_E_TAXONOMY;
-            single_pay[p] = kListBase + (uint32_t)(arena.size() / 2);
-            arena.insert(arena.end(), rec.begin(), rec.end());
-        }
-    }
-    if (arena.size() / 2 + kListBase > kPayloadMask)
-        return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
-    int rc;
-    const size_t arena_words = arena.size();
-    arena.resize(arena_words + 8, 0);  // the kernels read a record's first 16 bytes in one load
-    if ((rc = dev_upload(c, &c->dev.arena, arena))) return rc;
-    c->arena_words = arena_words;
-    const uint64_t n = B.kmers.size();
-    if ((rc = alloc_table(c, n, table_bytes))) return rc;
-    c->dev.k = B.k;
-    const uint64_t chunk = 1ull << 24;
+// canonical payloads (16-bit DB id / list number) -> device payloads (internal taxid index / arena offset), chunk by
+// chunk: list records are built the first time a list is seen, so a database streams through without the whole
+// (k-mer, payload) array ever being resident on the host.
+namespace lmat {
+struct StreamBuild {
+    std::vector<uint16_t> arena{0, 0};  // offset 0 reserved
+    std::vector<uint32_t> list_pay;     // per canonical list: device payload (0 = not built yet)
+    std::vector<uint32_t> single_pay = std::vector<uint32_t>(65536, 0);
+    std::vector<uint32_t> pay;
     uint64_t* d_k = nullptr;
     uint32_t* d_p = nullptr;
     uint32_t* d_fail = nullptr;
-    std::vector<uint32_t> pay(std::min(chunk, std::max<uint64_t>(n, 1)));
-    HIPCHK(c, hipMalloc((void**)&d_k, pay.size() * 8));
-    HIPCHK(c, hipMalloc((void**)&d_p, pay.size() * 4));
-    HIPCHK(c, hipMalloc((void**)&d_fail, 4));
-    HIPCHK(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
-    for (uint64_t s = 0; s < n; s += chunk) {
-        const uint64_t m = std::min(chunk, n - s);
+    uint64_t cap = 0, inserted = 0;
+};
+}
+static void sb_free(lmat_ctx* c) {
+    if (!c->sb) return;
+    if (c->sb->d_k) hipFree(c->sb->d_k);
+    if (c->sb->d_p) hipFree(c->sb->d_p);
+    if (c->sb->d_fail) hipFree(c->sb->d_fail);
+    delete c->sb;
+    c->sb = nullptr;
+}
+static int sb_begin(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k) {
+    hipSetDevice(c->device);
+    sb_free(c);
+    c->sb = new StreamBuild();
+    int rc = alloc_table(c, n_kmers, table_bytes);
+    if (rc) return rc;
+    c->dev.k = k;
+    c->sb->cap = 1ull << 24;
+    HIPCHK(c, hipMalloc((void**)&c->sb->d_k, c->sb->cap * 8));
+    HIPCHK(c, hipMalloc((void**)&c->sb->d_p, c->sb->cap * 4));
+    HIPCHK(c, hipMalloc((void**)&c->sb->d_fail, 4));
+    HIPCHK(c, hipMemsetAsync(c->sb->d_fail, 0, 4, c->stream));
+    return LMAT_OK;
+}
+// inserts B.kmers / B.payload (all of them) and clears both
+static int sb_push(lmat_ctx* c, Ingest& B) {
+    StreamBuild& S = *c->sb;
+    const HostTaxonomy& T = c->tax;
+    std::vector<uint16_t> rec, one(1);
+    if (S.list_pay.size() < B.lists.size()) S.list_pay.resize(B.lists.size(), 0);
+    const uint64_t n = B.kmers.size();
+    for (uint64_t s = 0; s < n; s += S.cap) {
+        const uint64_t m = std::min(S.cap, n - s);
+        S.pay.resize(m);
         for (uint64_t i = 0; i < m; ++i) {
             const uint32_t p = B.payload[s + i];
-            pay[i] = p < kListBase ? single_pay[p] : list_pay[p - kListBase];
+            uint32_t dp;
+            if (p >= kListBase) {
+                uint32_t& lp = S.list_pay[p - kListBase];
+                if (!lp) {
+                    if (!build_list_record(c, B.lists[p - kListBase], rec)) return LMAT_E_TAXONOMY;
+                    lp = kListBase + (uint32_t)(S.arena.size() / 2);
+                    S.arena.insert(S.arena.end(), rec.begin(), rec.end());
+                }
+                dp = lp;
+            } else {
+                uint32_t& sp = S.single_pay[p];
+                if (!sp) {
+                    // one-element lists: a plain taxid index unless the id needs per-list treatment (unmapped, human
+                    // variants folded to 9606, ignored ids): those get a one-element list record
+                    // (-s: even a lone taxid brings its lineage into the position set, so it needs a record too)
+                    const uint32_t t32 = T.conv[p];
+                    const bool special = c->permissive || t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
+                    auto it = T.index_of.find(t32);
+                    if (!special && it != T.index_of.end()) {
+                        sp = it->second;
+                    } else {
+                        one[0] = (uint16_t)p;
+                        if (!build_list_record(c, one, rec)) return LMAT_E_TAXONOMY;
+                        sp = kListBase + (uint32_t)(S.arena.size() / 2);
+                        S.arena.insert(S.arena.end(), rec.begin(), rec.end());
+                    }
+                }
+                dp = sp;
+            }
+            S.pay[i] = dp;
         }
-        HIPCHK(c, hipMemcpyAsync(d_k, B.kmers.data() + s, m * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_p, pay.data(), m * 4, hipMemcpyHostToDevice, c->stream));
-        launch_insert_pairs(c->dev.slots, c->dev.nbuckets, d_k, d_p, m, d_fail, c->stream);
+        if (S.arena.size() / 2 + kListBase > kPayloadMask)
+            return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
+        HIPCHK(c, hipMemcpyAsync(S.d_k, B.kmers.data() + s, m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(S.d_p, S.pay.data(), m * 4, hipMemcpyHostToDevice, c->stream));
+        launch_insert_pairs(c->dev.slots, c->dev.nbuckets, S.d_k, S.d_p, m, S.d_fail, c->stream);
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        S.inserted += m;
     }
+    B.flushed += n;
+    B.kmers.clear();
+    B.payload.clear();
+    return LMAT_OK;
+}
+static int sb_finish(lmat_ctx* c) {
+    StreamBuild& S = *c->sb;
+    int rc;
+    const size_t arena_words = S.arena.size();
+    S.arena.resize(arena_words + 8, 0);  // the kernels read a record's first 16 bytes in one load
+    if ((rc = dev_upload(c, &c->dev.arena, S.arena))) return rc;
+    c->arena_words = arena_words;
     uint32_t fail = 0;
-    HIPCHK(c, hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost));
-    hipFree(d_k); hipFree(d_p); hipFree(d_fail);
-    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during insert");
+    HIPCHK(c, hipMemcpy(&fail, S.d_fail, 4, hipMemcpyDeviceToHost));
+    const uint64_t n = S.inserted;
+    sb_free(c);
+    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during insert (n_kmers_hint / table_bytes too small)");
     c->n_kmers = n;
     c->db_ready = true;
     return LMAT_OK;
 }
 
+static int build_device_db(lmat_ctx* c, Ingest& B, uint64_t table_bytes) {
+    int rc = sb_begin(c, B.kmers.size(), table_bytes, B.k);
+    if (rc) return rc;
+    std::vector<uint64_t> keep_k;
+    std::vector<uint32_t> keep_p;
+    keep_k.swap(B.kmers);   // sb_push consumes the arrays; a caller-owned ingest keeps its contents
+    keep_p.swap(B.payload);
+    const uint64_t n = keep_k.size(), chunk = 1ull << 24;
+    for (uint64_t s = 0; s < n && !rc; s += chunk) {
+        const uint64_t m = std::min(chunk, n - s);
+        B.kmers.assign(keep_k.begin() + s, keep_k.begin() + s + m);
+        B.payload.assign(keep_p.begin() + s, keep_p.begin() + s + m);
+        rc = sb_push(c, B);
+    }
+    B.kmers.swap(keep_k);
+    B.payload.swap(keep_p);
+    B.flushed = 0;
+    if (rc) { sb_free(c); return rc; }
+    return sb_finish(c);
+}
+
 int lmat_db_finalize(lmat_ctx* c) {
     if (!c) return LMAT_E_ARG;
     if (!c->ingest) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
-    int rc = build_device_db(c, *c->ingest, c->ingest_table_bytes);
+    int rc;
+    if (c->ingest->flush) {  // streamed build: the tail, then the list arena
+        rc = c->ingest->stream_failed ? (c->last_rc ? c->last_rc : LMAT_E_DEVICE) : sb_push(c, *c->ingest);
+        if (!rc) rc = sb_finish(c);
+        else sb_free(c);
+    } else {
+        rc = build_device_db(c, *c->ingest, c->ingest_table_bytes);
+    }
     delete c->ingest;
     c->ingest = nullptr;
     return rc;
@@ -341,6 +441,7 @@ int lmat_db_lookup(lmat_ctx* c, const uint64_t* kmers, uint64_t n, uint32_t* cou
     HIPCHK(c, hipMalloc((void**)&d_k, n * 8));
     HIPCHK(c, hipMalloc((void**)&d_c, n * 4));
     HIPCHK(c, hipMalloc((void**)&d_t, std::max<uint64_t>(n * stride, 1) * 4));
+    HIPCHK(c, hipMemsetAsync(d_t, 0, std::max<uint64_t>(n * stride, 1) * 4, c->stream));  // entries past a k-mer's count read as 0
     HIPCHK(c, hipMemcpyAsync(d_k, kmers, n * 8, hipMemcpyHostToDevice, c->stream));
     launch_lookup(c->dev, d_k, n, d_c, d_t, stride, c->stream);
     HIPCHK(c, hipMemcpyAsync(counts, d_c, n * 4, hipMemcpyDeviceToHost, c->stream));

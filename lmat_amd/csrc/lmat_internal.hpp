@@ -76,6 +76,8 @@ struct KernelParams {
 
 }  // namespace lmat
 
+namespace lmat { struct StreamBuild; }
+
 struct lmat_reads {
     uint32_t* words = nullptr;    // device: packed records
     uint64_t* rec_off = nullptr;  // device: [n+1] word offsets
@@ -96,6 +98,8 @@ struct lmat_ctx {
     std::string err;
     lmat::HostTaxonomy tax;
     lmat::DeviceTables dev;
+    lmat::StreamBuild* sb = nullptr;     // device-side build in progress (lmat_api.cpp)
+    int last_rc = 0;                     // code of the last set_err
     lmat::Ingest* ingest = nullptr;      // open between lmat_db_begin / lmat_db_load_image and lmat_db_finalize
     uint64_t ingest_table_bytes = 0;
     uint64_t n_kmers = 0;

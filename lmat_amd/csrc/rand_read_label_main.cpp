@@ -100,7 +100,14 @@ int main(int argc, char* argv[]) {
             else files.push_back(kmer_db_fn);
             uint32_t klen = 0;
             { FILE* f = fopen(files[0].c_str(), "rb"); if (f) { fseek(f, 25, SEEK_SET); if (fread(&klen, 4, 1, f) != 1) klen = 0; fclose(f); } }
-            if (lmat_db_begin(ctx, (int)klen, 0, 0) != LMAT_OK) return fail("k-mer DB");
+            uint64_t n_total = 0;
+            for (auto& fn : files) {
+                FILE* h = fopen(fn.c_str(), "rb");
+                uint64_t nk = 0;
+                if (h) { fseek(h, 4, SEEK_SET); if (fread(&nk, 8, 1, h) != 1) nk = 0; fclose(h); }
+                n_total += nk;
+            }
+            if (lmat_db_begin(ctx, (int)klen, n_total, 0) != LMAT_OK) return fail("k-mer DB");
             for (auto& fn : files) if (lmat_db_add_taxhisto(ctx, fn.c_str()) != LMAT_OK) return fail("k-mer DB");
         }
         if (lmat_db_finalize(ctx) != LMAT_OK) return fail("k-mer DB");

@@ -17,7 +17,7 @@
 namespace lmat {
 
 int set_err(lmat_ctx* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
+    if (c) { c->err = msg; c->last_rc = code; }
     return code;
 }
 

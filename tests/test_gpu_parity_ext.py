@@ -534,3 +534,46 @@ def test_rand_read_label_tables_match_oracle(tmp_path):
     # the human variants keep their own rows in this mode when they occur
     eng.close()
     orc.close()
+
+
+def test_streamed_database_build_equals_buffered(tmp_path, monkeypatch):
+    """With the table sized up front the tax_histo files (and images) stream through the insert kernel in chunks;
+    chunk boundaries (here every 777 k-mers) must not change a single lookup or call."""
+    from lmat_amd import Engine, Params
+    ds = dict(tree=os.path.join(DS, "tax.dat"), depth=os.path.join(DS, "depth.dat"), rank=os.path.join(DS, "rank.txt"),
+              idmap=os.path.join(DS, "map32to16.txt"), db=os.path.join(DS, "th.bin"))
+    reads = [l.strip() for l in open(os.path.join(DS, "reads.fa")) if not l.startswith(">")]
+    blob, off = _blob(reads)
+    gold = [(int(l.split()[0]), [int(x) for x in l.split()[2:]]) for l in open(os.path.join(G, "ref_lookup.txt"))]
+    km = np.array([g[0] for g in gold[::17]], dtype=np.uint64)
+
+    def run(eng):
+        counts, tids = eng.lookup(km)
+        dr = eng.upload_reads((blob, off))
+        res, cands = eng.classify(dr, cand_cap=256 * len(reads))
+        return counts.copy(), tids.copy(), eng.format_out(res, cands, (blob, off), 0), eng.db_size
+
+    eng = _engine(ds)
+    img = str(tmp_path / "db.img")
+    base = run(eng)
+    eng.close()
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    eng.build_db(ds["db"], k=20, save_image=img)   # buffered build can still write an image
+    eng.close()
+    monkeypatch.setenv("LMAT_INGEST_CHUNK", "777")
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    eng.build_db(ds["db"], k=20, n_kmers_hint=base[3])
+    streamed = run(eng)
+    eng.close()
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    eng.load_image(img)
+    from_image = run(eng)
+    eng.close()
+    for name, other in (("streamed", streamed), ("image", from_image)):
+        assert (other[0] == base[0]).all(), name
+        bad = np.nonzero((other[1] != base[1]).any(axis=1))[0]
+        assert bad.size == 0, (name, int(bad.size), int(km[bad[0]]), base[0][bad[0]], base[1][bad[0]][:8], other[1][bad[0]][:8])
+        assert other[2] == base[2] and other[3] == base[3], name
