@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from lmat_amd import Engine, Params
 eng = Engine(0, Params.run_rl())   # -p: n_cand = registered taxids with score >= 0 = nT
 eng.synth_taxonomy((3, 4, 4, 4, 4, 3))
-tb = 8 << 30
+tb = int(__import__("os").environ.get("NT_DB_GB", "8")) << 30
 G = int(0.8 * (tb / 8) / (768 * (1.0 + 3 * (1 - 0.99 ** 20))))
 eng.synth_db(G, k=20, seed=2002, table_bytes=tb)
 reads = eng.synth_reads(200000, (150,), seed=3003)
