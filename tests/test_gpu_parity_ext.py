@@ -577,3 +577,34 @@ def test_streamed_database_build_equals_buffered(tmp_path, monkeypatch):
         bad = np.nonzero((other[1] != base[1]).any(axis=1))[0]
         assert bad.size == 0, (name, int(bad.size), int(km[bad[0]]), base[0][bad[0]], base[1][bad[0]][:8], other[1][bad[0]][:8])
         assert other[2] == base[2] and other[3] == base[3], name
+
+
+def test_degenerate_reads():
+    """Empty, shorter-than-k, all-N, poly-A (one distinct k-mer), single-N-every-19-bases (no valid k-mer), mixed case,
+    IUPAC codes, exactly k and k+1 bases, a read repeated verbatim: record by record against the oracle; an empty batch
+    and a zero-count classify are no-ops."""
+    ds = dict(tree=os.path.join(DS, "tax.dat"), depth=os.path.join(DS, "depth.dat"), rank=os.path.join(DS, "rank.txt"),
+              idmap=os.path.join(DS, "map32to16.txt"), db=os.path.join(DS, "th.bin"))
+    real = [l.strip() for l in open(os.path.join(DS, "reads.fa")) if not l.startswith(">")]
+    r0 = real[0]
+    reads = ["", "A", "ACGT" * 4 + "ACG", "N" * 150, "A" * 150, "acgt" * 40, ("ACGTACGTACGTACGTACG" + "N") * 8, r0[:20], r0[:21],
+             r0.lower(), r0[:70] + "RYKM" + r0[74:], r0, r0, "T" * 19, "G" * 20, r0[::-1], "ACGTN" * 30, r0[:75] + "N" + r0[76:]]
+    eng = _engine(ds)
+    orc = _oracle(ds)
+    res, _, _ = _compare(eng, orc, reads)
+    assert res["status"][0] != 0 and res["status"][11] == res["status"][12]
+    # min_kmer 1 lets the short ones through to the lookup
+    from lmat_amd import Params
+    eng.set_params(Params(1.0, 0.0, 0.0, 1, 1, 1, 1))
+    orc.set_options(min_kmer=1)
+    _compare(eng, orc, reads)
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    res0, cands0 = eng.classify(dr, first=3, count=0)
+    assert res0.size == 0
+    dr.free()
+    empty = eng.upload_reads((np.zeros(1, dtype=np.uint8), np.zeros(1, dtype=np.uint64)))
+    assert len(empty) == 0
+    empty.free()
+    eng.close()
+    orc.close()
