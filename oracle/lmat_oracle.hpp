@@ -20,11 +20,15 @@
 //     SortedDb / TaxNodeStat / TaxTree compiled from /root/reference
 //     (oracle/_ref/ref_lookup) -> tests/golden/ref_lookup_*.txt
 //   * fastsummary / nomatchsum tallies : pinned by the example run's outputs
-//   * per-read label filtering, scoring and findReadLabelVer2 decision
-//     (src/read_label.cpp:225-941,1031-1204): PARITY UNPINNED.  read_label.cpp
-//     itself cannot be built here without stand-ins for generated
-//     all_headers.hpp, gzstream and perm-je, and the reference ships no test
-//     vectors for it beyond the example run's statistics columns.
+//   * per-read label retrieval -- taxid filtering, depth sort, leaf-most filter, representative strain per species,
+//     lineage closure, registration order, position counts, permissive mode (retrieve_kmer_labels) : pinned against
+//     the reference's own src/rkmer.hpp compiled in place (oracle/_ref/ref_rkmer, the function rand_read_label runs)
+//     on two fixture datasets -> tests/golden/ref_rkmer*.txt.  read_label.cpp's copy of the function differs by the
+//     human folding (:1033-1037, predicates pinned by ref_tidchecks.txt) and by marking a position after the
+//     duplicate test instead of before; both differences are restated, not pinned.
+//   * scoring and findReadLabelVer2 decision (src/read_label.cpp:225-941): PARITY UNPINNED.  read_label.cpp
+//     itself cannot be built here without stand-ins for generated all_headers.hpp, gzstream and perm-je, and the
+//     reference ships no test vectors for it beyond the example run's statistics columns.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -764,8 +768,9 @@ struct Classifier {
                 gc_cnt = 0;
                 tot_cnt = 0;
                 const kmer_t kmer_id = (forward < reverse) ? forward : reverse;
-                if (no_dups.find(kmer_id) != no_dups.end()) continue;
                 const int pos = j - klen + 1;
+                if (opt.rand_mode) label_vec[pos].first = 0;  // rkmer.hpp:106 marks the position before the duplicate test
+                if (no_dups.find(kmer_id) != no_dups.end()) continue;
                 label_vec[pos].first = 0;
                 no_dups.insert(kmer_id);
                 if (tr) { tr->uniq_kmers.push_back(kmer_id); tr->uniq_pos.push_back(pos); }
@@ -1068,6 +1073,38 @@ struct Classifier {
             mtype = res.second;
         }
         return std::make_pair(best_guess, mtype);
+    }
+
+    // What src/rkmer.hpp's retrieve_kmer_labels leaves behind for one read, in the form oracle/ref_rkmer.cpp prints for the
+    // reference's own function: valid k-mers, its GC bin (rkmer.hpp:289-290: G/C among all encodable bases over the read
+    // length), marked positions, registered taxids in registration order with their position counts
+    std::string rkmer_trace(const std::string& line, int k_size) const {
+        std::ostringstream o;
+        const int ri_len = (int)line.length();
+        o << "len=" << ri_len;
+        if (ri_len < k_size) { o << " short"; return o.str(); }
+        std::vector<label_info_t> label_vec(ri_len - k_size + 1, std::make_pair((int16_t)-1, tax_data_t()));
+        std::list<tid_t> taxid_lst;
+        hmap_t tax2idx, idx2tax;
+        const int valid_kmers = retrieve_kmer_labels(line.c_str(), ri_len, k_size, label_vec, taxid_lst, tax2idx, idx2tax, nullptr).first;
+        int gc_cnt = 0;
+        for (int j = 0; j < ri_len; ++j) {
+            const char b = line[j];
+            if (encode_base(b) < 0) continue;
+            if (b == 'g' || b == 'G' || b == 'c' || b == 'C') ++gc_cnt;
+        }
+        const float gc_pcnt = ((float)gc_cnt / (float)ri_len) * 100.0;
+        const int bin_sel = gc_pcnt / 10;
+        std::map<tid_t, int> cnt_tids;
+        int marked = 0;
+        for (unsigned pos = 0; pos < label_vec.size(); ++pos) {
+            if (label_vec[pos].first >= 0) ++marked;
+            for (auto& el : label_vec[pos].second) cnt_tids[el.first] += 1;
+        }
+        o << " valid=" << valid_kmers << " bin=" << bin_sel << " marked=" << marked << " reg=";
+        bool first = true;
+        for (tid_t t : taxid_lst) { o << (first ? "" : ",") << t << ":" << cnt_tids[t]; first = false; }
+        return o.str();
     }
 
     // rand_read_label's proc_line + construct_labels (src/rand_read_label.cpp:372-398, 185-213): per taxid the number of

@@ -32,6 +32,21 @@ const char* orc_error(orc_ctx* c) { return c->err.c_str(); }
 int orc_set_build_options(orc_ctx* c, int tid_cutoff, const char* rank_map, const char* human, const char* adaptors) {
     return c->db.set_options(tid_cutoff, rank_map ? rank_map : "", human ? human : "", adaptors ? adaptors : "") ? 0 : -1;
 }
+// rkmer.hpp's retrieve_kmer_labels per read, one text line each (see Classifier::rkmer_trace)
+const char* orc_rkmer_trace(orc_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, int k, int permissive) {
+    Options o = c->opt;
+    o.rand_mode = true;
+    o.permissive = permissive != 0;
+    Classifier cls(c->tax, c->db, o, nullptr);
+    std::ostringstream out;
+    for (uint64_t i = 0; i < n; ++i) {
+        std::string read((const char*)bases + off[i], (size_t)(off[i + 1] - off[i]));
+        out << "R " << i << " " << cls.rkmer_trace(read, k) << "\n";
+    }
+    c->text = out.str();
+    return c->text.c_str();
+}
+
 // rand_read_label over the given reads: rows (ascending taxid) of max label_prob and hit count per GC bucket
 int orc_rand_label(orc_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, int k, const uint8_t* gc_bucket, uint32_t nb,
                    uint32_t* tid, float* mx, int32_t* ct, uint32_t cap) {

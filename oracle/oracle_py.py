@@ -52,6 +52,8 @@ def _load():
     L.orc_text.argtypes = [vp]
     L.orc_summaries_from_calls.restype = C.c_long
     L.orc_summaries_from_calls.argtypes = [vp, vp, vp, vp, C.c_long, i32, i32, vp, C.c_long, vp, C.c_long]
+    L.orc_rkmer_trace.restype = cp
+    L.orc_rkmer_trace.argtypes = [vp, vp, vp, u64, i32, i32]
     L.orc_rand_label.restype = i32
     L.orc_rand_label.argtypes = [vp, vp, vp, u64, i32, vp, C.c_uint32, vp, vp, vp, C.c_uint32]
     L.orc_run_file.restype = C.c_long
@@ -80,6 +82,11 @@ class Oracle:
     def set_label_modes(self, permissive=False, tid_cutoff=0, rank_map=None):
         if self.L.orc_set_label_modes(self.h, int(permissive), tid_cutoff, (rank_map or "").encode()) != 0:
             raise RuntimeError("oracle: cannot read rank map")
+
+    def rkmer_trace(self, blob, off, k, permissive=False):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        return self.L.orc_rkmer_trace(self.h, blob.ctypes.data, off.ctypes.data, off.size - 1, k, int(permissive)).decode()
 
     def rand_label(self, blob, off, k, gc_bucket, nb=10, cap=70000):
         """rand_read_label over these reads -> {taxid: ([max label_prob per bucket], [hit count per bucket])}"""

@@ -7,6 +7,9 @@
   ref_paths.txt     TaxTree::getPathToRoot for every node of ds/tax.dat, from the reference's TaxTree
   ref_kencode.txt   kencode_c::kencode for 20-mer strings, from the reference's include/kencode.hpp
   ref_tidchecks.txt isHuman / isPhiX truth table from include/tid_checks.hpp
+  ref_rkmer[_permissive].txt  per read of ds/reads.fa: valid k-mers, GC bin, marked positions, and the registered
+                    taxids in registration order with their position counts, from the REFERENCE's
+                    retrieve_kmer_labels (src/rkmer.hpp, compiled in place -> oracle/_ref/ref_rkmer)
 Only inputs and expected outputs are stored; no reference source travels."""
 import os
 import subprocess
@@ -92,5 +95,21 @@ for tag, env in (("ranks", {"REF_RT_CUT": "2", "REF_RT_RANKS": os.path.join(ds, 
                              capture_output=True, text=True, check=True, env=dict(os.environ, **env)).stdout
         o.write("".join(l + "\n" for l in out.splitlines() if l and l[0].isdigit() and len(l.split()) >= 2 and l.split()[1].isdigit()))
 os.remove(kf)
+# ---- the reference's own retrieve_kmer_labels (src/rkmer.hpp) over the fixture reads, default and permissive
+for name, perm in (("ref_rkmer.txt", "0"), ("ref_rkmer_permissive.txt", "1")):
+    out = subprocess.run([os.path.join(ref, "ref_rkmer"), info["db"], info["idmap"], info["tree"], info["depth"], info["rank"], info["fasta"],
+                          "20", perm], capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(here, name), "w") as o:
+        o.write("".join(l + "\n" for l in out.splitlines() if l.startswith("R ")))
+# ---- a second, differently shaped dataset (4 strains per species, more sharing, mixed read lengths) for the same function
+ds2 = os.path.join(here, "ds2")
+info2 = synth.generate_dataset(ds2, (3, 2, 2, 2, 2, 4), 220, 300, L=(60, 100, 150, 250), seeds=(1001, 2102, 3103), frac_short=0.03,
+                               lower_frac=0.1, frac_n=0.05, frac_lowc=0.03)
+os.remove(info2["fastq"])
+for name, perm in (("ref_rkmer_ds2.txt", "0"), ("ref_rkmer_ds2_permissive.txt", "1")):
+    out = subprocess.run([os.path.join(ref, "ref_rkmer"), info2["db"], info2["idmap"], info2["tree"], info2["depth"], info2["rank"],
+                          info2["fasta"], "20", perm], capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(here, name), "w") as o:
+        o.write("".join(l + "\n" for l in out.splitlines() if l.startswith("R ")))
 print("option lookups:", q.size)
 print("k-mers looked up:", kms.size, "db k-mers:", info["n_kmers"], "reads:", len(reads))

@@ -608,3 +608,39 @@ def test_degenerate_reads():
     empty.free()
     eng.close()
     orc.close()
+
+
+@pytest.mark.parametrize("dsname", ["ds", "ds2"])
+def test_gpu_label_retrieval_against_reference_rkmer(dsname):
+    """The HIP path against the REFERENCE's own retrieve_kmer_labels (src/rkmer.hpp compiled in place,
+    tests/golden/ref_rkmer*.txt), without the oracle in between: per taxid, the largest count / valid_kmers over the
+    fixture reads and the number of reads that registered it, as the rand_read_label tables hold them."""
+    from lmat_amd import Engine, Params
+    ds = os.path.join(G, dsname)
+    want_max, want_cnt = {}, {}
+    tag = "_ds2" if dsname == "ds2" else ""
+    for line in open(os.path.join(G, f"ref_rkmer{tag}.txt")):
+        f = dict(x.split("=", 1) for x in line.split()[2:] if "=" in x)
+        if "valid" not in f or int(f["valid"]) <= 0 or not f.get("reg"):
+            continue
+        v = np.float32(int(f["valid"]))
+        for item in f["reg"].split(","):
+            t, c = item.split(":")
+            p = np.float32(int(c)) / v
+            want_max[int(t)] = max(want_max.get(int(t), np.float32(0)), p)
+            want_cnt[int(t)] = want_cnt.get(int(t), 0) + 1
+    reads = [l.rstrip("\n") for l in open(os.path.join(ds, "reads.fa")) if not l.startswith(">")]
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(os.path.join(ds, "tax.dat"), os.path.join(ds, "depth.dat"), os.path.join(ds, "rank.txt"), os.path.join(ds, "map32to16.txt"))
+    eng.rand_mode(True)
+    eng.build_db(os.path.join(ds, "th.bin"), k=20)
+    eng.rand_reset(10)
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    eng.rand_label(dr, np.zeros(len(reads), dtype=np.uint8))
+    got = eng.rand_table()
+    assert set(got) == set(want_cnt) and len(got) > 100
+    for t in want_cnt:
+        assert int(got[t][1][0]) == want_cnt[t], t
+        assert got[t][0][0].view(np.uint32) == np.float32(want_max[t]).view(np.uint32), t
+    eng.close()
