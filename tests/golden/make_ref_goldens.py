@@ -111,5 +111,15 @@ for name, perm in (("ref_rkmer_ds2.txt", "0"), ("ref_rkmer_ds2_permissive.txt", 
                           info2["fasta"], "20", perm], capture_output=True, text=True, check=True).stdout
     with open(os.path.join(here, name), "w") as o:
         o.write("".join(l + "\n" for l in out.splitlines() if l.startswith("R ")))
+# ---- an 18-mer database through the reference's 18-mer index configuration (IDX_CONFIG=1827, SortedDb.hpp:103-109)
+ds3 = os.path.join(here, "ds3")
+info3 = synth.generate_dataset(ds3, (2, 3, 2, 2, 2, 2), 260, 300, L=(50, 100, 150), k=18, seeds=(1001, 2203, 3203), frac_short=0.03,
+                               lower_frac=0.05, frac_n=0.03, frac_lowc=0.03)
+os.remove(info3["fastq"])
+for name, perm in (("ref_rkmer_ds3.txt", "0"), ("ref_rkmer_ds3_permissive.txt", "1")):
+    out = subprocess.run([os.path.join(ref, "ref_rkmer18"), info3["db"], info3["idmap"], info3["tree"], info3["depth"], info3["rank"],
+                          info3["fasta"], "18", perm], capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(here, name), "w") as o:
+        o.write("".join(l + "\n" for l in out.splitlines() if l.startswith("R ")))
 print("option lookups:", q.size)
 print("k-mers looked up:", kms.size, "db k-mers:", info["n_kmers"], "reads:", len(reads))

@@ -610,7 +610,7 @@ def test_degenerate_reads():
     orc.close()
 
 
-@pytest.mark.parametrize("dsname", ["ds", "ds2"])
+@pytest.mark.parametrize("dsname", ["ds", "ds2", "ds3"])
 def test_gpu_label_retrieval_against_reference_rkmer(dsname):
     """The HIP path against the REFERENCE's own retrieve_kmer_labels (src/rkmer.hpp compiled in place,
     tests/golden/ref_rkmer*.txt), without the oracle in between: per taxid, the largest count / valid_kmers over the
@@ -618,7 +618,8 @@ def test_gpu_label_retrieval_against_reference_rkmer(dsname):
     from lmat_amd import Engine, Params
     ds = os.path.join(G, dsname)
     want_max, want_cnt = {}, {}
-    tag = "_ds2" if dsname == "ds2" else ""
+    tag = "" if dsname == "ds" else "_" + dsname
+    k = 18 if dsname == "ds3" else 20
     for line in open(os.path.join(G, f"ref_rkmer{tag}.txt")):
         f = dict(x.split("=", 1) for x in line.split()[2:] if "=" in x)
         if "valid" not in f or int(f["valid"]) <= 0 or not f.get("reg"):
@@ -633,7 +634,7 @@ def test_gpu_label_retrieval_against_reference_rkmer(dsname):
     eng = Engine(0, Params.run_rl())
     eng.load_taxonomy(os.path.join(ds, "tax.dat"), os.path.join(ds, "depth.dat"), os.path.join(ds, "rank.txt"), os.path.join(ds, "map32to16.txt"))
     eng.rand_mode(True)
-    eng.build_db(os.path.join(ds, "th.bin"), k=20)
+    eng.build_db(os.path.join(ds, "th.bin"), k=k)
     eng.rand_reset(10)
     blob, off = _blob(reads)
     dr = eng.upload_reads((blob, off))
