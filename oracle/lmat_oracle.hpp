@@ -26,7 +26,10 @@
 //     on two fixture datasets -> tests/golden/ref_rkmer*.txt.  read_label.cpp's copy of the function differs by the
 //     human folding (:1033-1037, predicates pinned by ref_tidchecks.txt) and by marking a position after the
 //     duplicate test instead of before; both differences are restated, not pinned.
-//   * scoring and findReadLabelVer2 decision (src/read_label.cpp:225-941): PARITY UNPINNED.  read_label.cpp
+//   * score statistics (mean / stdev, :806-880): reproduced to print precision from the example run's own records
+//     (tests/golden/example_score_stats.json).
+//   * null-model scores, PhiX/human handling, TCmp sort and the findReadLabelVer2 decision
+//     (src/read_label.cpp:225-805,881-941): PARITY UNPINNED.  read_label.cpp
 //     itself cannot be built here without stand-ins for generated all_headers.hpp, gzstream and perm-je, and the
 //     reference ships no test vectors for it beyond the example run's statistics columns.
 #pragma once
@@ -1003,30 +1006,14 @@ struct Classifier {
             std::list<ufpair_t> valid_cand;
             std::pair<ufpair_t, Match> res = std::make_pair(std::make_pair(0, 0), kNoMatchT);
             std::string match_type = match_str(res.second);
-            unsigned use_sig_hits = 0;
-            float log_avg;
-            const unsigned min_pos_examples = 3;
-            if (pos_sig_hits > min_pos_examples) {
-                use_sig_hits = pos_sig_hits;
-                log_avg = pos_log_sum / (float)pos_sig_hits;
-            } else {
-                use_sig_hits = sig_hits;
-                log_avg = sig_hits > 0 ? log_sum / (float)sig_hits : 0;
-            }
-            float log_std = 0;
-            for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
-                if (rank_label[tax_idx].second > 0) {
-                    if (pos_sig_hits > min_pos_examples) {
-                        const float val = log_avg - rank_label[tax_idx].second;
-                        log_std += (val * val);
-                    }
-                }
-                if (pos_sig_hits <= min_pos_examples) {
-                    const float val = log_avg - rank_label[tax_idx].second;
-                    log_std += (val * val);
-                }
-            }
-            float stdev1 = use_sig_hits > 1 ? sqrt(log_std / (use_sig_hits - 1)) : 0;
+            // mean and standard deviation of the scores (:850-880), in registration order
+            std::vector<float> sc(num_tax_ids);
+            for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) sc[tax_idx] = rank_label[tax_idx].second;
+            const ScoreStats st = score_stats(sc.data(), num_tax_ids);
+            const unsigned use_sig_hits = st.use_sig_hits;
+            const float log_avg = st.log_avg;
+            float stdev1 = st.stdev;
+            (void)log_sum; (void)pos_log_sum; (void)sig_hits; (void)pos_sig_hits;
             if (use_sig_hits > 0) {
                 if (has_human) {
                     for (unsigned tax_idx = 0; tax_idx < num_tax_ids; ++tax_idx) {
@@ -1073,6 +1060,44 @@ struct Classifier {
             mtype = res.second;
         }
         return std::make_pair(best_guess, mtype);
+    }
+
+    // construct_labels' score statistics (src/read_label.cpp:806-880): sums in the order given; the mean and the
+    // (n-1) standard deviation run over the positive scores when there are more than three of them, else over all
+    struct ScoreStats { float log_avg, stdev; unsigned use_sig_hits; };
+    static ScoreStats score_stats(const float* score, unsigned n) {
+        float log_sum = 0.0, pos_log_sum = 0.0;
+        unsigned sig_hits = 0, pos_sig_hits = 0;
+        for (unsigned i = 0; i < n; ++i) {
+            const float log_odds = score[i];
+            log_sum += log_odds;
+            sig_hits++;
+            if (log_odds > 0) { pos_sig_hits++; pos_log_sum += log_odds; }
+        }
+        ScoreStats r;
+        const unsigned min_pos_examples = 3;
+        if (pos_sig_hits > min_pos_examples) {
+            r.use_sig_hits = pos_sig_hits;
+            r.log_avg = pos_log_sum / (float)pos_sig_hits;
+        } else {
+            r.use_sig_hits = sig_hits;
+            r.log_avg = sig_hits > 0 ? log_sum / (float)sig_hits : 0;
+        }
+        float log_std = 0;
+        for (unsigned i = 0; i < n; ++i) {
+            if (score[i] > 0) {
+                if (pos_sig_hits > min_pos_examples) {
+                    const float val = r.log_avg - score[i];
+                    log_std += (val * val);
+                }
+            }
+            if (pos_sig_hits <= min_pos_examples) {
+                const float val = r.log_avg - score[i];
+                log_std += (val * val);
+            }
+        }
+        r.stdev = r.use_sig_hits > 1 ? sqrt(log_std / (r.use_sig_hits - 1)) : 0;
+        return r;
     }
 
     // What src/rkmer.hpp's retrieve_kmer_labels leaves behind for one read, in the form oracle/ref_rkmer.cpp prints for the

@@ -32,6 +32,13 @@ const char* orc_error(orc_ctx* c) { return c->err.c_str(); }
 int orc_set_build_options(orc_ctx* c, int tid_cutoff, const char* rank_map, const char* human, const char* adaptors) {
     return c->db.set_options(tid_cutoff, rank_map ? rank_map : "", human ? human : "", adaptors ? adaptors : "") ? 0 : -1;
 }
+// construct_labels' mean / stdev of a score list (Classifier::score_stats)
+void orc_score_stats(const float* score, uint32_t n, float* log_avg, float* stdev) {
+    const Classifier::ScoreStats s = Classifier::score_stats(score, n);
+    *log_avg = s.log_avg;
+    *stdev = s.stdev;
+}
+
 // rkmer.hpp's retrieve_kmer_labels per read, one text line each (see Classifier::rkmer_trace)
 const char* orc_rkmer_trace(orc_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, int k, int permissive) {
     Options o = c->opt;

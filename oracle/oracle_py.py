@@ -52,6 +52,8 @@ def _load():
     L.orc_text.argtypes = [vp]
     L.orc_summaries_from_calls.restype = C.c_long
     L.orc_summaries_from_calls.argtypes = [vp, vp, vp, vp, C.c_long, i32, i32, vp, C.c_long, vp, C.c_long]
+    L.orc_score_stats.restype = None
+    L.orc_score_stats.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.orc_rkmer_trace.restype = cp
     L.orc_rkmer_trace.argtypes = [vp, vp, vp, u64, i32, i32]
     L.orc_rand_label.restype = i32
@@ -82,6 +84,12 @@ class Oracle:
     def set_label_modes(self, permissive=False, tid_cutoff=0, rank_map=None):
         if self.L.orc_set_label_modes(self.h, int(permissive), tid_cutoff, (rank_map or "").encode()) != 0:
             raise RuntimeError("oracle: cannot read rank map")
+
+    def score_stats(self, scores):
+        s = np.ascontiguousarray(scores, dtype=np.float32)
+        a, b = C.c_float(0), C.c_float(0)
+        self.L.orc_score_stats(s.ctypes.data, s.size, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def rkmer_trace(self, blob, off, k, permissive=False):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)

@@ -18,7 +18,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 with tempfile.TemporaryDirectory() as td:
     tarfile.open(ref).extractall(td)
     pre = "simple_list.1000.fna.kML+Human.v4-14.20.g10.db.lo.rl_output"
-    rows, calls = [], []
+    rows, calls, stats = [], [], []
     for f in sorted(glob.glob(os.path.join(td, pre + "[0-7].out"))):
         for line in open(f):
             c = line.rstrip("\n").split("\t")
@@ -31,6 +31,10 @@ with tempfile.TemporaryDirectory() as td:
             else:
                 what, exp = "cand", int(st[2])
                 calls.append([int(last[0]), last[1], kind])
+                cand = c[3].split() if len(c) == 5 else []
+                if st[0] != "-1" and cand and cand[0] != "-1":
+                    # the statistics columns next to the candidate scores the same record prints (text as printed)
+                    stats.append([st[0], st[1], cand[1::2]])
             rows.append((hdr, read, kind, what, exp))
     with open(os.path.join(here, "example_kmer_counts.tsv"), "w") as o:
         for r in rows:
@@ -39,4 +43,5 @@ with tempfile.TemporaryDirectory() as td:
     nm = dict(l.split() for l in open(os.path.join(td, pre + ".0.30.nomatchsum")))
     json.dump({"calls": calls, "fastsummary": fs, "nomatchsum": nm, "min_score": 0.0},
               open(os.path.join(here, "example_summary.json"), "w"))
+    json.dump(stats, open(os.path.join(here, "example_score_stats.json"), "w"))
     print(len(rows), "reads,", len(calls), "calls")
