@@ -645,3 +645,32 @@ def test_gpu_label_retrieval_against_reference_rkmer(dsname):
         assert int(got[t][1][0]) == want_cnt[t], t
         assert got[t][0][0].view(np.uint32) == np.float32(want_max[t]).view(np.uint32), t
     eng.close()
+
+
+def test_gpu_extraction_against_the_example_run(monkeypatch):
+    """K1 on the GPU (2-bit packing, canonical 20-mers, N handling, per-read dedupe) against what the REFERENCE
+    printed for its own example run (example/example.tgz, 1000 reads of 202 bp): distinct valid k-mers for
+    classified reads, valid k-mers for NoDbHits / ReadTooShort rows.  LMAT_STOP_AFTER=2 makes the kernel stop
+    after the compaction of first occurrences and report that count."""
+    from lmat_amd import Engine, Params
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(G, "example_kmer_counts.tsv"))]
+    reads = [r[1] for r in rows]
+    monkeypatch.setenv("LMAT_STOP_AFTER", "2")
+    eng = Engine(0, Params(1.0, 0.0, 0.0, 1, 1, 1, 1))  # min_kmer 1: every read with a valid k-mer reaches the compaction
+    eng.load_taxonomy(os.path.join(DS, "tax.dat"), os.path.join(DS, "depth.dat"), os.path.join(DS, "rank.txt"), os.path.join(DS, "map32to16.txt"))
+    eng.build_db(os.path.join(DS, "th.bin"), k=20)
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    res, _ = eng.classify(dr)
+    n_dup = 0
+    for (hdr, read, kind, what, exp), r in zip(rows, res):
+        exp = int(exp)
+        if len(read) < 20:
+            assert r["status"] == 2 and r["read_len"] == exp, hdr       # ReadTooShort (length)
+        elif what == "valid":
+            assert r["valid_kmers"] == exp, (hdr, kind)
+        else:
+            assert r["status"] == 250 and r["cand_kmer_cnt"] == exp, (hdr, kind, int(r["cand_kmer_cnt"]), exp)
+            n_dup += exp != len(read) - 19
+    assert n_dup >= 40
+    eng.close()
