@@ -41,7 +41,7 @@ void orc_score_stats(const float* score, uint32_t n, float* log_avg, float* stde
 
 // rkmer.hpp's retrieve_kmer_labels per read, one text line each (see Classifier::rkmer_trace)
 const char* orc_rkmer_trace(orc_ctx* c, const uint8_t* bases, const uint64_t* off, uint64_t n, int k, int permissive) {
-    Options o = c->opt;
+    Options o = c->opt;  // run-time pruning (orc_set_label_modes) rides along
     o.rand_mode = true;
     o.permissive = permissive != 0;
     Classifier cls(c->tax, c->db, o, nullptr);

@@ -32,7 +32,7 @@ id_convback_map_t conv_map;
 bool tid_map_is_strain_species = false;
 
 int main(int argc, char** argv) {
-    // ref_rkmer <taxhisto.bin> <map32to16.txt> <tax.dat> <depth.dat> <rank.txt> <reads.fa> <k> [permissive]
+    // ref_rkmer <taxhisto.bin> <map32to16.txt> <tax.dat> <depth.dat> <rank.txt> <reads.fa> <k> [permissive [max_count [numeric_ranks]]]
     if (argc < 8) return 2;
     bitreduce_map_t br_map;
     {
@@ -45,6 +45,14 @@ int main(int argc, char** argv) {
     }
     const int k = atoi(argv[7]);
     gPERMISSIVE_MATCH = argc > 8 && atoi(argv[8]) != 0;
+    const uint16_t max_count = argc > 9 ? (uint16_t)atoi(argv[9]) : (uint16_t)~0;  // -h of rand_read_label (:457)
+    if (argc > 10) {  // -r rank table (:640-650)
+        FILE* rmfp = fopen(argv[10], "r");
+        if (!rmfp) return 4;
+        uint32_t src, dest;
+        while (fscanf(rmfp, "%d%d", &src, &dest) > 0) tid_rank_map[src] = dest;
+        fclose(rmfp);
+    }
     SortedDb<uint16_t>* db = new SortedDb<uint16_t>(4000000, (size_t)4000000 * 64 + (1 << 20));
     db->set_kmer_length(k);
     my_map species_map;
@@ -66,22 +74,25 @@ int main(int argc, char** argv) {
     string line, read;
     unsigned idx = 0;
     auto run = [&](const string& rd) {
+        // one line per read, written after the call: with pruning on the reference prints blank lines of its own
+        // (TaxNodeStat.hpp:192) while it runs
+        ostringstream o;
         const int ri_len = (int)rd.length();
-        printf("R %u len=%d", idx++, ri_len);
-        if (ri_len < k) { printf(" short\n"); return; }
+        o << "R " << idx++ << " len=" << ri_len;
+        if (ri_len < k) { cout << o.str() << " short" << endl; return; }
         vector<label_info_t> label_vec(ri_len - k + 1, make_pair(-1, tax_data_t()));
         list<TID_T> taxid_lst;
         hmap_t tax2idx, idx2tax;
-        const pair<int, int> res = retrieve_kmer_labels(db, rd.c_str(), ri_len, k, label_vec, taxid_lst, tax2idx, idx2tax, dmap, tax_tree, (uint16_t)~0);
+        const pair<int, int> res = retrieve_kmer_labels(db, rd.c_str(), ri_len, k, label_vec, taxid_lst, tax2idx, idx2tax, dmap, tax_tree, max_count);
         map<TID_T, int> cnt_tids;  // src/rand_read_label.cpp:383-396
         int nonneg = 0;
         for (unsigned pos = 0; pos < label_vec.size(); ++pos) {
             if (label_vec[pos].first >= 0) ++nonneg;
             for (tax_data_t::const_iterator it = label_vec[pos].second.begin(); it != label_vec[pos].second.end(); ++it) cnt_tids[it->first] += 1;
         }
-        printf(" valid=%d bin=%d marked=%d reg=", res.first, res.second, nonneg);
-        for (list<TID_T>::const_iterator it = taxid_lst.begin(); it != taxid_lst.end(); ++it) printf("%s%u:%d", it == taxid_lst.begin() ? "" : ",", *it, cnt_tids[*it]);
-        printf("\n");
+        o << " valid=" << res.first << " bin=" << res.second << " marked=" << nonneg << " reg=";
+        for (list<TID_T>::const_iterator it = taxid_lst.begin(); it != taxid_lst.end(); ++it) o << (it == taxid_lst.begin() ? "" : ",") << *it << ":" << cnt_tids[*it];
+        cout << o.str() << endl;
     };
     while (getline(fa, line)) {
         if (!line.empty() && line[0] == '>') { if (!read.empty()) run(read); read.clear(); }

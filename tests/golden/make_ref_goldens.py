@@ -101,6 +101,12 @@ for name, perm in (("ref_rkmer.txt", "0"), ("ref_rkmer_permissive.txt", "1")):
                           "20", perm], capture_output=True, text=True, check=True).stdout
     with open(os.path.join(here, name), "w") as o:
         o.write("".join(l + "\n" for l in out.splitlines() if l.startswith("R ")))
+# ---- run-time pruning (-h 2 [-r ranks]) through the same function
+for name, extra in (("ref_rkmer_pruned.txt", ["2", os.path.join(ds, "numeric_ranks.txt")]), ("ref_rkmer_pruned_noranks.txt", ["2"])):
+    out = subprocess.run([os.path.join(ref, "ref_rkmer"), info["db"], info["idmap"], info["tree"], info["depth"], info["rank"], info["fasta"],
+                          "20", "0"] + extra, capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(here, name), "w") as o:
+        o.write("".join(l + "\n" for l in out.splitlines() if l.startswith("R ")))
 # ---- a second, differently shaped dataset (4 strains per species, more sharing, mixed read lengths) for the same function
 ds2 = os.path.join(here, "ds2")
 info2 = synth.generate_dataset(ds2, (3, 2, 2, 2, 2, 4), 220, 300, L=(60, 100, 150, 250), seeds=(1001, 2102, 3103), frac_short=0.03,

@@ -610,15 +610,16 @@ def test_degenerate_reads():
     orc.close()
 
 
-@pytest.mark.parametrize("dsname", ["ds", "ds2", "ds3"])
+@pytest.mark.parametrize("dsname", ["ds", "ds2", "ds3", "ds:pruned", "ds:pruned_noranks"])
 def test_gpu_label_retrieval_against_reference_rkmer(dsname):
     """The HIP path against the REFERENCE's own retrieve_kmer_labels (src/rkmer.hpp compiled in place,
     tests/golden/ref_rkmer*.txt), without the oracle in between: per taxid, the largest count / valid_kmers over the
     fixture reads and the number of reads that registered it, as the rand_read_label tables hold them."""
     from lmat_amd import Engine, Params
+    dsname, _, mode = dsname.partition(":")   # mode: run-time pruning (max_count 2) with / without the numeric rank map
     ds = os.path.join(G, dsname)
     want_max, want_cnt = {}, {}
-    tag = "" if dsname == "ds" else "_" + dsname
+    tag = ("" if dsname == "ds" else "_" + dsname) + ("_" + mode if mode else "")
     k = 18 if dsname == "ds3" else 20
     for line in open(os.path.join(G, f"ref_rkmer{tag}.txt")):
         f = dict(x.split("=", 1) for x in line.split()[2:] if "=" in x)
@@ -634,6 +635,8 @@ def test_gpu_label_retrieval_against_reference_rkmer(dsname):
     eng = Engine(0, Params.run_rl())
     eng.load_taxonomy(os.path.join(ds, "tax.dat"), os.path.join(ds, "depth.dat"), os.path.join(ds, "rank.txt"), os.path.join(ds, "map32to16.txt"))
     eng.rand_mode(True)
+    if mode:
+        eng.set_label_modes(False, 2, os.path.join(ds, "numeric_ranks.txt") if mode == "pruned" else None)
     eng.build_db(os.path.join(ds, "th.bin"), k=k)
     eng.rand_reset(10)
     blob, off = _blob(reads)
