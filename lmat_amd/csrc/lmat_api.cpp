@@ -841,11 +841,9 @@ int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t
         if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
         if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
         if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
-        std::vector<lmat_read_result> host(count);
-        HIPCHK(c, hipMemcpy(host.data(), c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
         if (cur[1] & kErrTidOverflow)
             return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
-        memcpy(results, host.data(), count * sizeof(lmat_read_result));
+        HIPCHK(c, hipMemcpy(results, c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
         if (want) {
             const uint64_t used = std::min<uint64_t>(cur[0], cand_cap);
             if (used) HIPCHK(c, hipMemcpy(cands, c->d_cands, used * sizeof(lmat_cand), hipMemcpyDeviceToHost));

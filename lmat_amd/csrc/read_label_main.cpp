@@ -15,7 +15,10 @@
 //   * -t N is the number of output shards (<o>0.out .. <o>N-1.out) and of formatter threads; reads
 //     are dealt to shards in contiguous blocks (the reference deals them dynamically, so only the
 //     multiset of lines across shards is defined there; -t 1 gives the reference's -t 1 file).
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
 #include <chrono>
@@ -67,17 +70,48 @@ static bool is_list_file(const std::string& fn) {
 struct Batch {
     std::vector<uint8_t> bases;
     std::vector<uint64_t> off{0};
-    std::vector<std::string> hdrs;
-    size_t n() const { return hdrs.size(); }
-    void clear() { bases.clear(); off.assign(1, 0); hdrs.clear(); }
+    std::string hdr_blob;             // headers back to back
+    std::vector<uint64_t> hoff{0};    // [n+1] into hdr_blob
+    size_t n() const { return hoff.size() - 1; }
+    void add_hdr(const char* p, size_t len) { hdr_blob.append(p, len); hoff.push_back(hdr_blob.size()); }
+    void clear() { bases.clear(); off.assign(1, 0); hdr_blob.clear(); hoff.assign(1, 0); }
 };
+
+// A contiguous piece of a FASTA file that starts at a '>' line -> one batch, with the record rules of FastxReader
+// (fastx.hpp; src/read_label.cpp:1651-1713): a record is its header line and the following lines up to the next '>'
+// line, lines of length <= 1 are ignored, a record without sequence is not emitted.  Pieces are parsed in parallel.
+static void parse_fasta_piece(const char* p, const char* end, Batch& b) {
+    b.clear();
+    const char* hdr = nullptr;
+    size_t hdr_len = 0;
+    bool open = false;  // sequence bytes of the current record already appended
+    auto close = [&]() {
+        if (open) { b.off.push_back(b.bases.size()); b.add_hdr(hdr ? hdr : "", hdr ? hdr_len : 0); }
+        open = false;
+    };
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        const size_t len = (size_t)(le - p);
+        if (len && *p == '>') {
+            close();
+            hdr = p + 1;
+            hdr_len = len - 1;
+        } else if (len > 1) {
+            b.bases.insert(b.bases.end(), (const uint8_t*)p, (const uint8_t*)le);
+            open = true;
+        }
+        p = nl ? nl + 1 : end;
+    }
+    close();
+}
 
 // One batch on its way through the three stages: parse (reader thread) -> classify (main thread, GPU) ->
 // format + write + tally (writer thread).  The stages of consecutive batches overlap.
 struct Work {
     Batch b;
     std::vector<lmat_read_result> res;
-    std::vector<lmat_cand> cands;
+    std::unique_ptr<lmat_cand[]> cands;  // uninitialised on purpose: zero-filling 64 candidates per read cost more than the GPU work
 };
 class WorkQueue {
     std::mutex m;
@@ -257,7 +291,75 @@ int main(int argc, char* argv[]) {
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b_) { return std::chrono::duration<double>(b_ - a).count(); };
     WorkQueue parsed(2), classified(2);
+    // A FASTA query in a regular file is mapped and cut at '>' lines into 32 MB pieces that are parsed in parallel,
+    // one batch per piece (FASTQ and stdin keep the sequential reader: its header pairing is line-order dependent).
+    const char* map_base = nullptr;
+    size_t map_size = 0;
+    if (!fastq && query_fn != "-") {
+        int fd = open(query_fn.c_str(), O_RDONLY);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { map_base = (const char*)m; map_size = (size_t)sb.st_size; madvise(m, map_size, MADV_SEQUENTIAL); }
+        }
+        if (fd >= 0) close(fd);
+    }
     std::thread reader([&]() {  // stage 1: FASTA/FASTQ -> batches
+        if (map_base) {
+            size_t kPiece = 32u << 20;
+            if (const char* e = getenv("LMAT_FASTA_PIECE")) kPiece = std::max<size_t>(16, strtoull(e, nullptr, 10));  // tests: force many pieces
+            const unsigned P = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+            size_t pos = 0;
+            while (pos < map_size) {
+                auto tp0 = now();
+                std::vector<size_t> cut(1, pos);
+                for (unsigned j = 1; j <= P && cut.back() < map_size; ++j) {
+                    size_t target = cut.back() + kPiece;
+                    size_t c = map_size;
+                    while (target < map_size) {  // next line that starts with '>'
+                        const char* nl = (const char*)memchr(map_base + target, '\n', map_size - target);
+                        if (!nl) break;
+                        const size_t at = (size_t)(nl - map_base) + 1;
+                        if (at >= map_size) break;
+                        if (map_base[at] == '>') { c = at; break; }
+                        target = at;
+                    }
+                    cut.push_back(c);
+                }
+                const size_t np = cut.size() - 1;
+                std::vector<std::unique_ptr<Work>> ws(np);
+                std::vector<std::thread> th;
+                for (size_t j = 0; j < np; ++j) {
+                    ws[j].reset(new Work());
+                    th.emplace_back([&, j]() { parse_fasta_piece(map_base + cut[j], map_base + cut[j + 1], ws[j]->b); });
+                }
+                for (auto& x : th) x.join();
+                for (size_t j = 0; j < np; ++j) {
+                    Batch& b = ws[j]->b;
+                    const size_t n = b.n();
+                    bool unnamed = false;
+                    for (size_t i = 0; i < n && !unnamed; ++i) unnamed = b.hoff[i + 1] == b.hoff[i] || b.hdr_blob[b.hoff[i]] == '\0';
+                    if (unnamed) {  // "unknown_hdr:<running read number>" (:1728-1732)
+                        std::string blob;
+                        std::vector<uint64_t> ho(1, 0);
+                        for (size_t i = 0; i < n; ++i) {
+                            if (b.hoff[i + 1] == b.hoff[i] || b.hdr_blob[b.hoff[i]] == '\0') blob += "unknown_hdr:" + std::to_string(read_count + i + 1);
+                            else blob.append(b.hdr_blob, b.hoff[i], b.hoff[i + 1] - b.hoff[i]);
+                            ho.push_back(blob.size());
+                        }
+                        b.hdr_blob.swap(blob);
+                        b.hoff.swap(ho);
+                    }
+                    read_count += n;
+                    if (n) { b.bases.push_back(0); parsed.push(std::move(ws[j])); }
+                }
+                pos = cut.back();
+                t_parse += secs(tp0, now());
+            }
+            std::cout << "Total reads loaded: " << read_count << std::endl;
+            parsed.close();
+            return;
+        }
         FastxReader rd(*in, fastq);
         std::string read, hdr;
         bool more = true;
@@ -273,7 +375,7 @@ int main(int argc, char* argv[]) {
                     o << "unknown_hdr:" << read_count;
                     hdr = o.str();
                 }
-                b.hdrs.push_back(hdr);
+                b.add_hdr(hdr.data(), hdr.size());
                 b.bases.insert(b.bases.end(), read.begin(), read.end());
                 b.off.push_back(b.bases.size());
             }
@@ -289,7 +391,7 @@ int main(int argc, char* argv[]) {
             auto tp2 = now();
             const Batch& b = w->b;
             const std::vector<lmat_read_result>& res = w->res;
-            const lmat_cand* cands = w->cands.data();
+            const lmat_cand* cands = w->cands.get();
             const size_t n = b.n();
             // shard t holds a contiguous block of every batch; a block is formatted in slices by several threads
             const size_t per = (n + n_threads - 1) / n_threads;
@@ -305,7 +407,7 @@ int main(int argc, char* argv[]) {
                     std::string& s = text[j];
                     s.reserve((hi - lo) * (prn_read ? 384 : 200));
                     for (size_t i = lo; i < hi; ++i) {
-                        s += b.hdrs[i];
+                        s.append(b.hdr_blob.data() + b.hoff[i], b.hoff[i + 1] - b.hoff[i]);
                         s += '\t';
                         if (prn_read) s.append((const char*)b.bases.data() + b.off[i], b.off[i + 1] - b.off[i]);
                         else s += 'X';
@@ -344,8 +446,8 @@ int main(int argc, char* argv[]) {
         uint64_t ncand = 0;
         size_t cap = std::max<size_t>(64 * n, 4096);
         for (;;) {  // grow the candidate buffer until the batch fits
-            w->cands.resize(cap);
-            int rc = lmat_classify(ctx, dr, 0, n, w->res.data(), w->cands.data(), cap, &ncand);
+            w->cands.reset(new lmat_cand[cap]);
+            int rc = lmat_classify(ctx, dr, 0, n, w->res.data(), w->cands.get(), cap, &ncand);
             if (rc == LMAT_OK) break;
             if (rc == LMAT_E_CAPACITY && strstr(lmat_last_error(ctx), "cand_cap") && cap < (size_t)1 << 31) { cap *= 4; continue; }
             failed = true;

@@ -102,3 +102,34 @@ def test_rand_read_label_cli(tmp_path):
         assert len(x) == 21
         for b in range(10):
             assert x[1 + 2 * b] == "%g" % float(mx[b]) and int(x[2 + 2 * b]) == int(ct[b])
+
+
+def test_parallel_fasta_front_end_equals_the_sequential_reader(small_dataset, tmp_path):
+    """A FASTA file is mapped and parsed in pieces in parallel; stdin goes through the sequential reader that
+    restates the reference's producer loop.  Same text either way, also for a file full of the reader's corner
+    cases (multi-line records, blank and one-character lines, records without sequence or header, no final newline)
+    and with pieces of a few hundred bytes so that many cuts fall inside the file."""
+    ds = small_dataset
+    real = [l.rstrip("\n") for l in open(ds["fasta"])]
+    tricky = str(tmp_path / "tricky.fa")
+    with open(tricky, "w") as f:
+        f.write("ACGTACGTACGTACGTACGTACGTACGTACGTAC\n")            # sequence before any header
+        f.write(">multi line record\n" + real[1][:70] + "\n\n" + real[1][70:] + "\nA\n")
+        f.write(">\n" + real[3] + "\n")                              # empty header
+        f.write(">no sequence at all\n>another without\n\n")
+        f.write(">x y z\tw\n" + real[5] + "\r\n")                    # CR kept as data, tab in the header
+        for i in range(7, 201, 2):
+            f.write(real[i - 1] + "\n" + "\n".join(real[i][j:j + 60] for j in range(0, len(real[i]), 60)) + "\n")
+        f.write(">last one without newline\n" + real[9])
+    for name, query in (("plain", ds["fasta"]), ("tricky", tricky)):
+        outs = []
+        for mode in ("file", "stdin", "pieces"):
+            out = str(tmp_path / f"{name}_{mode}")
+            args = [EXE, "-f", ds["idmap"], "-u", ds["names"], "-w", ds["rank"], "-x", "0", "-j", "30", "-l", "0", "-b", "1.0",
+                    "-e", ds["depth"], "-p", "-t", "1", "-i", "-" if mode == "stdin" else query, "-d", ds["db"], "-c", ds["tree"], "-o", out]
+            env = dict(os.environ, LMAT_FASTA_PIECE="300") if mode == "pieces" else dict(os.environ)
+            r = subprocess.run(args, capture_output=True, text=True, env=env, stdin=open(query) if mode == "stdin" else None)
+            assert r.returncode == 0, r.stderr + r.stdout
+            outs.append(open(out + "0.out").read() + open(out + ".0.30.fastsummary").read())  # (-t 1: shards cut every batch)
+        assert outs[0] == outs[1] == outs[2], name
+        assert "unknown_hdr:" in outs[0] or name == "plain"
