@@ -170,7 +170,7 @@ int lmat_classify_async(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, 
 int lmat_sync(lmat_ctx* ctx, float* kernel_ms_total, uint64_t* kernel_launches);
 /* HIP-event times accumulated by the launches the last lmat_sync waited for, split per kernel:
  * classify_ms = classify_kernel (extract + probe + registration/closure, the HBM-bound kernel),
- * decide_ms = k4_kernel (score + LCA decision) + the large-capacity re-run. */
+ * decide_ms = the K4 kernels (score + LCA decision) + the larger-class re-runs. */
 int lmat_last_timing(const lmat_ctx* ctx, float* classify_ms, float* decide_ms, uint64_t* launches);
 int lmat_results_fetch(lmat_ctx* ctx, uint64_t first, uint64_t count, lmat_read_result* results);
 

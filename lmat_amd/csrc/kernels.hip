@@ -3,7 +3,7 @@
 // One wavefront classifies one read end to end (k-mer extraction -> dedupe -> hash probe
 // -> taxid registration / lineage closure / counting -> score + LCA decision), keeping
 // all per-read state in LDS.  The k-mer database is an open-addressed hash in HBM probed
-// 8 lanes per 64-byte bucket.  No MFMA: this is a hash/gather path.
+// 4 lanes per 64-byte bucket (16 B each).  No MFMA: this is a hash/gather path.
 //
 // Reference semantics restated here (paths relative to the LMAT tree):
 //   K1 extract/canonical/dedupe   src/read_label.cpp:943-950, 978-1017
@@ -1433,7 +1433,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         return;
     }
     if (!INK4) {
-        // hand the read to k4_kernel (one lane per read): registration-ordered (taxid, count) table + cand
+        // hand the read to the K4 kernels (one lane per read): registration-ordered (taxid, count) table + cand
         if (nT > (uint32_t)kK4T) {
             if (lane == 0) {
                 emit(255, 0);

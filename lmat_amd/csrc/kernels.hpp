@@ -36,7 +36,7 @@ struct ClassifyArgs {
     NullModelDev nm;           // -n null models (active == 0: scores are plain k-mer fractions)
 };
 
-// record handed to k4_kernel: word0 = nT | cand << 16, word1 reserved, then K4T words reg | cnt << 16
+// record handed to the K4 kernels: word0 = nT | cand << 16, word1 reserved, then K4T words reg | cnt << 16
 static const int kK4T = 64;
 static const int kK4RecWords = 2 + kK4T;
 

@@ -14,7 +14,7 @@ namespace lmat {
 // slot (u64) = canonical k-mer (40 bits for k<=20) << 24 | payload (24 bits); 0 = empty.
 // payload 1..65535          : plain singleton, value = internal taxid index
 // payload 65536 + o         : taxid-list record at arena[2*o] (arena in u16 units)
-// bucket = 8 slots = 64 B = one HBM sector read by 8 lanes; linear probing over buckets.
+// bucket = 8 slots = 64 B = one HBM sector read by 4 lanes (16 B each); slots fill front to back; linear probing over buckets.
 static const int kPayloadBits = 24;
 static const uint32_t kPayloadMask = (1u << kPayloadBits) - 1;
 static const uint32_t kListBase = 65536;

@@ -145,7 +145,7 @@ struct lmat_ctx {
     uint64_t counts_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;   // around the classify kernel
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events2;  // around k4_kernel + large-capacity re-run
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events2;  // around the K4 kernels + the larger-class re-runs
     float kernel_ms_total = 0, kernel2_ms_total = 0, last_classify_ms = 0, last_decide_ms = 0;
     uint64_t last_launches = 0;
     uint64_t kernel_launches = 0;
