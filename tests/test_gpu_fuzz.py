@@ -15,7 +15,7 @@ def _blob(reads):
     return np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8), off
 
 
-@pytest.mark.parametrize("seed", list(range(32)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("LMAT_FUZZ_SEEDS", "32")))))  # LMAT_FUZZ_SEEDS=N for a longer soak
 def test_random_configuration_matches_oracle(seed, tmp_path):
     from lmat_amd import Engine, Params, synth
     import oracle_py
