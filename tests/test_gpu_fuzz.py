@@ -39,6 +39,11 @@ def test_random_configuration_matches_oracle(seed, tmp_path):
                 min_fnd_kmer=int(rng.choice([1, 3])))
     permissive = int(rng.integers(0, 4) == 0)
     use_map = bool(rng.integers(0, 4))  # one in four: database of 32-bit taxids, codes from the tree
+    null_models = k == 20 and int(rng.integers(0, 4)) == 0  # one in four of the 20-mer cases: log-odds scores (-n)
+    null_lst = None
+    if null_models:
+        null_lst = synth.write_null_models(os.path.join(str(tmp_path), "nm"), tax, seed=4004 + seed)
+        os.environ["LMAT_DIR"] = os.path.join(str(tmp_path), "nm")
     idmap = p["idmap"] if use_map else None
     eng = Engine(0, Params(opts["sdiff"], opts["hbias"], opts["min_score"], opts["min_kmer"], opts["min_fnd_kmer"], opts["prn_all"],
                            opts["screen_phix"]))
@@ -46,11 +51,15 @@ def test_random_configuration_matches_oracle(seed, tmp_path):
     if permissive:
         eng.set_label_modes(permissive=1)
     eng.build_db(p["db"], k=k)
+    if null_lst:
+        eng.load_null_models(null_lst)
     orc = oracle_py.Oracle(p["tree"], p["depth"], p["rank"], idmap)
     if permissive:
         orc.set_label_modes(permissive=1)
     orc.add_taxhisto(p["db"])
     orc.set_options(**opts)
+    if null_lst:
+        orc.load_null_models(null_lst)
     blob, off = _blob(seqs)
     dr = eng.upload_reads((blob, off))
     res, cands = eng.classify(dr, cand_cap=512 * len(seqs))
@@ -59,7 +68,7 @@ def test_random_configuration_matches_oracle(seed, tmp_path):
     if got != want:
         g, w = got.split("\n"), want.split("\n")
         bad = [(i, a, b) for i, (a, b) in enumerate(zip(g, w)) if a != b]
-        raise AssertionError(f"seed {seed} ({branching}, k={k}, {opts}, permissive={permissive}): {len(bad)} records differ; first: {bad[0]}")
+        raise AssertionError(f"seed {seed} ({branching}, k={k}, {opts}, permissive={permissive}, null_models={null_models}): {len(bad)} records differ; first: {bad[0]}")
     counts, nomatch = eng.counts()
     assert nomatch == nm
     assert {t: c for t, (c, s) in counts.items()} == {t: c for t, (c, s) in tally.items()}
