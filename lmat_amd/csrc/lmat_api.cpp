@@ -785,7 +785,8 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
     if (!c->d_gscratch)  // per-read tables of the global-memory class (very long reads, very large taxid tables)
         HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
-    if (!launch_classify(a, std::min<uint32_t>(reads->class_len, 2048 + 19), 0, c->stream))
+    // the fast classes end at 512 k-mers (531 bp at k = 20); longer reads ride the overflow list to the wave-per-read classes behind it
+    if (!launch_classify(a, std::min<uint32_t>(reads->class_len, 512 + (uint32_t)c->dev.k - 1), 0, c->stream))
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
