@@ -1732,19 +1732,22 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
 // Random 64-byte bucket gather with the probe's access shape (4 lanes x 16 B per bucket, 9 wave-loads = 144 buckets
 // in flight per wave): the practical ceiling of K2 on this table, and a known byte count to calibrate the
 // FETCH_SIZE counter against.
+template <int LPB>  // lanes per probe: 4 = one 64-byte bucket (the probe's shape), 8 = an aligned 128-byte pair of buckets
 __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __restrict__ slots, uint32_t nbuckets,
                                                           uint64_t probes_per_wave, uint64_t seed,
                                                           unsigned long long* sink) {
-    const int lane = threadIdx.x & 63, g4 = lane >> 2, q4 = lane & 3;
+    const int lane = threadIdx.x & 63, g = lane / LPB, q = lane % LPB;
+    constexpr int PPL = 64 / LPB;  // probes per wave-load
     const GAS u32x4* quarters = (const GAS u32x4*)slots;
     unsigned long long acc = 0;
     uint64_t ctr = (uint64_t)blockIdx.x * probes_per_wave;
-    for (uint64_t i = 0; i < probes_per_wave; i += 144) {
+    for (uint64_t i = 0; i < probes_per_wave; i += 9 * PPL) {
         u32x4 sl[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const uint32_t b = bucket_of(seed + ctr + i + j * 16 + g4, nbuckets);
-            sl[j] = quarters[(uint64_t)b * 4 + q4];
+            uint32_t b = bucket_of(seed + ctr + i + j * PPL + g, nbuckets);
+            if (LPB == 8) b &= ~1u;
+            sl[j] = quarters[(uint64_t)b * 4 + q];
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) acc += (sl[j].x >> 13) + sl[j].w;
@@ -1840,10 +1843,15 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
 }
 
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,
-                         unsigned long long* sink, hipStream_t stream) {
+                         unsigned long long* sink, hipStream_t stream, int bytes_per_probe) {
     const int grid = 256 * 16;
-    const uint64_t per_wave = (n_probes / grid + 143) / 144 * 144;
-    gather_bench_kernel<<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
+    if (bytes_per_probe == 128) {
+        const uint64_t per_wave = (n_probes / grid + 71) / 72 * 72;
+        gather_bench_kernel<8><<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
+    } else {
+        const uint64_t per_wave = (n_probes / grid + 143) / 144 * 144;
+        gather_bench_kernel<4><<<dim3(grid), dim3(64), 0, stream>>>(slots, nbuckets, per_wave, seed, sink);
+    }
 }
 
 // The LDS kernel (5 waves per CU, LDS-bound) and the scratch kernel (64 VGPRs, latency-bound on HBM) fit a CU side by

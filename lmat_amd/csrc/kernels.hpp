@@ -62,7 +62,7 @@ int classify_max_read_len();
 size_t classify_gmem_scratch_bytes();
 // issues ~n_probes random bucket reads (rounded up to 144 per wave x 4096 waves)
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,
-                         unsigned long long* sink, hipStream_t stream);
+                         unsigned long long* sink, hipStream_t stream, int bytes_per_probe = 64);
 
 
 // host-callable copies of the synthetic genome functions (tests / oracle cross-checks)

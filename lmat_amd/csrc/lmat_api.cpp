@@ -1075,15 +1075,16 @@ int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, 
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    launch_gather_bench(c->dev.slots, c->dev.nbuckets, n_probes, seed, sink, c->stream);
+    const int bpp = getenv("LMAT_GATHER_BYTES") && atoi(getenv("LMAT_GATHER_BYTES")) == 128 ? 128 : 64;  // experiment: aligned 128-byte requests
+    launch_gather_bench(c->dev.slots, c->dev.nbuckets, n_probes, seed, sink, c->stream, bpp);
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float t = 0;
     HIPCHK(c, hipEventElapsedTime(&t, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink);
     if (ms) *ms = t;
-    const uint64_t per_wave = (n_probes / 4096 + 143) / 144 * 144;
-    if (bytes) *bytes = per_wave * 4096 * 64;
+    const uint64_t per_wave = bpp == 128 ? (n_probes / 4096 + 71) / 72 * 72 : (n_probes / 4096 + 143) / 144 * 144;
+    if (bytes) *bytes = per_wave * 4096 * (uint64_t)bpp;
     return LMAT_OK;
 }
 
