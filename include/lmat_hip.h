@@ -165,7 +165,9 @@ int lmat_classify(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64
 
 /* Same kernels, results left in device memory (throughput runs).  Asynchronous on
  * the context's stream; lmat_sync waits.  kernel_ms_total (may be NULL) = HIP-event time of
- * all kernels of those launches; lmat_last_timing splits it per kernel. */
+ * all kernels of those launches; lmat_last_timing splits it per kernel.  The device-side result
+ * buffer holds the records of the most recent launch only (lmat_results_fetch reads those); the
+ * tallies accumulate over all launches. */
 int lmat_classify_async(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count);
 int lmat_sync(lmat_ctx* ctx, float* kernel_ms_total, uint64_t* kernel_launches);
 /* HIP-event times accumulated by the launches the last lmat_sync waited for, split per kernel:
