@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--db-gb", type=float, default=64.0, help="hash table size in GiB (BASELINE metric: 64)")
     ap.add_argument("--batch", type=int, default=2_000_000, help="reads per step per GPU")
-    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--read-len", default="150", help="read length, or a comma list for a mixed-length batch (not the headline workload)")
     ap.add_argument("--cpu-sample", type=int, default=40000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -151,7 +151,9 @@ def main():
     log(f"db built: {eng.db_size} k-mers in {t_build:.2f}s, table {table_bytes / 2**30:.1f} GiB, G={G}")
     n_steps_total = args.steps + args.warmup
     n_reads = args.batch * n_steps_total
-    reads = eng.synth_reads(n_reads, (args.read_len,), seed=3003 + 7919 * rank)
+    read_lens = tuple(int(x) for x in str(args.read_len).split(","))
+    args.read_len = read_lens[0] if len(read_lens) == 1 else "/".join(str(x) for x in read_lens)
+    reads = eng.synth_reads(n_reads, read_lens, seed=3003 + 7919 * rank)
     log(f"{n_reads} reads generated ({reads.device_bytes / 2**20:.0f} MiB packed)")
 
     def barrier():

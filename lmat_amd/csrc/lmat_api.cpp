@@ -613,6 +613,7 @@ int lmat_reads_upload(lmat_ctx* c, const uint8_t* bases, const uint64_t* off, ui
     }
     int rc = reads_alloc(c, rec_off, max_len, out);
     if (rc) return rc;
+    (*out)->lens = lens;
     (*out)->class_len = bulk_length(lens);
     if (!n) return LMAT_OK;
     uint8_t* d_b = nullptr;
@@ -633,16 +634,19 @@ int lmat_reads_synth(lmat_ctx* c, uint64_t n, const uint32_t* lengths, uint32_t 
     hipSetDevice(c->device);
     // the kernel picks lengths[(h>>48) % n_lengths]; offsets must match, so mirror that choice here
     std::vector<uint64_t> rec_off(n + 1, 0);
+    std::vector<uint32_t> lens(n);
     uint32_t max_len = 0;
     for (uint64_t r = 0; r < n; ++r) {
         const uint64_t h0 = splitmix(seed ^ (r * 0x9E3779B97F4A7C15ull));
         const uint32_t len = lengths[(uint32_t)((h0 >> 48) % n_lengths)];
+        lens[r] = len;
         max_len = std::max(max_len, len);
         rec_off[r + 1] = rec_off[r] + rec_words(len);
     }
     int rc = reads_alloc(c, rec_off, max_len, out);
     if (rc) return rc;
     (*out)->class_len = max_len;  // a handful of configured lengths: no tail to cut
+    (*out)->lens.swap(lens);
     uint32_t* d_len = nullptr;
     HIPCHK(c, hipMalloc((void**)&d_len, n_lengths * 4));
     HIPCHK(c, hipMemcpyAsync(d_len, lengths, n_lengths * 4, hipMemcpyHostToDevice, c->stream));
@@ -685,6 +689,7 @@ void lmat_reads_free(lmat_ctx* c, lmat_reads* r) {
     if (c) hipSetDevice(c->device);
     if (r->words) hipFree(r->words);
     if (r->rec_off) hipFree(r->rec_off);
+    for (int j = 0; j < 3; ++j) if (r->cls_dev[j]) hipFree(r->cls_dev[j]);
     delete r;
 }
 
@@ -785,9 +790,46 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
     if (!c->d_gscratch)  // per-read tables of the global-memory class (very long reads, very large taxid tables)
         HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
-    // the fast classes end at 512 k-mers (531 bp at k = 20); longer reads ride the overflow list to the wave-per-read classes behind it
-    if (!launch_classify(a, std::min<uint32_t>(reads->class_len, 512 + (uint32_t)c->dev.k - 1), 0, c->stream))
-        return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+    // Each read runs in the smallest fast class that holds it (160 / 256 / 512 k-mers; 512 = 531 bp at k = 20); longer
+    // reads ride the overflow list to the wave-per-read classes behind it.  A batch of one class is one plain launch.
+    {
+        lmat_reads* rw = const_cast<lmat_reads*>(reads);
+        const uint32_t k = (uint32_t)c->dev.k;
+        if (rw->cls_k != (int)k && rw->lens.size() == rw->n) {
+            for (int j = 0; j < 3; ++j) { rw->cls_host[j].clear(); if (rw->cls_dev[j]) { hipFree(rw->cls_dev[j]); rw->cls_dev[j] = nullptr; } }
+            for (uint64_t i = 0; i < rw->n; ++i) {
+                const uint32_t P = rw->lens[i] >= k ? rw->lens[i] - k + 1 : 0;
+                rw->cls_host[P <= 160 ? 0 : (P <= 256 ? 1 : 2)].push_back((uint32_t)i);
+            }
+            int used = 0;
+            for (int j = 0; j < 3; ++j) used += !rw->cls_host[j].empty();
+            if (used > 1)
+                for (int j = 0; j < 3; ++j)
+                    if (!rw->cls_host[j].empty()) {
+                        HIPCHK(c, hipMalloc((void**)&rw->cls_dev[j], rw->cls_host[j].size() * 4));
+                        HIPCHK(c, hipMemcpyAsync(rw->cls_dev[j], rw->cls_host[j].data(), rw->cls_host[j].size() * 4, hipMemcpyHostToDevice, c->stream));
+                    }
+            rw->cls_k = (int)k;
+        }
+        const uint32_t cls_len[3] = {160 + k - 1, 256 + k - 1, 512 + k - 1};
+        bool mixed = rw->cls_dev[0] || rw->cls_dev[1] || rw->cls_dev[2];
+        if (!mixed) {
+            if (!launch_classify(a, std::min<uint32_t>(reads->max_len, 512 + k - 1), 0, c->stream))
+                return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+        } else {
+            for (int j = 0; j < 3; ++j) {
+                const std::vector<uint32_t>& v = rw->cls_host[j];
+                const size_t lo = std::lower_bound(v.begin(), v.end(), (uint32_t)first) - v.begin();
+                const size_t hi = std::lower_bound(v.begin(), v.end(), (uint32_t)(first + count)) - v.begin();
+                if (hi == lo) continue;
+                ClassifyArgs s = a;
+                s.index = rw->cls_dev[j] + lo;
+                s.count = hi - lo;
+                if (!launch_classify(s, cls_len[j], 0, c->stream))
+                    return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+            }
+        }
+    }
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipEventRecord(e2, c->stream));

@@ -84,7 +84,13 @@ struct lmat_reads {
     uint64_t n = 0;
     uint64_t n_words = 0;
     uint32_t max_len = 0;
-    uint32_t class_len = 0;       // length that all but the longest 1 % of the reads stay under: picks the fast kernel class
+    uint32_t class_len = 0;       // length that all but the longest 1 % of the reads stay under
+    // Length classes of the fast kernel (k-mer capacities 160 / 256 / 512): read indices per class, ascending, so a
+    // mixed-length batch runs each read in the smallest class that holds it.  Built on first use for the database's k.
+    std::vector<uint32_t> lens;
+    std::vector<uint32_t> cls_host[3];
+    uint32_t* cls_dev[3] = {nullptr, nullptr, nullptr};
+    int cls_k = 0;
 };
 
 struct lmat_ingest {
