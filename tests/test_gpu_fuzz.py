@@ -23,7 +23,10 @@ def test_random_configuration_matches_oracle(seed, tmp_path):
     branching = tuple(int(rng.integers(1, 4)) for _ in range(4)) + (int(rng.integers(2, 4)), int(rng.integers(1, 5)))
     k = int(rng.choice([16, 18, 20, 20]))
     G = int(rng.integers(300, 1500))
-    lens = [int(x) for x in rng.choice([40, 75, 100, 150, 151, 179, 180, 250, 300, 531, 600], size=4)]
+    pool = [40, 75, 100, 150, 151, 179, 180, 250, 300, 531, 600]
+    if os.environ.get("LMAT_FUZZ_LONG"):  # soak option: contig-length reads reach the 2048-k-mer and the global-memory classes
+        pool += [1500, 2067, 2068, 5000]
+    lens = [int(x) for x in rng.choice(pool, size=4)]
     tax = synth.make_taxonomy(branching, specials=bool(rng.integers(0, 2)))
     p = synth.write_aux_files(str(tmp_path), tax)
     genomes = synth.make_genomes(tax, G, 2002 + seed, strain_sub=float(rng.choice([0.002, 0.01, 0.05])),
