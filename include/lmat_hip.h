@@ -225,6 +225,12 @@ int lmat_db_from_ingest(lmat_ctx* ctx, lmat_ingest* ing, uint64_t table_bytes);
  * reports the HIP-event time and the bytes it read (the practical ceiling of the probe). */
 int lmat_gather_bench(lmat_ctx* ctx, uint64_t n_probes, uint64_t seed, float* ms, uint64_t* bytes);
 
+/* Where the compact table layout files a k-mer (forward-encoded, either strand): bucket index and 16-bit slot tag
+ * for a table of about want_buckets buckets; *n_buckets = the bucket count actually used (the 16-bit tag sets a
+ * minimum).  (bucket, tag) <-> canonical k-mer is a bijection; tests check exactly that.  Needs no device.
+ * LMAT_E_ARG when this k has no compact layout (k < 10). */
+int lmat_table_address(int k, uint64_t want_buckets, uint64_t kmer, uint64_t* n_buckets, uint32_t* bucket, uint32_t* tag);
+
 /* ---- record text -------------------------------------------------------------
  * The bytes read_label writes to a .out file for these results (prefix
  * read_label.cpp:1733-1738, body :844-848,894-937,1218,1233,1271).  Headers are

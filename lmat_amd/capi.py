@@ -100,6 +100,7 @@ def load_library(path: str | None = None):
         "lmat_counts_device_ptr": (vp, [vp]),
         "lmat_counts_get": (i32, [vp, vp, vp, vp, u32, P(u32), vp]),
         "lmat_gather_bench": (i32, [vp, u64, u64, P(C.c_float), P(u64)]),
+        "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
     }
     for name, (res, args) in sig.items():
@@ -121,7 +122,7 @@ EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
-            "lmat_format_out"]
+            "lmat_table_address", "lmat_format_out"]
 
 
 def _ptr(a):

@@ -1130,7 +1130,18 @@ int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, 
     return LMAT_OK;
 }
 
-// experiment hook (not in the public header): burst-structured gather
+int lmat_table_address(int k, uint64_t want_buckets, uint64_t kmer, uint64_t* n_buckets, uint32_t* bucket, uint32_t* tag) {
+    const CptGeom g = cpt_geometry(k, want_buckets);
+    if (n_buckets) *n_buckets = g.nb;
+    if (!g.nb) return LMAT_E_ARG;
+    if (k < 32 && (kmer >> (2 * k))) return LMAT_E_ARG;
+    const uint64_t r = revcomp_fwd(kmer, k);
+    uint32_t b = 0, t = 0;
+    cpt_address(g, kmer < r ? kmer : r, kmer < r ? r : kmer, b, t);
+    if (bucket) *bucket = b;
+    if (tag) *tag = t;
+    return LMAT_OK;
+}
 
 int64_t lmat_format_out(const lmat_ctx* c, const lmat_read_result* results, uint64_t n, const lmat_cand* cands,
                         const uint8_t* bases, const uint64_t* off, int prn_read, uint64_t first_index, char* buf,

@@ -52,6 +52,110 @@ LM_HD uint32_t bucket_of(uint64_t kmer, uint32_t nbuckets) {
 #endif
 }
 
+// ---- compact table: minimizer-addressed quotient buckets --------------------------------------
+// The default layout of large tables (any table the tag width allows, see cpt_geometry).  A k-mer is filed under its
+// MINIMIZER: the canonical m-mer (m = k - 3, so w = 4 m-mers per k-mer) that is smallest under a scrambled order.
+// Consecutive k-mers of a read (and of a genome) mostly share their minimizer, so they land in the same 64-byte
+// bucket: a 150 bp read touches ~53 buckets instead of 131.  The bucket index consumes most of the minimizer's
+// bits (quotienting), so a slot needs only a 16-bit tag beside its 24-bit payload:
+//   bucket (64 B) = tag u16[12] | payload low u16[12] | payload high u8[12] | header u32
+//   header: bits 0..23 insert counter, bit 31 = a k-mer of this bucket lives in the overflow table
+//   tag = 1 + ((((rho << lowbits | low) * 4 + j) * 2 + strand) * 64 + other), 0 = empty slot, where
+//     S'     = mix(scramble(minimizer))  (bijective on 2m bits),  hi = S' >> lowbits, low = S' & (2^lowbits - 1)
+//     bucket = hi / W,  rho = hi mod W   (W = width of a bucket in hi-space, a run-time integer)
+//     j      = position of the minimizer inside the canonical k-mer, strand = the m-mer there is the larger of its pair
+//     other  = the k-mer's 3 bases outside the minimizer
+//   (bucket, tag) <-> canonical k-mer is a bijection, so a tag match is an exact key match.
+// 12 slots at ~10 bytes per k-mer is a load of ~0.5: a k-mer whose bucket is full goes to a small overflow table in
+// the wide (8 x 64-bit slot) layout above, keyed by the full k-mer; the header bit tells lookups to go there.
+static const int kCptSlots = 12;
+static const int kCptW = 4;                       // m-mers per k-mer
+static const uint32_t kCptOvfFlag = 0x80000000u;
+static const uint32_t kCptCountMask = 0x00FFFFFFu;
+
+struct CptGeom {
+    uint32_t nb = 0;       // buckets; 0 = the table is in the wide layout
+    uint32_t W = 0;        // bucket width in hi-space
+    double invW = 0;       // 1.0 / W
+    int k = 0, m = 0, lowbits = 0;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LM_MUL24(a, b) __umul24((a), (b))
+#else
+#define LM_MUL24(a, b) ((uint32_t)(a) * (uint32_t)(b))
+#endif
+
+// four Feistel rounds on the two m-bit halves of a 2m-bit value (m <= 17): a bijection whatever the round function
+LM_HD uint64_t cpt_feistel(uint64_t x, int m, uint32_t ka, uint32_t kb, uint32_t kc, uint32_t kd) {
+    const uint32_t mm = (1u << m) - 1;
+    uint32_t L = (uint32_t)(x >> m), R = (uint32_t)x & mm;
+    L ^= (LM_MUL24(R, ka) >> 7) & mm;  // R < 2^17, ka < 2^15: the product stays below 2^32
+    R ^= (LM_MUL24(L, kb) >> 7) & mm;
+    L ^= (LM_MUL24(R, kc) >> 7) & mm;
+    R ^= (LM_MUL24(L, kd) >> 7) & mm;
+    return ((uint64_t)L << m) | R;
+}
+LM_HD uint64_t cpt_scramble(uint64_t y, int m) { return cpt_feistel(y, m, 0x6A09u, 0x3B67u, 0x5F1Du, 0x7C15u); }  // minimizer order
+LM_HD uint64_t cpt_mix(uint64_t s, int m) { return cpt_feistel(s, m, 0x52DBu, 0x4F6Du, 0x6E2Bu, 0x35A7u); }       // bucket hash
+
+// reverse complement of a forward-encoded k-mer (first base in the high bits)
+LM_HD uint64_t revcomp_fwd(uint64_t fwd, int k) {
+    uint64_t x = ~fwd;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * k);
+}
+
+// geometry for a table of about want_buckets buckets; nb == 0 when the compact layout cannot hold this k / size
+// (then the caller uses the wide layout).  min_buckets: the smallest table the 16-bit tag allows for this k.
+LM_HD CptGeom cpt_geometry(int k, uint64_t want_buckets) {
+    CptGeom g;
+    if (k < 10 || k > 20) return g;
+    const int m = k - (kCptW - 1), n = 2 * m;
+    const int lowbits = n > 32 ? n - 32 : 0;
+    const uint64_t space = 1ull << (n - lowbits);        // hi-space
+    const uint64_t wmax = 127u >> lowbits;               // (W << lowbits) * 512 + 1 <= 65536
+    if (want_buckets < 1) want_buckets = 1;
+    uint64_t W = space / want_buckets;                   // floor: never fewer buckets than asked for
+    if (W < 1) W = 1;
+    if (W > wmax) W = wmax;
+    const uint64_t nb = (space + W - 1) / W;
+    if (nb > 0xFFFFFFFFull) return g;
+    g.nb = (uint32_t)nb; g.W = (uint32_t)W; g.invW = 1.0 / (double)W; g.k = k; g.m = m; g.lowbits = lowbits;
+    return g;
+}
+
+// canonical k-mer c (c <= cr, cr = its reverse complement, both forward-encoded) -> bucket and tag
+LM_HD void cpt_address(const CptGeom& g, uint64_t c, uint64_t cr, uint32_t& bucket, uint32_t& tag) {
+    const int m = g.m;
+    const uint64_t mmask = (1ull << (2 * m)) - 1;
+    uint64_t best = ~0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < kCptW; ++j) {
+        const uint64_t x = (c >> (2 * (kCptW - 1 - j))) & mmask;  // m-mer j of the canonical k-mer
+        const uint64_t xr = (cr >> (2 * j)) & mmask;              // its reverse complement
+        const uint64_t y = x < xr ? x : xr;
+        const uint64_t v = (cpt_scramble(y, m) << 3) | ((uint64_t)j << 1) | (xr < x ? 1u : 0u);
+        best = v < best ? v : best;                                // equal minimizers: the smaller j
+    }
+    const int j = (int)(best >> 1) & 3;
+    const uint64_t sp = cpt_mix(best >> 3, m);
+    const uint32_t hi = (uint32_t)(sp >> g.lowbits), low = (uint32_t)sp & ((1u << g.lowbits) - 1);
+    // hi / W, exact: (hi + 0.5) / W is never within 2^-8 of an integer and the double product is good to 2^-20
+    const uint32_t b = (uint32_t)(((double)hi + 0.5) * g.invW);
+    const uint32_t rho = hi - b * g.W;
+    const int rs = 2 * (kCptW - 1 - j);                            // bits of the k-mer right of the minimizer
+    const uint32_t other = (uint32_t)((c >> (2 * m + rs)) << rs) | ((uint32_t)c & ((1u << rs) - 1));
+    bucket = b;
+    tag = 1 + (((((rho << g.lowbits) | low) * 4 + (uint32_t)j) * 2 + ((uint32_t)best & 1u)) * 64 + other);
+}
+
 // ---- packed read record (4-byte words) ---------------------------------------------------
 //   word 0: length in bases; then ceil(len/16) words of 2-bit codes (base j at bits 2*(j%16)),
 //   then ceil(len/32) words of validity bits (1 = ACGT).
