@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t* __restri
 // DB build: insert (k-mer, payload) pairs.  Equal keys keep the smaller payload, which makes
 // the synthetic generator deterministic; ingested files never repeat a key.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool hash_insert(uint64_t* slots, uint32_t nbuckets, uint64_t kmer, uint32_t payload) {
+// wide layout: 8 x (k-mer << 24 | payload) per bucket, linear probing over buckets from b
+__device__ __forceinline__ bool wide_insert(uint64_t* slots, uint32_t nbuckets, uint32_t b, uint64_t kmer, uint32_t payload) {
     const uint64_t val = (kmer << kPayloadBits) | payload;
-    uint32_t b = bucket_of(kmer, nbuckets);
     for (uint32_t tries = 0; tries < nbuckets; ++tries) {
         unsigned long long* s = (unsigned long long*)(slots + (uint64_t)b * kSlotsPerBucket);
         for (int j = 0; j < kSlotsPerBucket; ++j) {
@@ -131,13 +131,131 @@ __device__ __forceinline__ bool hash_insert(uint64_t* slots, uint32_t nbuckets, 
     }
     return false;
 }
+__device__ __forceinline__ uint32_t wide_lookup(const uint64_t* __restrict__ slots, uint32_t nbuckets, uint32_t b, uint64_t kmer) {
+    for (uint32_t tries = 0; tries < nbuckets; ++tries) {
+        const uint64_t* s = slots + (uint64_t)b * kSlotsPerBucket;
+        bool empty = false;
+        for (int j = 0; j < kSlotsPerBucket; ++j) {
+            const uint64_t v = s[j];
+            if (v == 0) empty = true;
+            else if ((v >> kPayloadBits) == kmer) return (uint32_t)(v & kPayloadMask);
+        }
+        if (empty) return 0;
+        b = b + 1 == nbuckets ? 0 : b + 1;
+    }
+    return 0;
+}
+// where the overflow table of a compact table files a k-mer: a cheap function of its compact address
+__device__ __forceinline__ uint32_t ovf_bucket_of(uint32_t bucket, uint32_t tag, uint32_t nbuckets) {
+    uint32_t h = (bucket ^ (tag << 16) ^ (tag >> 3)) * 0x9E3779B1u;
+    h ^= h >> 15;
+    return __umulhi(h, nbuckets);
+}
 
-__global__ void insert_pairs_kernel(uint64_t* slots, uint32_t nbuckets, const uint64_t* __restrict__ kmers,
+// compact layout (lmat_common.hpp).  Only canonical k-mers (kmer <= its reverse complement) live in the buckets: the
+// address is a function of the strand pair, so a non-canonical key -- a database may hold one, SortedDb::begin_
+// would find it only when asked for exactly that word -- goes to the overflow table, which stores full keys.
+__device__ __forceinline__ bool table_insert(const DeviceTables& tb, uint64_t kmer, uint32_t payload) {
+    if (!tb.cpt.nb) return wide_insert(tb.slots, tb.nbuckets, bucket_of(kmer, tb.nbuckets), kmer, payload);
+    const uint64_t rc = revcomp_fwd(kmer, tb.cpt.k);
+    uint32_t b, tag;
+    cpt_address(tb.cpt, kmer < rc ? kmer : rc, kmer < rc ? rc : kmer, b, tag);
+    uint32_t* bk = (uint32_t*)tb.slots + (uint64_t)b * 16;
+    if (kmer <= rc) {
+        const uint32_t i = atomicAdd(&bk[15], 1u) & kCptCountMask;
+        if (i < (uint32_t)kCptSlots) {
+            ((uint16_t*)bk)[12 + i] = (uint16_t)payload;
+            ((uint8_t*)bk)[48 + i] = (uint8_t)(payload >> 16);
+            ((uint16_t*)bk)[i] = (uint16_t)tag;
+            return true;
+        }
+    }
+    atomicOr(&bk[15], kCptOvfFlag);
+    return wide_insert(tb.ovf_slots, tb.ovf_nbuckets, ovf_bucket_of(b, tag, tb.ovf_nbuckets), kmer, payload);
+}
+__device__ __forceinline__ uint32_t table_lookup(const DeviceTables& tb, uint64_t kmer) {
+    if (!tb.cpt.nb) return wide_lookup(tb.slots, tb.nbuckets, bucket_of(kmer, tb.nbuckets), kmer);
+    const uint64_t rc = revcomp_fwd(kmer, tb.cpt.k);
+    uint32_t b, tag;
+    cpt_address(tb.cpt, kmer < rc ? kmer : rc, kmer < rc ? rc : kmer, b, tag);
+    const uint32_t* bk = (const uint32_t*)tb.slots + (uint64_t)b * 16;
+    if (kmer <= rc) {
+        for (int i = 0; i < kCptSlots; ++i)
+            if (((const uint16_t*)bk)[i] == (uint16_t)tag)
+                return (uint32_t)((const uint16_t*)bk)[12 + i] | ((uint32_t)((const uint8_t*)bk)[48 + i] << 16);
+    }
+    if (!(bk[15] & kCptOvfFlag)) return 0;
+    return wide_lookup(tb.ovf_slots, tb.ovf_nbuckets, ovf_bucket_of(b, tag, tb.ovf_nbuckets), kmer);
+}
+
+__global__ void insert_pairs_kernel(DeviceTables tb, const uint64_t* __restrict__ kmers,
                                     const uint32_t* __restrict__ payload, uint64_t n, uint32_t* fail) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride)
-        if (!hash_insert(slots, nbuckets, kmers[i], payload[i])) atomicAdd(fail, 1u);
+        if (!table_insert(tb, kmers[i], payload[i])) atomicAdd(fail, 1u);
+}
+
+// After a build of the compact layout, per bucket: two inserts of one key that raced into the same bucket are merged
+// (smaller payload wins, as in the wide layout), the insert counter becomes the slot count, and the slots in use are
+// summed into *total.  One thread per bucket.
+__global__ void cpt_tidy_kernel(DeviceTables tb, unsigned long long* total) {
+    uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long local = 0;
+    for (; b < tb.cpt.nb; b += stride) {
+        uint32_t* bk = (uint32_t*)tb.slots + b * 16;
+        const uint32_t hdr = bk[15];
+        uint32_t n = hdr & kCptCountMask;
+        if (n > (uint32_t)kCptSlots) n = kCptSlots;
+        uint16_t* tg = (uint16_t*)bk;
+        uint8_t* ph = (uint8_t*)bk + 48;
+        bool changed = false;
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t j = i + 1; j < n;) {
+                if (tg[i] != tg[j]) { ++j; continue; }
+                const uint32_t pi = (uint32_t)tg[12 + i] | ((uint32_t)ph[i] << 16), pj = (uint32_t)tg[12 + j] | ((uint32_t)ph[j] << 16);
+                if (pj < pi) { tg[12 + i] = (uint16_t)pj; ph[i] = (uint8_t)(pj >> 16); }
+                --n;  // the last slot moves into the hole
+                tg[j] = tg[n]; tg[12 + j] = tg[12 + n]; ph[j] = ph[n];
+                tg[n] = 0; tg[12 + n] = 0; ph[n] = 0;
+                changed = true;
+            }
+        if (changed || (hdr & kCptCountMask) != n) bk[15] = (hdr & kCptOvfFlag) | n;
+        local += n;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, local);
+}
+// ... and per overflow entry: a key that is also in its home bucket (a second insert of it arrived after the bucket
+// filled up) is merged into the bucket copy -- the one lookups find -- and not counted; the others add to *total.
+__global__ void cpt_merge_overflow_kernel(DeviceTables tb, unsigned long long* total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, nslots = (uint64_t)tb.ovf_nbuckets * kSlotsPerBucket;
+    unsigned long long local = 0;
+    for (; i < nslots; i += stride) {
+        const uint64_t v = tb.ovf_slots[i];
+        if (!v) continue;
+        const uint64_t kmer = v >> kPayloadBits;
+        const uint32_t pay = (uint32_t)(v & kPayloadMask);
+        const uint64_t rc = revcomp_fwd(kmer, tb.cpt.k);
+        bool merged = false;
+        if (kmer <= rc) {
+            uint32_t b, tag;
+            cpt_address(tb.cpt, kmer, rc, b, tag);
+            uint16_t* tg = (uint16_t*)((uint32_t*)tb.slots + (uint64_t)b * 16);
+            uint8_t* ph = (uint8_t*)tg + 48;
+            for (int s = 0; s < kCptSlots; ++s)
+                if (tg[s] == (uint16_t)tag) {
+                    const uint32_t ps = (uint32_t)tg[12 + s] | ((uint32_t)ph[s] << 16);
+                    if (pay < ps) { tg[12 + s] = (uint16_t)pay; ph[s] = (uint8_t)(pay >> 16); }
+                    merged = true;
+                }
+        }
+        local += merged ? 0 : 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, local);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -160,19 +278,12 @@ __host__ __device__ __forceinline__ bool synth_strain_mut(uint64_t seed, uint32_
     return (h % 100) == 0;
 }
 __host__ __device__ __forceinline__ uint64_t canon_from_fwd(uint64_t fwd, int k) {
-    // reverse complement of a forward-encoded k-mer (first base in the high bits)
-    uint64_t x = ~fwd;
-    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
-    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
-    x = (x >> 32) | (x << 32);
-    x >>= (64 - 2 * k);
+    const uint64_t x = revcomp_fwd(fwd, k);
     return fwd < x ? fwd : x;
 }
 
 // one thread per (species, window start); S strains per species (S <= 8)
-__global__ void synth_db_kernel(uint64_t* slots, uint32_t nbuckets, uint64_t seed, uint32_t n_species, uint32_t S,
+__global__ void synth_db_kernel(DeviceTables tb, uint64_t seed, uint32_t n_species, uint32_t S,
                                 uint64_t G, int k, const uint16_t* __restrict__ strain_idx,
                                 const uint32_t* __restrict__ list_payload /*[species*(1<<S)+mask]*/, uint32_t* fail,
                                 unsigned long long* inserted) {
@@ -196,12 +307,12 @@ __global__ void synth_db_kernel(uint64_t* slots, uint32_t nbuckets, uint64_t see
             } else {
                 uint64_t f = 0;
                 for (int j = 0; j < k; ++j) f = (f << 2) | synth_strain_base(seed, sp, sg, pos + j);
-                if (!hash_insert(slots, nbuckets, canon_from_fwd(f, k), strain_idx[sg])) atomicAdd(fail, 1u);
+                if (!table_insert(tb, canon_from_fwd(f, k), strain_idx[sg])) atomicAdd(fail, 1u);
                 ++local;
             }
         }
         if (mask) {
-            if (!hash_insert(slots, nbuckets, canon_from_fwd(anc, k), list_payload[(uint64_t)sp * (1u << S) + mask]))
+            if (!table_insert(tb, canon_from_fwd(anc, k), list_payload[(uint64_t)sp * (1u << S) + mask]))
                 atomicAdd(fail, 1u);
             ++local;
         }
@@ -274,27 +385,11 @@ __global__ void synth_reads_kernel(uint32_t* words, const uint64_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // TaxNodeStat-style lookup for tests and tooling: one thread per k-mer.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t probe_scalar(const uint64_t* __restrict__ slots, uint32_t nbuckets, uint64_t kmer) {
-    uint32_t b = bucket_of(kmer, nbuckets);
-    for (uint32_t tries = 0; tries < nbuckets; ++tries) {
-        const uint64_t* s = slots + (uint64_t)b * kSlotsPerBucket;
-        bool empty = false;
-        for (int j = 0; j < kSlotsPerBucket; ++j) {
-            const uint64_t v = s[j];
-            if (v == 0) empty = true;
-            else if ((v >> kPayloadBits) == kmer) return (uint32_t)(v & kPayloadMask);
-        }
-        if (empty) return 0;
-        b = b + 1 == nbuckets ? 0 : b + 1;
-    }
-    return 0;
-}
-
 __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmers, uint64_t n, uint32_t* counts,
                               uint32_t* tids, uint32_t stride) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t pay = probe_scalar(tb.slots, tb.nbuckets, kmers[i]);
+    const uint32_t pay = table_lookup(tb, kmers[i]);
     if (pay == 0) { counts[i] = 0; return; }
     if (pay < kListBase) {
         counts[i] = 1;
@@ -350,7 +445,18 @@ struct WL {
     static constexpr int OFF_R1 = ((RD_WORDS * 4 + 15) / 16) * 16;
     static constexpr int OFF_R2 = OFF_R1 + ((R1 + 15) / 16) * 16;
     static constexpr int OFF_R3 = OFF_R2 + ((R2 + 15) / 16) * 16;
-    static constexpr int BYTES = OFF_R3 + ((R3 + 15) / 16) * 16;
+    static constexpr int BYTES_BASE = OFF_R3 + ((R3 + 15) / 16) * 16;
+    // compact-layout probe: a block of real LDS [bucket stage 4096 | repeat filter 1024 | overflow-probe list 1024].
+    // Classes that keep a read's k-mers in registers (U <= 512) overlay it on R1..R3, which are idle until the probe is
+    // done; the others get it behind their tables (the global-memory class keeps nothing else in LDS).
+    static constexpr int XL_BYTES = 6144;
+    static constexpr bool XL_OVERLAY = U <= 512;
+    static constexpr int OFF_XL = XL_OVERLAY ? OFF_R1 : BYTES_BASE;
+    // payload per k-mer position (compact) / per distinct k-mer (wide): at R3, or behind the block where that overlaps R3
+    static constexpr int OFF_UPAY_C = XL_OVERLAY && OFF_R1 + XL_BYTES > OFF_R3 ? OFF_R1 + XL_BYTES : OFF_R3;
+    static constexpr int BYTES_C = XL_OVERLAY ? (OFF_UPAY_C + 4 * U > BYTES_BASE ? ((OFF_UPAY_C + 4 * U + 15) / 16) * 16 : BYTES_BASE)
+                                              : BYTES_BASE + XL_BYTES;
+    static constexpr int BYTES = BYTES_BASE;
 };
 
 static const uint64_t kEmpty64 = ~0ull;
@@ -689,8 +795,8 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
 #pragma push_macro("WSYNC")
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
-template <int U, int T, int E, bool INK4, bool PERM>
-__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, int lane,
+template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
+__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, unsigned char* xl, int lane,
                                              const uint32_t* wcur, uint32_t (&nmacc)[2]) {
     using L = WL<U, T, E, INK4>;
     constexpr int THM = L::TH - 1;
@@ -728,7 +834,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     uint8_t* dfl = (uint8_t*)(dstart + U);
     LinEnt* lin = (LinEnt*)(lds + L::OFF_R2);
     // R3: payload per distinct k-mer, then the staged kept-list elements
-    uint32_t* upay = (uint32_t*)(lds + L::OFF_R3);
+    uint32_t* upay = (uint32_t*)(lds + (CPT ? L::OFF_UPAY_C : L::OFF_R3));
     uint32_t* el_poff = (uint32_t*)(lds + L::OFF_R3);
     uint16_t* el_t = (uint16_t*)(el_poff + E);   // kept id, registration order
     uint16_t* el_ta = el_t + E;                  // kept id, ascending order (closure order)
@@ -793,7 +899,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint32_t w = (uint32_t)lane + 64u * j;  // record word index; rd[] starts at word 1
         if (w >= 1 && w - 1 < (uint32_t)L::RD_WORDS) rd[w - 1] = (w - 1 < nb + nm) ? wcur[j] : 0u;
     }
-    for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
+    if (!CPT) { for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64; }
+    else { *(u32x4*)(xl + 4096 + 16 * lane) = u32x4{0u, 0u, 0u, 0u}; }  // the repeat filter of the compact path
     WSYNC();
     const uint32_t* codes = rd;
     const uint32_t* vmask = rd + nb;
@@ -802,8 +909,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 
     // canonical k-mer of the window starting at base p (read_label.cpp:992-1009).  Bases are
     // packed little-endian, so the 2k-bit window w has base p in its low bits: the reference's
-    // "reverse" is ~w and its "forward" is the pair-reversal of w.
-    auto window = [&](uint32_t p, uint64_t& canon) -> bool {
+    // "reverse" is ~w and its "forward" is the pair-reversal of w.  `other` = the strand that is not canonical.
+    auto window = [&](uint32_t p, uint64_t& canon, uint64_t& other, bool& fwd_canon) -> bool {
         const uint32_t mb = p >> 5, ms = p & 31;
         const uint64_t m2 = ((uint64_t)vmask[mb + 1] << 32) | vmask[mb];
         const bool ok = ((uint32_t)(m2 >> ms) & wmask) == wmask;
@@ -816,32 +923,42 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         f = ((f & 0x5555555555555555ull) << 1) | ((f >> 1) & 0x5555555555555555ull);
         f >>= (64 - 2 * k);
         canon = f < rev ? f : rev;
+        other = f < rev ? rev : f;
+        fwd_canon = f < rev;
         return ok;
     };
 
-    // ---- K1 pass 1: valid k-mers, first-occurrence hash, GC accounting.  For U <= 512 the canonical
-    //      k-mers and their hash slots stay in registers for pass 2 (chunk loop fully unrolled).
+    // ---- K1 pass 1: valid k-mers and GC accounting; wide layout: first-occurrence hash; compact layout: table
+    //      address of every k-mer.  For U <= 512 the canonical k-mers (and hash slots / addresses) stay in registers
+    //      for the later passes (chunk loop fully unrolled).
     constexpr int CH = (U + 32 + 63) / 64;   // 64-base chunks of the longest read of this class
     constexpr bool CACHE = U <= 512;
     constexpr int KC = CACHE ? CH : 1;
     uint64_t kreg[KC];
-    uint32_t hreg[KC];
+    uint32_t hreg[KC];   // wide: slot in the k-mer hash; compact: bucket
+    uint32_t treg[KC];   // compact: tag
     uint64_t okm[KC];
     int gc = 0, tot = 0;
     uint64_t prevV = 0;
 #pragma unroll
     for (int c = 0; c < (CACHE ? CH : 1); ++c) {
-        if (CACHE) { kreg[c] = 0; hreg[c] = 0; okm[c] = 0; }
+        if (CACHE) { kreg[c] = 0; hreg[c] = 0; treg[c] = 0; okm[c] = 0; }
     }
     const bool want_gc = A.nm.active != 0;
-    auto pass1_chunk = [&](uint32_t p0, uint64_t& km_out, uint32_t& h_out, uint64_t& V_out) {
+    auto pass1_chunk = [&](uint32_t p0, uint64_t& km_out, uint32_t& h_out, uint32_t& t_out, uint64_t& V_out) {
         const uint32_t p = p0 + lane;
-        uint64_t km = 0;
-        const bool ok = (p < P) && window(p, km);
+        uint64_t km = 0, kr = 0;
+        bool fc = false;
+        const bool ok = (p < P) && window(p, km, kr, fc);
         const uint64_t V = __ballot(ok);
         valid_kmers += popc64(V);
-        uint32_t h = 0;
-        if (ok) h = lds_min_insert(hv, L::H - 1, km, p);
+        uint32_t h = 0, t = 0;
+        if (!CPT) { if (ok) h = lds_min_insert(hv, L::H - 1, km, p); }
+        else if (CACHE) {
+            cpt_address(tb.cpt, km, kr, h, t);
+            const uint32_t j = ((t - 1u) >> 7) & 3u;   // minimizer position in the canonical k-mer -> in the read's direction
+            t |= (fc ? j : (uint32_t)(kCptW - 1) - j) << 30;
+        }
         // bases covered by at least one valid k-mer (read_label.cpp:987-1008): base b is covered
         // iff some window start in [b-k+1, b] is valid.  Only the null-model scores consume the GC decile.
         if (want_gc) {
@@ -859,16 +976,16 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             tot += popc64(hi);
             prevV = V;
         }
-        km_out = km; h_out = h; V_out = V;
+        km_out = km; h_out = h; t_out = t; V_out = V;
     };
     if (CACHE) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= len) break;
-            pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], okm[c]);
+            pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c], okm[c]);
         }
     } else {
-        for (uint32_t p0 = 0; p0 < len; p0 += 64) { uint64_t a; uint32_t b; uint64_t v; pass1_chunk(p0, a, b, v); }
+        for (uint32_t p0 = 0; p0 < len; p0 += 64) { uint64_t a; uint32_t b, t; uint64_t v; pass1_chunk(p0, a, b, t, v); }
     }
     WSYNC();
     if (tot > 0) {  // :1205-1206
@@ -882,8 +999,10 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
     if (A.prm.stop_after == 1) { if (lane == 0) { emit(250, 0); } return; }
     RELANE();
+    uint32_t nuniq = 0;   // distinct valid k-mers of the read
+    uint32_t nscan = 0;   // entries of upay[]: one per distinct k-mer (wide) or per k-mer position (compact)
+    if constexpr (!CPT) {
     // ---- K1 pass 2: compact first occurrences in position order
-    uint32_t nuniq = 0;
     auto pass2_chunk = [&](uint32_t p0, uint64_t km, uint32_t h, bool ok) {
         const uint32_t p = p0 + lane;
         const bool first = ok && (uint32_t)(hv[h] & 0xFFFF) == p;
@@ -905,21 +1024,23 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     } else {
         for (uint32_t p0 = 0; p0 < P; p0 += 64) {
             const uint32_t p = p0 + lane;
-            uint64_t km = 0;
+            uint64_t km = 0, kr = 0;
             uint32_t h = 0;
-            const bool ok = p < P && window(p, km);
+            bool fc;
+            const bool ok = p < P && window(p, km, kr, fc);
             if (ok) h = lds_find(hv, L::H - 1, km);
             pass2_chunk(p0, km, h, ok);
         }
     }
     WSYNC();
+    nscan = nuniq;
     if (A.prm.stop_after == 2) { if (lane == 0) { emit(250, nuniq); } return; }
     RELANE();
     // ---- K2: probe in rounds.  FOUR lanes read one 64-byte bucket, 16 B (two slots) each: one wave-instruction
     //      covers 16 buckets, still one request per 64-byte line, and a 150 bp read's nine wave-loads are all in
     //      flight before the first is consumed.  (Half the steps of an 8-lane layout: the kernel is bound by
     //      instruction issue.  One lane per bucket is slower: its four 16-byte loads are four requests per line.)
-    //      Slots fill a bucket front to back (hash_insert), so "has a free slot" is "the last slot is empty".
+    //      Slots fill a bucket front to back (wide_insert), so "has a free slot" is "the last slot is empty".
     //      A k-mer whose bucket is full without the key (31 % at load 0.8) goes on a pending list; round 1 reads
     //      its next two buckets at once, later rounds four: nearly every read is done after three round trips.
     {
@@ -991,6 +1112,206 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
     }
     WSYNC();
+    } else {
+    // ==== compact layout =====================================================================================
+    // Per 64-position chunk: neighbouring k-mers that share a bucket form a group; the group's 64-byte bucket is
+    // copied once from HBM straight into LDS (global_load_lds, 4 lanes x 16 B = one request per bucket, 16 buckets
+    // per wave-instruction), then every k-mer's lane matches its 16-bit tag against the 12 tags of its group's
+    // bucket.  A k-mer missing from a bucket that spilled (header bit) is looked up in the overflow table in one
+    // batched pass at the end.  upay[] gets one entry per k-mer POSITION (0 for repeats, misses and invalid
+    // windows): K3 only needs the payloads in first-occurrence order, which position order is.
+    uint32_t* stage = (uint32_t*)xl;
+    uint32_t* gbkt = (uint32_t*)(xl + 4096 - 256);  // bucket of group g while the loads are being issued: the tail of
+                                                    // the stage, which only the last wave-load of a full chunk overwrites
+    unsigned int* bloomA = (unsigned int*)(xl + 4096);
+    unsigned int* bloomB = (unsigned int*)(xl + 4096 + 512);
+    u32x4* olist = (u32x4*)(xl + 5120);             // k-mers to look up in the overflow table: k-mer, bucket, tag | position << 16
+    const GAS u32x4* quarters = (const GAS u32x4*)g_slots;
+    uint64_t firstm[KC];
+    // ---- repeats.  A k-mer seen twice in a read is looked up once (read_label.cpp:985,1010,1017).  Exact detection
+    //      (the LDS hash of the wide path) runs only when a cheap filter cannot rule a repeat out.  Here a group is a
+    //      run of k-mers around ONE occurrence of their minimizer (same bucket, same minimizer position in the read:
+    //      at most 4 k-mers).  Two positions with the same k-mer are then either in one group, hence within 3 bases
+    //      of each other (compared directly, on a 32-bit digest), or in two groups with the same bucket (two
+    //      4096-bit filters over the buckets of the groups' first k-mers).
+    bool suspect = !CACHE;
+    if (CACHE) {
+        uint32_t pb = 0, pq = 0, ps1 = 0, ps2 = 0, ps3 = 0;  // bucket / minimizer position / digests of the last lanes of the previous chunk
+        uint64_t Vp = 0, seen = 0;                   // ... and its valid mask
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((uint32_t)c * 64 >= P) break;
+            const uint64_t V = okm[c];
+            const uint64_t V1 = (V << 1) | (Vp >> 63), V2 = (V << 2) | (Vp >> 62), V3 = (V << 3) | (Vp >> 61);  // lane - d is valid
+            const bool ok = (V >> lane) & 1ull;
+            const uint32_t b = hreg[c];
+            const uint32_t sig = (uint32_t)(kreg[c] ^ (kreg[c] >> 17));
+            const uint32_t q = (uint32_t)c * 64 + lane + (treg[c] >> 30);  // where the k-mer's minimizer starts in the read
+            const uint32_t bprev = (uint32_t)__builtin_amdgcn_update_dpp((int)pb, (int)b, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            const uint32_t qprev = (uint32_t)__builtin_amdgcn_update_dpp((int)pq, (int)q, 0x138, 0xf, 0xf, false);
+            const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps1, (int)sig, 0x138, 0xf, 0xf, false);
+            const uint32_t s2 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps2, (int)s1, 0x138, 0xf, 0xf, false);
+            const uint32_t s3 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps3, (int)s2, 0x138, 0xf, 0xf, false);
+            bool hit = ok && ((((V1 >> lane) & 1ull) && sig == s1) || (((V2 >> lane) & 1ull) && sig == s2) || (((V3 >> lane) & 1ull) && sig == s3));
+            if (ok && !(((V1 >> lane) & 1ull) && b == bprev && q == qprev)) {  // opens a group
+                const uint32_t h1 = b & 4095u, h2 = (b >> 12) & 4095u;
+                const unsigned int oa = atomicOr(&bloomA[h1 >> 5], 1u << (h1 & 31)), ob = atomicOr(&bloomB[h2 >> 5], 1u << (h2 & 31));
+                hit |= ((oa >> (h1 & 31)) & (ob >> (h2 & 31)) & 1u) != 0;
+            }
+            seen |= __ballot(hit);
+            pb = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+            pq = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+            ps1 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 63);
+            ps2 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 62);
+            ps3 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 61);
+            Vp = V;
+        }
+        suspect = seen != 0;
+    }
+    if (suspect) {
+        for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
+        WSYNC();
+        if (CACHE) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((uint32_t)c * 64 >= P) break;
+                const bool ok = (okm[c] >> lane) & 1ull;
+                uint32_t h = 0;
+                if (ok) h = lds_min_insert(hv, L::H - 1, kreg[c], (uint32_t)c * 64 + lane);
+                treg[c] = (treg[c] & 0xC000FFFFu) | (h << 16);  // the tag is 16 bits wide; the hash slot rides above it
+            }
+            WSYNC();
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((uint32_t)c * 64 >= P) break;
+                const bool ok = (okm[c] >> lane) & 1ull;
+                firstm[c] = __ballot(ok && (uint32_t)(hv[(treg[c] >> 16) & 0x3FFFu] & 0xFFFF) == (uint32_t)c * 64 + lane);
+                nuniq += popc64(firstm[c]);
+            }
+        } else {
+            for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+                const uint32_t p = p0 + lane;
+                uint64_t km = 0, kr = 0;
+                bool fc;
+                if (p < P && window(p, km, kr, fc)) lds_min_insert(hv, L::H - 1, km, p);
+            }
+        }
+        WSYNC();
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((uint32_t)c * 64 >= P) break;
+            firstm[c] = okm[c];
+            nuniq += popc64(okm[c]);
+        }
+    }
+    RELANE();
+    // ---- probe, chunk by chunk
+    uint32_t nov = 0;  // entries of olist
+    auto ovf_pass = [&]() {  // looks the listed k-mers up in the overflow table (wide layout, linear probing)
+        const GAS u32x4* oq = (const GAS u32x4*)tb.ovf_slots;
+        bool act = (uint32_t)lane < nov;
+        u32x4 e = {0u, 0u, 0u, 0u};
+        if (act) e = olist[lane];
+        const uint64_t key1 = ((((uint64_t)e.y << 32) | e.x) << kPayloadBits) + 1;
+        uint32_t ob = act ? ovf_bucket_of(e.z, e.w & 0xFFFFu, tb.ovf_nbuckets) : 0u;
+        while (__ballot(act)) {
+            if (act) {
+                const u32x4 q0 = oq[(uint64_t)ob * 4], q1 = oq[(uint64_t)ob * 4 + 1], q2 = oq[(uint64_t)ob * 4 + 2], q3 = oq[(uint64_t)ob * 4 + 3];
+                const uint64_t sv[8] = {((uint64_t)q0.y << 32) | q0.x, ((uint64_t)q0.w << 32) | q0.z, ((uint64_t)q1.y << 32) | q1.x,
+                                        ((uint64_t)q1.w << 32) | q1.z, ((uint64_t)q2.y << 32) | q2.x, ((uint64_t)q2.w << 32) | q2.z,
+                                        ((uint64_t)q3.y << 32) | q3.x, ((uint64_t)q3.w << 32) | q3.z};
+                uint32_t pay = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint64_t d = sv[j] - key1;
+                    if (d < 0xFFFFFFull) pay = (uint32_t)d + 1u;
+                }
+                if (pay) { upay[e.w >> 16] = pay; act = false; }
+                else if (sv[7] == 0) act = false;  // slots fill front to back: a free last slot ends the chain
+                else ob = ob + 1 == tb.ovf_nbuckets ? 0 : ob + 1;
+            }
+        }
+        nov = 0;
+    };
+    auto probe_chunk = [&](uint32_t p0, uint64_t km, uint32_t b, uint32_t tag, bool ok, bool first) {
+        const uint32_t p = p0 + lane;
+        const uint64_t V1 = __ballot(ok) << 1;  // lane - 1 holds a valid k-mer (lane 0 always opens a group)
+        const uint32_t bprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const bool leader = ok && !(((V1 >> lane) & 1ull) && b == bprev);
+        const uint64_t lm = __ballot(leader);
+        const uint32_t ng = (uint32_t)popc64(lm);
+        const uint32_t gidx = (uint32_t)popc64(lm & ((lt_mask(lane) << 1) | 1ull)) - 1u;  // group of this lane (ok lanes)
+        if (leader) gbkt[gidx] = b;
+        WSYNC();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if ((uint32_t)s * 16 < ng) {
+                const uint32_t g = (uint32_t)s * 16 + ((uint32_t)lane >> 2);
+                if (g < ng) {
+                    const uint32_t gb = gbkt[g];
+                    __builtin_amdgcn_global_load_lds((const GAS void*)(quarters + (uint64_t)gb * 4 + (lane & 3)),
+                                                     (__attribute__((address_space(3))) void*)(xl + s * 1024), 16, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        WSYNC();
+        uint32_t pay = 0;
+        bool spill = false;
+        if (ok) {
+            const uint32_t* bk = stage + gidx * 16;
+            const u32x4 t0 = *(const u32x4*)bk;
+            const uint32_t t4 = bk[4], t5 = bk[5];
+            const uint32_t key2 = tag * 0x10001u;
+            // bit 15 / bit 31 of z(x): the low / high half of x equals the tag (exact: tags are never 0, empty slots are)
+            auto z = [&](uint32_t x) -> uint32_t { x ^= key2; return ~(((x & 0x7FFF7FFFu) + 0x7FFF7FFFu) | x) & 0x80008000u; };
+            const uint32_t acc = (z(t0.x) >> 15) | ((z(t0.y) >> 15) << 1) | ((z(t0.z) >> 15) << 2) | ((z(t0.w) >> 15) << 3) |
+                                 ((z(t4) >> 15) << 4) | ((z(t5) >> 15) << 5);  // bit i: slot 2i, bit 16 + i: slot 2i + 1
+            if (acc) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(acc);
+                const uint32_t slot = 2 * (bit & 15u) + (bit >> 4);
+                pay = (uint32_t)((const uint16_t*)bk)[12 + slot] | ((uint32_t)((const uint8_t*)bk)[48 + slot] << 16);
+            } else {
+                spill = (bk[15] & kCptOvfFlag) != 0;
+            }
+        }
+        if (p < P) upay[p] = first ? pay : 0u;
+        const bool pend = first && spill;
+        const uint64_t pm = __ballot(pend);
+        if (pm) {
+            if (nov + (uint32_t)popc64(pm) > 64u) { WSYNC(); ovf_pass(); WSYNC(); }
+            if (pend) olist[nov + (uint32_t)popc64(pm & lt_mask(lane))] = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, tag | (p << 16)};
+            nov += (uint32_t)popc64(pm);
+        }
+        WSYNC();
+    };
+    if (CACHE) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((uint32_t)c * 64 >= P) break;
+            probe_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c] & 0xFFFFu, (okm[c] >> lane) & 1ull, (firstm[c] >> lane) & 1ull);
+        }
+    } else {
+        for (uint32_t p0 = 0; p0 < P; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            uint64_t km = 0, kr = 0;
+            uint32_t b = 0, t = 0;
+            bool fc;
+            const bool ok = p < P && window(p, km, kr, fc);
+            bool first = false;
+            if (ok) {
+                cpt_address(tb.cpt, km, kr, b, t);
+                first = (uint32_t)(hv[lds_find(hv, L::H - 1, km)] & 0xFFFF) == p;
+            }
+            nuniq += (uint32_t)popc64(__ballot(first));
+            probe_chunk(p0, km, b, t, ok, first);
+        }
+    }
+    if (nov) { ovf_pass(); WSYNC(); }
+    nscan = P;
+    if (A.prm.stop_after == 2) { if (lane == 0) { emit(250, nuniq); } return; }
+    }
     if (A.prm.stop_after == 3) { if (lane == 0) { emit(250, upay[0]); } return; }
     RELANE();
     // ---- K3a: distinct payloads in first-occurrence order with multiplicities.  Identical payload
@@ -1001,9 +1322,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     bool many = false;
     {
         uint32_t dp_reg = 0, dm_reg = 0;
-        for (uint32_t i0 = 0; i0 < nuniq && !many; i0 += 64) {
+        for (uint32_t i0 = 0; i0 < nscan && !many; i0 += 64) {
             const uint32_t i = i0 + lane;
-            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            const uint32_t pay = i < nscan ? upay[i] : 0;
             uint64_t rem = __ballot(pay != 0);
             while (rem) {
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pay, __builtin_ctzll(rem));
@@ -1028,16 +1349,16 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     if (many) {
         for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
         WSYNC();
-        for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {
+        for (uint32_t i0 = 0; i0 < nscan; i0 += 64) {
             const uint32_t i = i0 + lane;
-            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            const uint32_t pay = i < nscan ? upay[i] : 0;
             if (pay) lds_min_insert(hv, L::H - 1, pay, i);
         }
         WSYNC();
         ndist = 0;
-        for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // dpay/dmult overlay the (dead) k-mer arrays
+        for (uint32_t i0 = 0; i0 < nscan; i0 += 64) {  // dpay/dmult overlay the (dead) k-mer arrays
             const uint32_t i = i0 + lane;
-            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            const uint32_t pay = i < nscan ? upay[i] : 0;
             bool owner = false;
             uint32_t h = 0;
             if (pay) {
@@ -1055,9 +1376,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
         for (uint32_t d = lane; d < (ndist + 1) / 2; d += 64) ((unsigned int*)dmult)[d] = 0;
         WSYNC();
-        for (uint32_t i0 = 0; i0 < nuniq; i0 += 64) {  // multiplicity = number of distinct k-mers carrying the payload
+        for (uint32_t i0 = 0; i0 < nscan; i0 += 64) {  // multiplicity = number of distinct k-mers carrying the payload
             const uint32_t i = i0 + lane;
-            const uint32_t pay = i < nuniq ? upay[i] : 0;
+            const uint32_t pay = i < nscan ? upay[i] : 0;
             if (pay) add_u16(dmult, (uint32_t)(hv[lds_find(hv, L::H - 1, pay)] & 0x7FFFu), 1u);
         }
         WSYNC();
@@ -1758,11 +2079,13 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #pragma push_macro("WSYNC")
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
-template <int U, int T, int E, bool INK4, bool PERM>
+template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
     // U > 2048: the per-read tables of this workgroup live in global memory
     unsigned char* smem = U > 2048 ? A.gscratch + (size_t)blockIdx.x * WL<U, T, E, INK4>::BYTES : lds_smem;
+    // scratch block of the compact-layout probe: always real LDS
+    unsigned char* xl = U > 2048 ? lds_smem : lds_smem + WL<U, T, E, INK4>::OFF_XL;
     const int lane = threadIdx.x & 63;
     const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
     const GAS uint32_t* index = (const GAS uint32_t*)A.index;
@@ -1785,7 +2108,7 @@ __global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs
         const uint64_t off2 = it + 2 * G < count ? rec_off[r_of(it + 2 * G)] : 0;
 #pragma unroll
         for (int j = 0; j < NW; ++j) wnext[j] = it + G < count ? words[off1 + lane + 64 * j] : 0u;
-        classify_one<U, T, E, INK4, PERM>(A, r_of(it), smem, lane, wcur, nmacc);
+        classify_one<U, T, E, INK4, PERM, CPT>(A, r_of(it), smem, xl, lane, wcur, nmacc);
         WSYNC();
 #pragma unroll
         for (int j = 0; j < NW; ++j) wcur[j] = wnext[j];
@@ -1815,20 +2138,26 @@ void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t
                        hipStream_t stream) {
     hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(n, 4, 8192)), dim3(256), 0, stream, bases, off, rec_off, words, n);
 }
-void launch_insert_pairs(uint64_t* slots, uint32_t nbuckets, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
+void launch_insert_pairs(const DeviceTables& tb, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
                          uint32_t* fail, hipStream_t stream) {
-    hipLaunchKernelGGL(insert_pairs_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, slots, nbuckets, kmers,
-                       payload, n, fail);
+    hipLaunchKernelGGL(insert_pairs_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, tb, kmers, payload, n, fail);
 }
-void launch_synth_db(uint64_t* slots, uint32_t nbuckets, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
+void launch_synth_db(const DeviceTables& tb, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
                      const uint16_t* strain_idx, const uint32_t* list_payload, uint32_t* fail,
                      unsigned long long* inserted, hipStream_t stream) {
     const uint64_t total = (uint64_t)n_species * (G - k + 1);
-    hipLaunchKernelGGL(synth_db_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, stream, slots, nbuckets, seed,
+    hipLaunchKernelGGL(synth_db_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, stream, tb, seed,
                        n_species, S, G, k, strain_idx, list_payload, fail, inserted);
 }
-void launch_count_slots(const uint64_t* slots, uint64_t nslots, unsigned long long* out, hipStream_t stream) {
-    hipLaunchKernelGGL(count_slots_kernel, dim3(grid_for(nslots, 256, 16384)), dim3(256), 0, stream, slots, nslots, out);
+// number of k-mers in the table -> *out (after a build; the compact layout is tidied on the way)
+void launch_table_count(const DeviceTables& tb, unsigned long long* out, hipStream_t stream) {
+    if (!tb.cpt.nb) {
+        const uint64_t nslots = (uint64_t)tb.nbuckets * kSlotsPerBucket;
+        hipLaunchKernelGGL(count_slots_kernel, dim3(grid_for(nslots, 256, 16384)), dim3(256), 0, stream, tb.slots, nslots, out);
+        return;
+    }
+    hipLaunchKernelGGL(cpt_tidy_kernel, dim3(grid_for(tb.cpt.nb, 256, 16384)), dim3(256), 0, stream, tb, out);
+    hipLaunchKernelGGL(cpt_merge_overflow_kernel, dim3(grid_for((uint64_t)tb.ovf_nbuckets * kSlotsPerBucket, 256, 16384)), dim3(256), 0, stream, tb, out);
 }
 void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t* lengths, uint32_t n_lengths, uint64_t n,
                         uint64_t seed, uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G, hipStream_t stream) {
@@ -1886,35 +2215,37 @@ void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, h
     else k4_kernel<false><<<dim3(64), dim3(64), 0, stream>>>(b);
 }
 
-template <int U, int T, int E, bool INK4, bool PERM>
+template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
-    if (U > 2048) {  // tables in global memory: few workgroups, no LDS
+    using L = WL<U, T, E, INK4>;
+    if (U > 2048) {  // tables in global memory: few workgroups; LDS only for the compact probe's scratch block
         int grid = kGmemGrid;
         if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)(a.count ? a.count : 1);
-        classify_kernel<U, T, E, INK4, PERM><<<dim3(grid), dim3(64), 0, stream>>>(a);
+        classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), CPT ? L::XL_BYTES : 0, stream>>>(a);
         return;
     }
+    constexpr int lds_bytes = CPT ? L::BYTES_C : L::BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        constexpr int lds_bytes0 = WL<U, T, E, INK4>::BYTES;
-        hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes0);
+        hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
-    const int per_cu = 160 * 1024 / WL<U, T, E, INK4>::BYTES;
+    const int per_cu = 160 * 1024 / lds_bytes;
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * 2;
     if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)a.count;
     if (a.count_ptr && grid > 512) grid = 512;
     if (grid < 1) grid = 1;
-    constexpr int lds_bytes = WL<U, T, E, INK4>::BYTES;
-    classify_kernel<U, T, E, INK4, PERM><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
+    classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
 
 int classify_max_read_len() { return kGmemU + 19; }
 size_t classify_gmem_scratch_bytes() { return (size_t)kGmemGrid * WL<kGmemU, 4096, 16384, true>::BYTES; }
 
 // permissive match (-s) is a compile-time variant: a run-time test of it inside the closure loops cost 22%
-#define LC(U, T, E, K) (a.prm.permissive ? launch_classify_t<U, T, E, K, true>(a, stream) : launch_classify_t<U, T, E, K, false>(a, stream))
+#define LC(U, T, E, K)                                                                                                   \
+    (a.tb.cpt.nb ? (a.prm.permissive ? launch_classify_t<U, T, E, K, true, true>(a, stream) : launch_classify_t<U, T, E, K, false, true>(a, stream)) \
+                 : (a.prm.permissive ? launch_classify_t<U, T, E, K, true, false>(a, stream) : launch_classify_t<U, T, E, K, false, false>(a, stream)))
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream) {
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;

@@ -45,12 +45,12 @@ enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLinea
 // launchers (all asynchronous on `stream`)
 void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t* rec_off, uint32_t* words, uint64_t n,
                        hipStream_t stream);
-void launch_insert_pairs(uint64_t* slots, uint32_t nbuckets, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
+void launch_insert_pairs(const DeviceTables& tb, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
                          uint32_t* fail, hipStream_t stream);
-void launch_synth_db(uint64_t* slots, uint32_t nbuckets, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
+void launch_synth_db(const DeviceTables& tb, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
                      const uint16_t* strain_idx, const uint32_t* list_payload, uint32_t* fail,
                      unsigned long long* inserted, hipStream_t stream);
-void launch_count_slots(const uint64_t* slots, uint64_t nslots, unsigned long long* out, hipStream_t stream);
+void launch_table_count(const DeviceTables& tb, unsigned long long* out, hipStream_t stream);
 void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t* lengths, uint32_t n_lengths, uint64_t n,
                         uint64_t seed, uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G, hipStream_t stream);
 void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids,

@@ -105,7 +105,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     hipDeviceSynchronize();
     for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    void* ptrs[] = {c->dev.slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
+    void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
                     c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
     for (void* p : ptrs)
@@ -259,7 +259,38 @@ int lmat_db_load_image(lmat_ctx* c, const char* fn, uint64_t table_bytes) {
     return LMAT_OK;
 }
 
-static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes) {
+// Share of the k-mers that do not fit their 12-slot bucket at an average of `load` k-mers per bucket (k-mers arrive in
+// minimizer groups of ~2.5, so the tail is heavier than Poisson; scripts/minimizer_sim.py: 6.1 % at 6.4).
+static double cpt_displaced_share(double load) { return std::min(0.6, 0.061 * std::pow(load / 6.4, 3.2)); }
+
+static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k) {
+    if (c->dev.slots) { hipFree(c->dev.slots); c->dev.slots = nullptr; }
+    if (c->dev.ovf_slots) { hipFree(c->dev.ovf_slots); c->dev.ovf_slots = nullptr; }
+    c->dev.cpt = CptGeom();
+    c->dev.ovf_nbuckets = 0;
+    const char* fmt = getenv("LMAT_TABLE_FORMAT");  // "wide": the 8 x 64-bit-slot layout for every table (A/B runs)
+    if (!(fmt && !strcmp(fmt, "wide"))) {
+        // compact layout, ~10 bytes per k-mer: 6.4 k-mers on average in a 12-slot bucket
+        const uint64_t want = table_bytes ? table_bytes / 64 : (uint64_t)((double)n_kmers / 6.4) + 1;
+        const CptGeom g = cpt_geometry(k, want);
+        if (g.nb) {
+            const double n_est = n_kmers ? (double)n_kmers : 6.4 * (double)g.nb;
+            const double load = n_est / (double)g.nb;
+            if (load > 11.0) return set_err(c, LMAT_E_CAPACITY, "table_bytes too small for the number of k-mers");
+            double share = cpt_displaced_share(load) * 1.6;
+            if (const char* e = getenv("LMAT_OVERFLOW_SHARE")) share = atof(e);
+            uint64_t onb = (uint64_t)(n_est * share / (0.7 * kSlotsPerBucket)) + 1024;
+            if (onb > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "overflow table above 2^32 buckets");
+            HIPCHK(c, hipMalloc((void**)&c->dev.slots, (uint64_t)g.nb * 64));
+            HIPCHK(c, hipMalloc((void**)&c->dev.ovf_slots, onb * 64));
+            HIPCHK(c, hipMemsetAsync(c->dev.slots, 0, (uint64_t)g.nb * 64, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->dev.ovf_slots, 0, onb * 64, c->stream));
+            c->dev.nbuckets = g.nb;
+            c->dev.cpt = g;
+            c->dev.ovf_nbuckets = (uint32_t)onb;
+            return LMAT_OK;
+        }
+    }
     uint64_t nb;
     if (table_bytes) nb = table_bytes / 64;
     else nb = (uint64_t)((double)n_kmers / (0.8 * kSlotsPerBucket)) + 1;
@@ -267,7 +298,6 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes) {
     if (nb > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "hash table above 2^32 buckets");
     if (nb * kSlotsPerBucket < n_kmers + n_kmers / 64)
         return set_err(c, LMAT_E_CAPACITY, "table_bytes too small for the number of k-mers");
-    if (c->dev.slots) { hipFree(c->dev.slots); c->dev.slots = nullptr; }
     HIPCHK(c, hipMalloc((void**)&c->dev.slots, nb * 64));
     HIPCHK(c, hipMemsetAsync(c->dev.slots, 0, nb * 64, c->stream));
     c->dev.nbuckets = (uint32_t)nb;
@@ -301,7 +331,7 @@ static int sb_begin(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k) 
     hipSetDevice(c->device);
     sb_free(c);
     c->sb = new StreamBuild();
-    int rc = alloc_table(c, n_kmers, table_bytes);
+    int rc = alloc_table(c, n_kmers, table_bytes, k);
     if (rc) return rc;
     c->dev.k = k;
     c->sb->cap = 1ull << 24;
@@ -358,7 +388,7 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
             return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
         HIPCHK(c, hipMemcpyAsync(S.d_k, B.kmers.data() + s, m * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(S.d_p, S.pay.data(), m * 4, hipMemcpyHostToDevice, c->stream));
-        launch_insert_pairs(c->dev.slots, c->dev.nbuckets, S.d_k, S.d_p, m, S.d_fail, c->stream);
+        launch_insert_pairs(c->dev, S.d_k, S.d_p, m, S.d_fail, c->stream);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         S.inserted += m;
     }
@@ -376,9 +406,20 @@ static int sb_finish(lmat_ctx* c) {
     c->arena_words = arena_words;
     uint32_t fail = 0;
     HIPCHK(c, hipMemcpy(&fail, S.d_fail, 4, hipMemcpyDeviceToHost));
-    const uint64_t n = S.inserted;
+    uint64_t n = S.inserted;
     sb_free(c);
     if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during insert (n_kmers_hint / table_bytes too small)");
+    if (c->dev.cpt.nb) {  // tidy the compact buckets (slot counts; a key fed twice keeps its smaller payload) and count
+        unsigned long long* d_n = nullptr;
+        unsigned long long cnt = 0;
+        HIPCHK(c, hipMalloc((void**)&d_n, 8));
+        HIPCHK(c, hipMemsetAsync(d_n, 0, 8, c->stream));
+        launch_table_count(c->dev, d_n, c->stream);
+        HIPCHK(c, hipMemcpyAsync(&cnt, d_n, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(d_n);
+        n = cnt;
+    }
     c->n_kmers = n;
     c->db_ready = true;
     return LMAT_OK;
@@ -430,7 +471,7 @@ int lmat_db_from_ingest(lmat_ctx* c, lmat_ingest* g, uint64_t table_bytes) {
 
 int lmat_db_kmer_length(const lmat_ctx* c) { return c ? c->dev.k : 0; }
 uint64_t lmat_db_size(const lmat_ctx* c) { return c ? c->n_kmers : 0; }
-uint64_t lmat_db_table_bytes(const lmat_ctx* c) { return c ? (uint64_t)c->dev.nbuckets * 64 : 0; }
+uint64_t lmat_db_table_bytes(const lmat_ctx* c) { return c ? ((uint64_t)c->dev.nbuckets + c->dev.ovf_nbuckets) * 64 : 0; }
 
 int lmat_db_lookup(lmat_ctx* c, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids, uint32_t stride) {
     if (!c || !c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
@@ -548,7 +589,7 @@ int lmat_synth_db_build(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t 
     // expected distinct k-mers ~ species * positions * (1 + S * P(window mutated)); size the table from that
     const double pm = 1.0 - std::pow(0.99, k);
     const uint64_t est = (uint64_t)((double)NS * (double)(G - k + 1) * (1.0 + S * pm));
-    if ((rc = alloc_table(c, est, table_bytes))) return rc;
+    if ((rc = alloc_table(c, est, table_bytes, k))) return rc;
     c->dev.k = k;
     uint32_t* d_fail = nullptr;
     unsigned long long* d_ins = nullptr;
@@ -556,8 +597,8 @@ int lmat_synth_db_build(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t 
     HIPCHK(c, hipMalloc((void**)&d_ins, 16));
     HIPCHK(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
     HIPCHK(c, hipMemsetAsync(d_ins, 0, 16, c->stream));
-    launch_synth_db(c->dev.slots, c->dev.nbuckets, seed, NS, S, G, k, c->d_synth_strain_idx, d_lp, d_fail, d_ins, c->stream);
-    launch_count_slots(c->dev.slots, (uint64_t)c->dev.nbuckets * kSlotsPerBucket, d_ins + 1, c->stream);
+    launch_synth_db(c->dev, seed, NS, S, G, k, c->d_synth_strain_idx, d_lp, d_fail, d_ins, c->stream);
+    launch_table_count(c->dev, d_ins + 1, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint32_t fail = 0;
     unsigned long long ins[2] = {0, 0};

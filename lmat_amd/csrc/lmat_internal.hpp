@@ -33,8 +33,11 @@ struct HostTaxonomy {
 };
 
 struct DeviceTables {
-    uint64_t* slots = nullptr;
+    uint64_t* slots = nullptr;      // the k-mer table: compact buckets when cpt.nb != 0, else wide (8 x u64 slots per bucket)
     uint32_t nbuckets = 0;
+    CptGeom cpt;                    // geometry of the compact layout (lmat_common.hpp)
+    uint64_t* ovf_slots = nullptr;  // compact only: k-mers whose bucket was full, wide layout
+    uint32_t ovf_nbuckets = 0;
     uint16_t* arena = nullptr;
     uint32_t* tid32 = nullptr;
     uint16_t* fdepth = nullptr;

@@ -20,6 +20,17 @@ def mix(x):
     x ^= x >> np.uint64(33)
     return x
 
+def feistel(x, m, ks):
+    mm = np.uint64((1 << m) - 1)
+    L = (x >> np.uint64(m)); R = x & mm
+    for i, kk in enumerate(ks):
+        if i % 2 == 0: L = L ^ (((R * np.uint64(kk)) & np.uint64(0xFFFFFFFF)) >> np.uint64(7)) & mm
+        else: R = R ^ (((L * np.uint64(kk)) & np.uint64(0xFFFFFFFF)) >> np.uint64(7)) & mm
+    return (L << np.uint64(m)) | R
+
+SCR = (0x6A09, 0x3B67, 0x5F1D, 0x7C15)   # cpt_scramble / cpt_mix of lmat_common.hpp
+MIX = (0x52DB, 0x4F6D, 0x6E2B, 0x35A7)
+
 def words(seq, n):
     out = np.zeros(len(seq) - n + 1, dtype=np.uint64)
     for i in range(n):
@@ -27,13 +38,20 @@ def words(seq, n):
     return out
 
 def minimizers(seq, k, m):
-    mm = mix(canon(words(seq, m), m))          # ordering hash per m-mer position
+    mm = feistel(canon(words(seq, m), m), m, SCR) if ENGINE else mix(canon(words(seq, m), m))  # ordering hash per m-mer position
     w = k - m + 1
     P = len(seq) - k + 1
     best = mm[0:P].copy()
     for j in range(1, w):
         best = np.minimum(best, mm[j:P + j])
     return best
+
+ENGINE = len(sys.argv) > 3 and sys.argv[3] == "engine"   # the engine's own Feistel scramblers instead of murmur
+
+def bucket_of(mn, m, nb):
+    if ENGINE:
+        return (feistel(mn, m, MIX).astype(np.float64) * nb / float(1 << (2 * m))).astype(np.int64)
+    return (mix(mn ^ np.uint64(0x9e3779b97f4a7c15)) % np.uint64(nb)).astype(np.int64)
 
 def main():
     rng = np.random.default_rng(7)
@@ -46,7 +64,7 @@ def main():
         mut = rng.random(G) < 0.01
         g[mut] = (g[mut] + rng.integers(1, 4, mut.sum())) & 3
         genomes.append(g)
-    for m in (20, 18, 17, 16, 15, 14):
+    for m in ((17, 16, 15) if ENGINE else (20, 18, 17, 16, 15, 14)):
         keys, mins = [], []
         for g in genomes:
             keys.append(canon(words(g, k), k)); mins.append(minimizers(g, k, m) if m < k else mix(canon(words(g, k), k)))
@@ -54,7 +72,7 @@ def main():
         uk, idx = np.unique(keys, return_index=True)
         um = mins[idx]
         nb = int(len(uk) / avg)
-        b = (mix(um ^ np.uint64(0x9e3779b97f4a7c15)) % np.uint64(nb)).astype(np.int64)
+        b = bucket_of(um, m, nb)
         cnt = np.bincount(b, minlength=nb)
         full = (cnt >= slots).mean()
         displaced = np.maximum(cnt - slots, 0).sum() / len(uk)
@@ -64,7 +82,7 @@ def main():
         for off in rng.integers(0, G - 150, 300):
             r = g[off:off + 150]
             mn = minimizers(r, k, m) if m < k else mix(canon(words(r, k), k))
-            bb = mix(mn ^ np.uint64(0x9e3779b97f4a7c15)) % np.uint64(nb)
+            bb = bucket_of(mn, m, nb)
             runs = 1 + int((bb[1:] != bb[:-1]).sum())
             touched.append((len(np.unique(bb)), runs))
         t = np.array(touched)
