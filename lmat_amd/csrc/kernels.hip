@@ -945,19 +945,30 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (CACHE) { kreg[c] = 0; hreg[c] = 0; treg[c] = 0; okm[c] = 0; }
     }
     const bool want_gc = A.nm.active != 0;
-    auto pass1_chunk = [&](uint32_t p0, uint64_t& km_out, uint32_t& h_out, uint32_t& t_out, uint64_t& V_out) {
+    // compact layout: the minimizer of a k-mer is the smallest of the 4 m-mers it covers, and neighbouring k-mers
+    // share 3 of them, so every lane scrambles ONE m-mer -- the one starting at its own position -- and the window
+    // minimum runs over the lanes (cpt_finish).  u = scrambled canonical m-mer << 4 | (reverse strand is the smaller)
+    // << 1 | (palindrome); bits 2..3 are left for the m-mer's place in the k-mer.
+    const int cm = tb.cpt.m;
+    uint64_t ureg[KC];
+    uint64_t fcm[KC];  // lanes whose forward strand is the canonical one
+#pragma unroll
+    for (int c = 0; c < KC; ++c) { ureg[c] = 0; fcm[c] = 0; }
+    auto pass1_chunk = [&](uint32_t p0, uint64_t& km_out, uint32_t& h_out, uint32_t& t_out, uint64_t& V_out, uint64_t& u_out,
+                           uint64_t& fc_out) {
         const uint32_t p = p0 + lane;
         uint64_t km = 0, kr = 0;
         bool fc = false;
-        const bool ok = (p < P) && window(p, km, kr, fc);
+        const bool ok = (CPT ? p < P + (uint32_t)(kCptW - 1) : p < P) && window(p, km, kr, fc);  // false past P: the record's tail is zero
         const uint64_t V = __ballot(ok);
         valid_kmers += popc64(V);
         uint32_t h = 0, t = 0;
         if (!CPT) { if (ok) h = lds_min_insert(hv, L::H - 1, km, p); }
         else if (CACHE) {
-            cpt_address(tb.cpt, km, kr, h, t);
-            const uint32_t j = ((t - 1u) >> 7) & 3u;   // minimizer position in the canonical k-mer -> in the read's direction
-            t |= (fc ? j : (uint32_t)(kCptW - 1) - j) << 30;
+            const uint64_t f = fc ? km : kr, rv = fc ? kr : km;
+            const uint64_t x = f >> (2 * (kCptW - 1)), xr = rv & ((1ull << (2 * cm)) - 1);  // the m-mer at p and its reverse complement
+            u_out = (cpt_scramble(x < xr ? x : xr, cm) << 4) | (xr < x ? 2u : 0u) | (x == xr ? 1u : 0u);
+            fc_out = __ballot(fc);
         }
         // bases covered by at least one valid k-mer (read_label.cpp:987-1008): base b is covered
         // iff some window start in [b-k+1, b] is valid.  Only the null-model scores consume the GC decile.
@@ -978,14 +989,54 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
         km_out = km; h_out = h; t_out = t; V_out = V;
     };
+    // bucket and tag of the k-mers of chunk c from the m-mer values of this chunk (u) and the next (un): cpt_address
+    // with the minimum taken across lanes.  Among equal m-mers cpt_address takes the first in the CANONICAL k-mer's
+    // direction, which is the last in the read's direction when the reverse strand is canonical: bits 2..3 of the
+    // compared words count positions in that direction.
+    auto cpt_finish = [&](uint64_t km, uint64_t u, uint64_t un, uint64_t fcmask, uint32_t& b_out, uint32_t& t_out) {
+        const uint32_t ulo = (uint32_t)u, uhi = (uint32_t)(u >> 32);
+        const int n0l = __builtin_amdgcn_readlane((int)(uint32_t)un, 0), n0h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 0);
+        const int n1l = __builtin_amdgcn_readlane((int)(uint32_t)un, 1), n1h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 1);
+        const int n2l = __builtin_amdgcn_readlane((int)(uint32_t)un, 2), n2h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 2);
+        // wave_shl:1 -- lane i takes lane i + 1, lane 63 the next chunk's value
+        const uint32_t u1l = (uint32_t)__builtin_amdgcn_update_dpp(n0l, (int)ulo, 0x130, 0xf, 0xf, false);
+        const uint32_t u1h = (uint32_t)__builtin_amdgcn_update_dpp(n0h, (int)uhi, 0x130, 0xf, 0xf, false);
+        const uint32_t u2l = (uint32_t)__builtin_amdgcn_update_dpp(n1l, (int)u1l, 0x130, 0xf, 0xf, false);
+        const uint32_t u2h = (uint32_t)__builtin_amdgcn_update_dpp(n1h, (int)u1h, 0x130, 0xf, 0xf, false);
+        const uint32_t u3l = (uint32_t)__builtin_amdgcn_update_dpp(n2l, (int)u2l, 0x130, 0xf, 0xf, false);
+        const uint32_t u3h = (uint32_t)__builtin_amdgcn_update_dpp(n2h, (int)u2h, 0x130, 0xf, 0xf, false);
+        const bool fc = (fcmask >> lane) & 1ull;
+        const uint64_t a0 = ((uint64_t)uhi << 32) | (ulo | (fc ? 0u : 12u)), a1 = ((uint64_t)u1h << 32) | (u1l | (fc ? 4u : 8u));
+        const uint64_t a2 = ((uint64_t)u2h << 32) | (u2l | (fc ? 8u : 4u)), a3 = ((uint64_t)u3h << 32) | (u3l | (fc ? 12u : 0u));
+        const uint64_t m01 = a0 < a1 ? a0 : a1, m23 = a2 < a3 ? a2 : a3;
+        const uint64_t best = m01 < m23 ? m01 : m23;
+        const uint32_t j = ((uint32_t)best >> 2) & 3u, fl = (uint32_t)best & 3u;
+        const uint32_t strand = fc ? fl >> 1 : (fl == 0u ? 1u : 0u);  // the m-mer in the canonical k-mer is the larger of its pair
+        const uint64_t sp = cpt_mix(best >> 4, cm);
+        const int lb = tb.cpt.lowbits;
+        const uint32_t hi = (uint32_t)(sp >> lb), low = (uint32_t)sp & ((1u << lb) - 1);
+        const uint32_t b = (uint32_t)(((double)hi + 0.5) * tb.cpt.invW);
+        const uint32_t rho = hi - b * tb.cpt.W;
+        const int rs = 2 * (kCptW - 1 - (int)j);
+        const uint32_t other = (uint32_t)((km >> (2 * cm + rs)) << rs) | ((uint32_t)km & ((1u << rs) - 1));
+        b_out = b;
+        t_out = (1u + (((((rho << lb) | low) * 4 + j) * 2 + strand) * 64 + other)) | ((fc ? j : (uint32_t)(kCptW - 1) - j) << 30);
+    };
     if (CACHE) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= len) break;
-            pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c], okm[c]);
+            pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c], okm[c], ureg[c], fcm[c]);
+        }
+        if (CPT) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((uint32_t)c * 64 >= P) break;
+                cpt_finish(kreg[c], ureg[c], c + 1 < CH ? ureg[c + 1] : 0ull, fcm[c], hreg[c], treg[c]);
+            }
         }
     } else {
-        for (uint32_t p0 = 0; p0 < len; p0 += 64) { uint64_t a; uint32_t b, t; uint64_t v; pass1_chunk(p0, a, b, t, v); }
+        for (uint32_t p0 = 0; p0 < len; p0 += 64) { uint64_t a; uint32_t b, t; uint64_t v, u, f; pass1_chunk(p0, a, b, t, v, u, f); }
     }
     WSYNC();
     if (tot > 0) {  // :1205-1206

@@ -2,7 +2,7 @@
 # instruction counts of the classify kernel after each phase (debug switch LMAT_STOP_AFTER)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for s in 1 2 3 4 5 6 0; do
+for s in ${STOPS:-1 2 3 4 5 6 0}; do
   OUT=$ROOT/gpurun_out/pmc_ab/s$s; mkdir -p $OUT
   LMAT_STOP_AFTER=$s rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT -o p -- python3 $ROOT/bench.py --no-cpu --steps 2 --warmup 1 --batch 1000000 > /dev/null 2>&1
   python3 - <<PY
