@@ -39,6 +39,9 @@ static const int kGmemGrid = 128;  // its workgroups (one per-read table set of 
 #define GAS __attribute__((address_space(1)))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));              // 16-byte table records
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // list records are only 4-byte aligned
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#define LAS __attribute__((address_space(3)))
 #define G_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define G_OR(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 __device__ __forceinline__ void store_result(GAS uint64_t* dst, const lmat_read_result& r) {
@@ -423,9 +426,10 @@ static const int kK4SmallStride = 125;               // dwords per lane (odd): 6
 // Regions are reused across phases (see classify_one).
 constexpr int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <int U, int T, int E, bool INK4>
+template <int U, int T, int E, bool INK4, bool CPT = false>
 struct WL {
     static constexpr int H = pow2_ceil(U * 3 / 2);  // k-mer / payload hash slots
+    static constexpr int D = INK4 ? U : 64;  // distinct payloads (taxid lists) per read; the fast classes hand a read with more to a larger class
     static constexpr int TH = 4 * T;   // taxid hash slots: <= T registered + <= T unregistered species keys
     static constexpr int LIN = T + 72; // lineage scratch entries (in-kernel K4 only)
     static constexpr int RD_WORDS = (U + 96) / 16 + (U + 96) / 32 + 4;
@@ -434,8 +438,8 @@ struct WL {
     // score0, nm_rp (f32), nm_cl (u8)
     static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T + 4 * T + 4 * T + T : 0);
     static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
-    static constexpr int R2_K = 8 * U + 4 * U;                         // ukmer, ubucket
-    static constexpr int R2_D = 4 * U + 2 * U + 2 * U + 2 * U + U;     // dpay, dmult, dn, dstart, dfl
+    static constexpr int R2_K = CPT ? 0 : 8 * U + 4 * U;               // ukmer, ubucket (wide layout only)
+    static constexpr int R2_D = 4 * D + 2 * D + 2 * D + 2 * D + D;     // dpay, dmult, dn, dstart, dfl
     static constexpr int R2_L = INK4 ? 12 * LIN : 0;                   // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
@@ -446,17 +450,17 @@ struct WL {
     static constexpr int OFF_R2 = OFF_R1 + ((R1 + 15) / 16) * 16;
     static constexpr int OFF_R3 = OFF_R2 + ((R2 + 15) / 16) * 16;
     static constexpr int BYTES_BASE = OFF_R3 + ((R3 + 15) / 16) * 16;
-    // compact-layout probe: a block of real LDS [bucket stage 4096 | repeat filter 1024 | overflow-probe list 1024].
+    // compact-layout probe: a block of real LDS [bucket stage 4096 | repeat filter 512 | overflow-probe list 1024].
     // Classes that keep a read's k-mers in registers (U <= 512) overlay it on R1..R3, which are idle until the probe is
     // done; the others get it behind their tables (the global-memory class keeps nothing else in LDS).
-    static constexpr int XL_BYTES = 6144;
+    static constexpr int XL_BYTES = 5632;
     static constexpr bool XL_OVERLAY = U <= 512;
     static constexpr int OFF_XL = XL_OVERLAY ? OFF_R1 : BYTES_BASE;
     // payload per k-mer position (compact) / per distinct k-mer (wide): at R3, or behind the block where that overlaps R3
     static constexpr int OFF_UPAY_C = XL_OVERLAY && OFF_R1 + XL_BYTES > OFF_R3 ? OFF_R1 + XL_BYTES : OFF_R3;
     static constexpr int BYTES_C = XL_OVERLAY ? (OFF_UPAY_C + 4 * U > BYTES_BASE ? ((OFF_UPAY_C + 4 * U + 15) / 16) * 16 : BYTES_BASE)
                                               : BYTES_BASE + XL_BYTES;
-    static constexpr int BYTES = BYTES_BASE;
+    static constexpr int BYTES = CPT ? BYTES_C : BYTES_BASE;
 };
 
 static const uint64_t kEmpty64 = ~0ull;
@@ -796,9 +800,9 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
-__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, unsigned char* xl, int lane,
+__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, LAS unsigned char* xl, int lane,
                                              const uint32_t* wcur, uint32_t (&nmacc)[2]) {
-    using L = WL<U, T, E, INK4>;
+    using L = WL<U, T, E, INK4, CPT>;
     constexpr int THM = L::TH - 1;
     // RELANE: values derived from the lane id (LDS addresses, masks) are cheap; re-deriving them per phase keeps the
     // register allocator from carrying (and spilling) them across the probe phase, where 34 VGPRs hold loads in flight
@@ -828,10 +832,10 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     unsigned long long* ukmer = (unsigned long long*)(lds + L::OFF_R2);
     uint32_t* ubucket = (uint32_t*)(lds + L::OFF_R2 + 8 * U);
     uint32_t* dpay = (uint32_t*)(lds + L::OFF_R2);
-    uint16_t* dmult = (uint16_t*)(lds + L::OFF_R2 + 4 * U);
-    uint16_t* dn = dmult + U;
-    uint16_t* dstart = dn + U;
-    uint8_t* dfl = (uint8_t*)(dstart + U);
+    uint16_t* dmult = (uint16_t*)(lds + L::OFF_R2 + 4 * L::D);
+    uint16_t* dn = dmult + L::D;
+    uint16_t* dstart = dn + L::D;
+    uint8_t* dfl = (uint8_t*)(dstart + L::D);
     LinEnt* lin = (LinEnt*)(lds + L::OFF_R2);
     // R3: payload per distinct k-mer, then the staged kept-list elements
     uint32_t* upay = (uint32_t*)(lds + (CPT ? L::OFF_UPAY_C : L::OFF_R3));
@@ -900,7 +904,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (w >= 1 && w - 1 < (uint32_t)L::RD_WORDS) rd[w - 1] = (w - 1 < nb + nm) ? wcur[j] : 0u;
     }
     if (!CPT) { for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64; }
-    else { *(u32x4*)(xl + 4096 + 16 * lane) = u32x4{0u, 0u, 0u, 0u}; }  // the repeat filter of the compact path
+    else { *(LAS u32x2*)(xl + 4096 + 8 * lane) = u32x2{0u, 0u}; }  // the repeat filter of the compact path
     WSYNC();
     const uint32_t* codes = rd;
     const uint32_t* vmask = rd + nb;
@@ -1171,12 +1175,12 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     // bucket.  A k-mer missing from a bucket that spilled (header bit) is looked up in the overflow table in one
     // batched pass at the end.  upay[] gets one entry per k-mer POSITION (0 for repeats, misses and invalid
     // windows): K3 only needs the payloads in first-occurrence order, which position order is.
-    uint32_t* stage = (uint32_t*)xl;
-    uint32_t* gbkt = (uint32_t*)(xl + 4096 - 256);  // bucket of group g while the loads are being issued: the tail of
-                                                    // the stage, which only the last wave-load of a full chunk overwrites
-    unsigned int* bloomA = (unsigned int*)(xl + 4096);
-    unsigned int* bloomB = (unsigned int*)(xl + 4096 + 512);
-    u32x4* olist = (u32x4*)(xl + 5120);             // k-mers to look up in the overflow table: k-mer, bucket, tag | position << 16
+    LAS uint32_t* stage = (LAS uint32_t*)xl;
+    LAS uint32_t* gbkt = (LAS uint32_t*)(xl + 4096 - 256);  // bucket of group g while the loads are being issued: the tail of
+                                                            // the stage, which only the last wave-load of a full chunk overwrites
+    LAS unsigned int* bloomA = (LAS unsigned int*)(xl + 4096);
+    LAS unsigned int* bloomB = (LAS unsigned int*)(xl + 4096 + 256);
+    LAS u32x4* olist = (LAS u32x4*)(xl + 4608);     // k-mers to look up in the overflow table: k-mer, bucket, tag | position << 16
     const GAS u32x4* quarters = (const GAS u32x4*)g_slots;
     uint64_t firstm[KC];
     // ---- repeats.  A k-mer seen twice in a read is looked up once (read_label.cpp:985,1010,1017).  Exact detection
@@ -1184,7 +1188,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     //      run of k-mers around ONE occurrence of their minimizer (same bucket, same minimizer position in the read:
     //      at most 4 k-mers).  Two positions with the same k-mer are then either in one group, hence within 3 bases
     //      of each other (compared directly, on a 32-bit digest), or in two groups with the same bucket (two
-    //      4096-bit filters over the buckets of the groups' first k-mers).
+    //      2048-bit filters over the buckets of the groups' first k-mers).
     bool suspect = !CACHE;
     if (CACHE) {
         uint32_t pb = 0, pq = 0, ps1 = 0, ps2 = 0, ps3 = 0;  // bucket / minimizer position / digests of the last lanes of the previous chunk
@@ -1205,8 +1209,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const uint32_t s3 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps3, (int)s2, 0x138, 0xf, 0xf, false);
             bool hit = ok && ((((V1 >> lane) & 1ull) && sig == s1) || (((V2 >> lane) & 1ull) && sig == s2) || (((V3 >> lane) & 1ull) && sig == s3));
             if (ok && !(((V1 >> lane) & 1ull) && b == bprev && q == qprev)) {  // opens a group
-                const uint32_t h1 = b & 4095u, h2 = (b >> 12) & 4095u;
-                const unsigned int oa = atomicOr(&bloomA[h1 >> 5], 1u << (h1 & 31)), ob = atomicOr(&bloomB[h2 >> 5], 1u << (h2 & 31));
+                const uint32_t h1 = b & 2047u, h2 = (b >> 11) & 2047u;
+                const unsigned int oa = __hip_atomic_fetch_or(&bloomA[h1 >> 5], 1u << (h1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned int ob = __hip_atomic_fetch_or(&bloomB[h2 >> 5], 1u << (h2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 hit |= ((oa >> (h1 & 31)) & (ob >> (h2 & 31)) & 1u) != 0;
             }
             seen |= __ballot(hit);
@@ -1259,31 +1264,29 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     RELANE();
     // ---- probe, chunk by chunk
     uint32_t nov = 0;  // entries of olist
-    auto ovf_pass = [&]() {  // looks the listed k-mers up in the overflow table (wide layout, linear probing)
+    auto ovf_pass = [&]() {  // looks the listed k-mers up in the overflow table: wide layout, linear probing, 4 lanes per bucket
+      for (uint32_t e0 = 0; e0 < nov; e0 += 16) {
         const GAS u32x4* oq = (const GAS u32x4*)tb.ovf_slots;
-        bool act = (uint32_t)lane < nov;
+        const uint32_t en = e0 + ((uint32_t)lane >> 2);
+        const int q4 = lane & 3;
+        bool act = en < nov;
         u32x4 e = {0u, 0u, 0u, 0u};
-        if (act) e = olist[lane];
+        if (act) e = olist[en];
         const uint64_t key1 = ((((uint64_t)e.y << 32) | e.x) << kPayloadBits) + 1;
         uint32_t ob = act ? ovf_bucket_of(e.z, e.w & 0xFFFFu, tb.ovf_nbuckets) : 0u;
         while (__ballot(act)) {
-            if (act) {
-                const u32x4 q0 = oq[(uint64_t)ob * 4], q1 = oq[(uint64_t)ob * 4 + 1], q2 = oq[(uint64_t)ob * 4 + 2], q3 = oq[(uint64_t)ob * 4 + 3];
-                const uint64_t sv[8] = {((uint64_t)q0.y << 32) | q0.x, ((uint64_t)q0.w << 32) | q0.z, ((uint64_t)q1.y << 32) | q1.x,
-                                        ((uint64_t)q1.w << 32) | q1.z, ((uint64_t)q2.y << 32) | q2.x, ((uint64_t)q2.w << 32) | q2.z,
-                                        ((uint64_t)q3.y << 32) | q3.x, ((uint64_t)q3.w << 32) | q3.z};
-                uint32_t pay = 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint64_t d = sv[j] - key1;
-                    if (d < 0xFFFFFFull) pay = (uint32_t)d + 1u;
-                }
-                if (pay) { upay[e.w >> 16] = pay; act = false; }
-                else if (sv[7] == 0) act = false;  // slots fill front to back: a free last slot ends the chain
-                else ob = ob + 1 == tb.ovf_nbuckets ? 0 : ob + 1;
-            }
+            u32x4 v = {1u, 0u, 1u, 0u};
+            if (act) v = oq[(uint64_t)ob * 4 + q4];
+            const uint64_t t0 = (((uint64_t)v.y << 32) | v.x) - key1, t1 = (((uint64_t)v.w << 32) | v.z) - key1;
+            const bool m0 = act && t0 < 0xFFFFFFull, m1 = act && t1 < 0xFFFFFFull;
+            if (m0 || m1) upay[e.w >> 16] = (uint32_t)(m0 ? t0 : t1) + 1u;
+            // found, or a free last slot (slots fill front to back) ends the chain for all four lanes of the entry
+            const uint32_t done = (uint32_t)(__ballot(m0 || m1 || (q4 == 3 && (v.z | v.w) == 0u)) >> (lane & ~3)) & 0xFu;
+            if (done) act = false;
+            else ob = ob + 1 == tb.ovf_nbuckets ? 0 : ob + 1;
         }
-        nov = 0;
+      }
+      nov = 0;
     };
     auto probe_chunk = [&](uint32_t p0, uint64_t km, uint32_t b, uint32_t tag, bool ok, bool first) {
         const uint32_t p = p0 + lane;
@@ -1302,7 +1305,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 if (g < ng) {
                     const uint32_t gb = gbkt[g];
                     __builtin_amdgcn_global_load_lds((const GAS void*)(quarters + (uint64_t)gb * 4 + (lane & 3)),
-                                                     (__attribute__((address_space(3))) void*)(xl + s * 1024), 16, 0, 0);
+                                                     (LAS void*)(xl + s * 1024), 16, 0, 0);
                 }
             }
         }
@@ -1311,18 +1314,21 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         uint32_t pay = 0;
         bool spill = false;
         if (ok) {
-            const uint32_t* bk = stage + gidx * 16;
-            const u32x4 t0 = *(const u32x4*)bk;
+            const LAS uint32_t* bk = stage + gidx * 16;
+            const u32x4 t0 = *(const LAS u32x4*)bk;
             const uint32_t t4 = bk[4], t5 = bk[5];
             const uint32_t key2 = tag * 0x10001u;
-            // bit 15 / bit 31 of z(x): the low / high half of x equals the tag (exact: tags are never 0, empty slots are)
-            auto z = [&](uint32_t x) -> uint32_t { x ^= key2; return ~(((x & 0x7FFF7FFFu) + 0x7FFF7FFFu) | x) & 0x80008000u; };
-            const uint32_t acc = (z(t0.x) >> 15) | ((z(t0.y) >> 15) << 1) | ((z(t0.z) >> 15) << 2) | ((z(t0.w) >> 15) << 3) |
-                                 ((z(t4) >> 15) << 4) | ((z(t5) >> 15) << 5);  // bit i: slot 2i, bit 16 + i: slot 2i + 1
+            // z(x): each 16-bit half is 0 where the slot's tag equals the k-mer's, else 1 (tags are never 0, empty slots are)
+            auto z = [&](uint32_t x) -> uint32_t {
+                const u16x2 d = __builtin_bit_cast(u16x2, x ^ key2), one = {1, 1};
+                return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, one));
+            };
+            const uint32_t miss = z(t0.x) | (z(t0.y) << 1) | (z(t0.z) << 2) | (z(t0.w) << 3) | (z(t4) << 4) | (z(t5) << 5);
+            const uint32_t acc = ~miss & 0x003F003Fu;  // bit i: slot 2i matches, bit 16 + i: slot 2i + 1
             if (acc) {
                 const uint32_t bit = (uint32_t)__builtin_ctz(acc);
                 const uint32_t slot = 2 * (bit & 15u) + (bit >> 4);
-                pay = (uint32_t)((const uint16_t*)bk)[12 + slot] | ((uint32_t)((const uint8_t*)bk)[48 + slot] << 16);
+                pay = (uint32_t)((const LAS uint16_t*)bk)[12 + slot] | ((uint32_t)((const LAS uint8_t*)bk)[48 + slot] << 16);
             } else {
                 spill = (bk[15] & kCptOvfFlag) != 0;
             }
@@ -1331,7 +1337,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const bool pend = first && spill;
         const uint64_t pm = __ballot(pend);
         if (pm) {
-            if (nov + (uint32_t)popc64(pm) > 64u) { WSYNC(); ovf_pass(); WSYNC(); }
+            if (nov + (uint32_t)popc64(pm) > 64u) { WSYNC(); ovf_pass(); WSYNC(); }  // the list holds 64 entries: one chunk's worth
             if (pend) olist[nov + (uint32_t)popc64(pm & lt_mask(lane))] = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, tag | (p << 16)};
             nov += (uint32_t)popc64(pm);
         }
@@ -1397,7 +1403,15 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             WSYNC();
         }
     }
-    if (many) {
+    if (many && !INK4) {  // more than 64 distinct taxid lists: a larger class takes the read
+        if (lane == 0) {
+            emit(255, 0);
+            if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;
+            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+        }
+        return;
+    }
+    if (INK4 && many) {
         for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64;
         WSYNC();
         for (uint32_t i0 = 0; i0 < nscan; i0 += 64) {
@@ -2131,12 +2145,12 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
-__global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs A) {
+__global__ __launch_bounds__(64, INK4 ? 1 : (CPT ? 7 : 5)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
     // U > 2048: the per-read tables of this workgroup live in global memory
-    unsigned char* smem = U > 2048 ? A.gscratch + (size_t)blockIdx.x * WL<U, T, E, INK4>::BYTES : lds_smem;
+    unsigned char* smem = U > 2048 ? A.gscratch + (size_t)blockIdx.x * WL<U, T, E, INK4, false>::BYTES : lds_smem;
     // scratch block of the compact-layout probe: always real LDS
-    unsigned char* xl = U > 2048 ? lds_smem : lds_smem + WL<U, T, E, INK4>::OFF_XL;
+    LAS unsigned char* xl = (LAS unsigned char*)(U > 2048 ? lds_smem : lds_smem + WL<U, T, E, INK4, CPT>::OFF_XL);
     const int lane = threadIdx.x & 63;
     const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
     const GAS uint32_t* index = (const GAS uint32_t*)A.index;
@@ -2145,7 +2159,7 @@ __global__ __launch_bounds__(64, INK4 ? 1 : 5) void classify_kernel(ClassifyArgs
     auto r_of = [&](uint64_t it) -> uint64_t { return index ? (uint64_t)index[it] : A.first + it; };
     // Software pipeline over the reads of this wave: the record offset is fetched two reads ahead and the
     // record words one read ahead, so a read never starts with a chain of dependent HBM round trips.
-    constexpr int NW = (WL<U, T, E, INK4>::RD_WORDS + 1 + 63) / 64;
+    constexpr int NW = (WL<U, T, E, INK4, CPT>::RD_WORDS + 1 + 63) / 64;
     const uint64_t G = gridDim.x;
     uint64_t it = blockIdx.x;
     if (it >= count) return;
@@ -2268,14 +2282,15 @@ void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, h
 
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
-    using L = WL<U, T, E, INK4>;
+    using L = WL<U, T, E, INK4, CPT>;
     if (U > 2048) {  // tables in global memory: few workgroups; LDS only for the compact probe's scratch block
         int grid = kGmemGrid;
         if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)(a.count ? a.count : 1);
         classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), CPT ? L::XL_BYTES : 0, stream>>>(a);
         return;
     }
-    constexpr int lds_bytes = CPT ? L::BYTES_C : L::BYTES;
+    static const int lds_pad = getenv("LMAT_LDS_PAD") ? atoi(getenv("LMAT_LDS_PAD")) : 0;  // experiments: fewer resident waves
+    const int lds_bytes = L::BYTES + lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
