@@ -159,12 +159,14 @@ void lmat_reads_free(lmat_ctx* ctx, lmat_reads* r);
  * Replaces proc_line (read_label.cpp:1211-1279) for reads [first, first+count).
  * results[count]; cands/cand_cap may be NULL/0 for calls-only output; *n_cands
  * receives the number of candidate pairs written.  Per-taxid tallies
- * (read_label.cpp:1241-1276) accumulate in the context until lmat_counts_reset. */
+ * (read_label.cpp:1241-1276) accumulate in the context until lmat_counts_reset; a call that fails (e.g.
+ * LMAT_E_CAPACITY because cand_cap was too small) leaves them as they were, so it can simply be retried. */
 int lmat_classify(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count, lmat_read_result* results,
                   lmat_cand* cands, uint64_t cand_cap, uint64_t* n_cands);
 
 /* Same kernels, results left in device memory (throughput runs).  Asynchronous on
- * the context's stream; lmat_sync waits.  kernel_ms_total (may be NULL) = HIP-event time of
+ * the context's stream; lmat_sync waits and reports an error raised by ANY launch since the last report
+ * (device-side error flags are sticky until reported).  kernel_ms_total (may be NULL) = HIP-event time of
  * all kernels of those launches; lmat_last_timing splits it per kernel.  The device-side result
  * buffer holds the records of the most recent launch only (lmat_results_fetch reads those); the
  * tallies accumulate over all launches. */

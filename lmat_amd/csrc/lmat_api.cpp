@@ -59,6 +59,7 @@ int upload_taxonomy(lmat_ctx* c) {
     c->dev.n_ids = T.n + 1;
     // tallies: u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     if (c->d_counts) { hipFree(c->d_counts); c->d_counts = nullptr; }
+    if (c->d_counts_bak) { hipFree(c->d_counts_bak); c->d_counts_bak = nullptr; }
     c->counts_bytes = (uint64_t)c->dev.n_ids * 16 + 24;
     HIPCHK(c, hipMalloc(&c->d_counts, c->counts_bytes));
     HIPCHK(c, hipMemset(c->d_counts, 0, c->counts_bytes));
@@ -107,7 +108,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
+                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
     for (void* p : ptrs)
         if (p) hipFree(p);
     sb_free(c);
@@ -817,9 +818,20 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     int rc = ensure_results(c, count, want_cands ? cand_cap : 0);
     if (rc) return rc;
     if (reads->n > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "read set above 2^32 reads");
-    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 64, c->stream));
+    if ((int)reads->max_len > classify_max_read_len())
+        return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+    if (!c->d_gscratch)  // per-read tables of the global-memory class (very long reads, very large taxid tables)
+        HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
+    // per-launch counters: the candidate cursor [0] and the list lengths [2..]; the error word [1] is sticky -- launches
+    // only OR into it and whoever reports it (lmat_sync, lmat_classify, lmat_rand_label) clears it
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cursor + 2, 0, 56, c->stream));
     ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    struct Ev {  // timing events of this launch: handed to the context on success, destroyed on any early return
+        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+        ~Ev() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); }
+    } ev;
+    hipEvent_t &e0 = ev.e[0], &e1 = ev.e[1], &e2 = ev.e[2], &e3 = ev.e[3];
     if (timed) {
         HIPCHK(c, hipEventCreate(&e0));
         HIPCHK(c, hipEventCreate(&e1));
@@ -827,10 +839,6 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         HIPCHK(c, hipEventCreate(&e3));
         HIPCHK(c, hipEventRecord(e0, c->stream));
     }
-    if ((int)reads->max_len > classify_max_read_len())
-        return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
-    if (!c->d_gscratch)  // per-read tables of the global-memory class (very long reads, very large taxid tables)
-        HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
     // Each read runs in the smallest fast class that holds it (160 / 256 / 512 k-mers; 512 = 531 bp at k = 20); longer
     // reads ride the overflow list to the wave-per-read classes behind it.  A batch of one class is one plain launch.
     {
@@ -874,7 +882,6 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipEventRecord(e2, c->stream));
-        c->pending_events.push_back(std::make_pair(e0, e1));
     }
     if (a.prm.stop_after == 0) {  // score + LCA decision, one lane per read
         if (!c->stream2) {
@@ -904,10 +911,28 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     }
     if (timed) {
         HIPCHK(c, hipEventRecord(e3, c->stream));
+        c->pending_events.push_back(std::make_pair(e0, e1));
         c->pending_events2.push_back(std::make_pair(e2, e3));
+        e0 = e1 = e2 = e3 = nullptr;
     }
     HIPCHK(c, hipGetLastError());
     return LMAT_OK;
+}
+
+// Reads and clears the sticky error word; maps it to the API's codes (the most specific message wins).
+static int report_device_errors(lmat_ctx* c, uint32_t* cand_cursor) {
+    uint32_t cur[2];
+    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    if (cand_cursor) *cand_cursor = cur[0];
+    if (!cur[1]) return LMAT_OK;
+    HIPCHK(c, hipMemset(c->d_cursor + 1, 0, 4));
+    if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
+    if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
+    if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
+    if (cur[1] & kErrTidOverflow)
+        return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
+    if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
+    return set_err(c, LMAT_E_DEVICE, "unknown device error flag");
 }
 
 int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, lmat_read_result* results,
@@ -915,26 +940,26 @@ int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t
     if (!c || !reads || (count && !results)) return LMAT_E_ARG;
     if (!count) { if (n_cands) *n_cands = 0; return LMAT_OK; }
     const bool want = cands != nullptr && cand_cap > 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        int rc = run_classify(c, reads, first, count, want, cand_cap, false);
-        if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        uint32_t cur[2];
-        HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
-        if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
-        if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
-        if (cur[1] & kErrCandOverflow) return set_err(c, LMAT_E_CAPACITY, "candidate buffer too small (cand_cap)");
-        if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
-        if (cur[1] & kErrTidOverflow)
-            return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
-        HIPCHK(c, hipMemcpy(results, c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
-        if (want) {
-            const uint64_t used = std::min<uint64_t>(cur[0], cand_cap);
-            if (used) HIPCHK(c, hipMemcpy(cands, c->d_cands, used * sizeof(lmat_cand), hipMemcpyDeviceToHost));
-            if (n_cands) *n_cands = used;
-        } else if (n_cands) *n_cands = 0;
-        return LMAT_OK;
+    hipSetDevice(c->device);
+    // a launch that ends in an error (say, cand_cap too small) has still tallied its reads: keep a copy of the tallies
+    // so that the caller's retry does not count the batch twice
+    if (c->d_counts && !c->d_counts_bak) HIPCHK(c, hipMalloc(&c->d_counts_bak, c->counts_bytes));
+    if (c->d_counts) HIPCHK(c, hipMemcpyAsync(c->d_counts_bak, c->d_counts, c->counts_bytes, hipMemcpyDeviceToDevice, c->stream));
+    int rc = run_classify(c, reads, first, count, want, cand_cap, false);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t cand_cursor = 0;
+    rc = report_device_errors(c, &cand_cursor);
+    if (rc) {
+        if (c->d_counts) HIPCHK(c, hipMemcpy(c->d_counts, c->d_counts_bak, c->counts_bytes, hipMemcpyDeviceToDevice));
+        return rc;
     }
+    HIPCHK(c, hipMemcpy(results, c->d_results, count * sizeof(lmat_read_result), hipMemcpyDeviceToHost));
+    if (want) {
+        const uint64_t used = std::min<uint64_t>(cand_cursor, cand_cap);
+        if (used) HIPCHK(c, hipMemcpy(cands, c->d_cands, used * sizeof(lmat_cand), hipMemcpyDeviceToHost));
+        if (n_cands) *n_cands = used;
+    } else if (n_cands) *n_cands = 0;
     return LMAT_OK;
 }
 
@@ -970,15 +995,13 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     c->kernel_ms_total = 0;
     c->kernel2_ms_total = 0;
     c->kernel_launches = 0;
-    uint32_t cur[6];
-    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 24, hipMemcpyDeviceToHost));
-    if (getenv("LMAT_DEBUG"))
-        fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags %u, reads re-run by the large class %u, by the global-memory class %u; "
-                        "K4 with small tables %u, with large tables %u\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
-    if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
-    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
-    if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
-    return LMAT_OK;
+    if (getenv("LMAT_DEBUG")) {
+        uint32_t cur[6];
+        HIPCHK(c, hipMemcpy(cur, c->d_cursor, 24, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags (all launches since the last report) %u, reads re-run by the large class %u, "
+                        "by the global-memory class %u; K4 with small tables %u, with large tables %u\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
+    }
+    return report_device_errors(c, nullptr);  // flags of every launch since the last report, not just the last one
 }
 
 int lmat_set_label_modes(lmat_ctx* c, int permissive, int tid_cutoff, const char* rank_map_fn) {
@@ -1042,11 +1065,7 @@ int lmat_rand_label(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64
     c->params = keep;
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint32_t cur[2];
-    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
-    if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
-    if (cur[1] & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
-    return LMAT_OK;
+    return report_device_errors(c, nullptr);
 }
 int lmat_rand_get(lmat_ctx* c, uint32_t* tid32, float* max_prob, uint32_t* cnt, uint32_t cap, uint32_t* n_rows) {
     if (!c || !n_rows) return LMAT_E_ARG;

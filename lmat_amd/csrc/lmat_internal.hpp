@@ -151,6 +151,7 @@ struct lmat_ctx {
     std::vector<void*> nm_allocs;
     uint64_t ovf_cap = 0;
     void* d_counts = nullptr;      // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
+    void* d_counts_bak = nullptr;  // tallies as they were before the current blocking launch (restored when it fails)
     uint64_t counts_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;   // around the classify kernel

@@ -13,12 +13,17 @@ def pytest_configure(config):
     # a fresh checkout has no built artefacts: compile the engine (hipcc cross-compiles without a GPU) and the
     # oracle once per session; the tests themselves never fall back to anything if this fails
     import subprocess
+
+    def make(*args):
+        r = subprocess.run(["make", *args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            pytest.exit("build failed: make %s\n%s" % (" ".join(args), r.stdout[-4000:]), returncode=2)
+
     if not os.path.exists(os.path.join(ROOT, "lmat_amd", "liblmat_hip.so")) or \
             not os.path.exists(os.path.join(ROOT, "lmat_amd", "csrc", "read_label")):
-        subprocess.call(["make", "-C", os.path.join(ROOT, "lmat_amd", "csrc"), "all"], stdout=subprocess.DEVNULL)
+        make("-C", os.path.join(ROOT, "lmat_amd", "csrc"), "all")
     if not os.path.exists(os.path.join(ROOT, "oracle", "liblmat_oracle.so")):
-        subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "lmat_oracle", "liblmat_oracle.so"],
-                        stdout=subprocess.DEVNULL)
+        make("-C", os.path.join(ROOT, "oracle"), "lmat_oracle", "liblmat_oracle.so")
 
 
 @pytest.fixture(scope="session")

@@ -63,8 +63,12 @@ def test_two_rank_gloo_merge_equals_single_process(small_dataset, oracle_small, 
     w.write_text(WORKER)
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket() as sk:  # a free port: concurrent runs on one host must not collide
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29613", str(w), ROOT, str(cfg), out],
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(w), ROOT, str(cfg), out],
                           env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
     reads = ds["reads"]
     bs = [r.encode() for r in reads]

@@ -677,3 +677,72 @@ def test_gpu_extraction_against_the_example_run(monkeypatch):
             n_dup += exp != len(read) - 19
     assert n_dup >= 40
     eng.close()
+
+
+# ---- error reporting of the asynchronous path ---------------------------------------------------------------
+def test_error_in_a_middle_launch_surfaces_at_sync(nullmodel_ds, tmp_path):
+    """Device-side error flags are sticky: of three queued launches only the middle one meets a taxid without a null
+    model (upstream asserts there, read_label.cpp:768-775); lmat_sync must still report it, once."""
+    import gzip
+    from lmat_amd import Engine, Params
+    from lmat_amd.capi import LmatError
+    ds = nullmodel_ds
+    # null models with the root's first child (and nothing else) removed: every read below it fails the lookup
+    tree_lines = open(ds["tree"]).read().split("\n")
+    drop = None
+    nmdir = os.path.join(str(tmp_path), "nm")
+    os.makedirs(nmdir)
+    lst = os.path.join(nmdir, "null_lst.txt")
+    with open(lst, "w") as lf:
+        for line in open(ds["null_lst"]):
+            kc, name = line.split()
+            lf.write(f"{kc} {name}\n")
+            rows = gzip.open(os.path.join(ds["lmat_dir"], name), "rt").read().split("\n")
+            if drop is None:
+                drop = [r.split()[0] for r in rows[1:] if r and r.split()[0] != "1"][0]
+            with gzip.open(os.path.join(nmdir, name), "wt") as g:
+                g.write("\n".join(r for r in rows if not r or r.split()[0] != drop))
+    os.environ["LMAT_DIR"] = nmdir
+    eng = Engine(0, Params.run_rl(prn_all=0))
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    eng.build_db(ds["db"], k=20)
+    eng.load_null_models(lst)
+    short = ["ACGTACGTAC"] * 64                       # below k: no lookups at all
+    normal = [r for r in ds["reads"] if len(r) >= 100][:512]
+    dr = eng.upload_reads(short + normal + short)
+    eng.classify_async(dr, 0, 64)
+    eng.classify_async(dr, 64, len(normal))
+    eng.classify_async(dr, 64 + len(normal), 64)
+    with pytest.raises(LmatError) as ei:
+        eng.sync()
+    assert ei.value.code == -5 and "NULL MODELS" in str(ei.value)
+    eng.sync()                                        # reported once, then clear
+    eng.classify_async(dr, 0, 64)
+    eng.sync()
+    os.environ["LMAT_DIR"] = ds["lmat_dir"]
+    dr.free()
+    eng.close()
+
+
+def test_failed_blocking_launch_leaves_the_tallies_alone(small_dataset):
+    """lmat_classify with a candidate buffer that is too small fails with LMAT_E_CAPACITY; the documented retry with a
+    larger buffer must not count the batch twice."""
+    from lmat_amd import Engine, Params
+    from lmat_amd.capi import LmatError
+    ds = small_dataset
+    eng = Engine(0, Params.run_rl())
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    eng.build_db(ds["db"], k=20)
+    dr = eng.upload_reads(ds["reads"])
+    eng.counts_reset()
+    with pytest.raises(LmatError) as ei:
+        eng.classify(dr, cand_cap=8)
+    assert ei.value.code == -4
+    assert eng.counts() == ({}, [0, 0, 0])
+    eng.classify(dr)
+    once = eng.counts()
+    eng.counts_reset()
+    eng.classify(dr)
+    assert eng.counts() == once and sum(c for c, _ in once[0].values()) > 100
+    dr.free()
+    eng.close()
