@@ -216,14 +216,20 @@ def test_async_and_calls_only_agree_with_full_output(config1):
     eng.close()
 
 
-def test_full_size_sample_parity(tmp_path):
-    """BASELINE config[1] (1 M reads vs an 8 GB DB; LMAT_TEST_DB_GB overrides): the whole batch runs on the GPU;
-    a 20 k-read sample is re-derived by the CPU oracle from the GPU table's own lookups and must match byte for
-    byte; size-independent properties are checked on all reads."""
+@pytest.mark.parametrize("gb,n_reads,lens", [(8, 1_000_000, (150,)), (64, 2_000_000, (150,)),
+                                             (186, 2_000_000, (75, 100, 125, 150, 200, 250, 300))],
+                         ids=["config2-8GiB", "config3-64GiB", "config5-shard-186GiB-mixed"])
+def test_full_size_sample_parity(tmp_path, gb, n_reads, lens):
+    """BASELINE configs at full table size on one GPU: [1] 1 M reads vs an 8 GB DB, [2] the 64 GB roofline DB, and the
+    single-GPU shard of [4]: a 200 GB-class DB (20 G 20-mers, near HBM capacity) with reads of 75-300 bp.  The whole
+    batch runs on the GPU; a 20 k-read sample is re-derived by the CPU oracle from the GPU table's own lookups and
+    must match byte for byte; size-independent properties are checked on all reads.  (LMAT_TEST_DB_GB /
+    LMAT_TEST_READS override the first case.)"""
     from lmat_amd import Engine, Params, synth
     import oracle_py
-    gb = float(os.environ.get("LMAT_TEST_DB_GB", "8"))
-    n_reads = int(os.environ.get("LMAT_TEST_READS", "1000000"))
+    if gb == 8:
+        gb = float(os.environ.get("LMAT_TEST_DB_GB", "8"))
+        n_reads = int(os.environ.get("LMAT_TEST_READS", str(n_reads)))
     br = (3, 4, 4, 4, 4, 3)
     eng = Engine(0, Params.run_rl())
     eng.synth_taxonomy(br)
@@ -231,7 +237,7 @@ def test_full_size_sample_parity(tmp_path):
     Glen = int(0.8 * (table_bytes / 8) / (768 * (1.0 + 3 * (1 - 0.99 ** 20))))
     eng.synth_db(Glen, k=20, seed=2002, table_bytes=table_bytes)
     assert eng.db_size > 0.7 * table_bytes / 8
-    reads = eng.synth_reads(n_reads, (150,), seed=3003)
+    reads = eng.synth_reads(n_reads, lens, seed=3003)
     eng.counts_reset()
     res, cands = eng.classify(reads, cand_cap=40 * n_reads)
     counts, nomatch = eng.counts()
@@ -239,8 +245,12 @@ def test_full_size_sample_parity(tmp_path):
     assert st.sum() == n_reads and st[0] > 0.8 * n_reads
     assert sum(c for c, _ in counts.values()) + sum(nomatch) == n_reads
     assert (res["valid_kmers"][res["status"] == 0] >= 30).all()
+    assert set(np.unique(res["read_len"]).tolist()) == set(lens)
     # genome-sampled reads without N: every k-mer is valid
-    assert (res["valid_kmers"] == 131).mean() > 0.97
+    assert (res["valid_kmers"] == res["read_len"] - 19).mean() > 0.97
+    # a call is one of its own candidates or an ancestor reached by the LCA walk: its score is a k-mer fraction
+    called = res[res["status"] == 0]
+    assert (called["call_score"] > 0).all() and (called["call_score"] <= 1.0).all()
     # sample parity through the oracle
     ns = 20000
     tax = synth.make_taxonomy(br, specials=False)
