@@ -138,6 +138,30 @@ int orc_path_to_root(orc_ctx* c, uint32_t tid, uint32_t* out, int cap) {
     return (int)p.size();
 }
 
+// The decision step alone (std::sort with TCmp + findReadLabelVer2, src/read_label.cpp:892-896, 284-419) on a
+// given candidate set: scores as construct_labels holds them after the human bias, stdev as it printed it.
+// Lets the tests replay records of the reference's own example run.  match: 0 Direct, 1 Multi, 2 Partial, 3 NoMatch, 4 LCA error.
+int orc_replay_decision(orc_ctx* c, const uint32_t* tids, const float* scores, int n, float stdev, uint32_t* call_tid,
+                        float* call_score, int* match) {
+    Classifier cls(c->tax, c->db, c->opt);
+    std::vector<ufpair_t> rank_label;
+    std::unordered_map<tid_t, float> all_cand_set;
+    float top = 0;
+    for (int i = 0; i < n; ++i) {
+        rank_label.push_back(std::make_pair((tid_t)tids[i], scores[i]));
+        all_cand_set[tids[i]] = scores[i];
+        if (i == 0 || scores[i] > top) top = scores[i];
+    }
+    Classifier::TCmp tcmp{&c->tax};
+    std::sort(rank_label.begin(), rank_label.end(), tcmp);
+    std::list<ufpair_t> valid_cand;
+    const auto res = cls.find_read_label(rank_label, stdev * c->opt.diff_thresh, valid_cand, all_cand_set, top);
+    *call_tid = res.first.first;
+    *call_score = res.first.second;
+    *match = (int)res.second;
+    return 0;
+}
+
 void orc_set_options(orc_ctx* c, float sdiff, float hbias, int prn_all, int screen_phix, float min_score, int min_kmer,
                      int min_fnd_kmer, int prn_read, int fastq) {
     c->opt.diff_thresh = sdiff;

@@ -59,6 +59,7 @@ def _load():
     L.orc_rand_label.restype = i32
     L.orc_rand_label.argtypes = [vp, vp, vp, u64, i32, vp, C.c_uint32, vp, vp, vp, C.c_uint32]
     L.orc_run_file.restype = C.c_long
+    L.orc_replay_decision.argtypes = [vp, vp, vp, i32, C.c_float, vp, vp, vp]
     L.orc_run_file.argtypes = [vp, cp, i32, cp, vp, C.c_long, vp, C.c_long]
     return L
 
@@ -160,6 +161,15 @@ class Oracle:
                     prn_read=1, fastq=0):
         self.L.orc_set_options(self.h, sdiff, hbias, prn_all, screen_phix, min_score, min_kmer, min_fnd_kmer, prn_read,
                                fastq)
+
+    def replay_decision(self, tids, scores, stdev):
+        """TCmp sort + findReadLabelVer2 on a given candidate set -> (call taxid, call score, match code)."""
+        t = np.ascontiguousarray(tids, dtype=np.uint32)
+        s = np.ascontiguousarray(scores, dtype=np.float32)
+        ct, cs, m = C.c_uint32(0), C.c_float(0), C.c_int(0)
+        self.L.orc_replay_decision(self.h, t.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), len(t), float(stdev),
+                                   C.byref(ct), C.byref(cs), C.byref(m))
+        return int(ct.value), float(cs.value), int(m.value)
 
     def extract(self, read: bytes, k=20):
         cap = max(len(read), 1)
