@@ -31,6 +31,7 @@ extern "C" {
 typedef struct lmat_ctx lmat_ctx;
 typedef struct lmat_reads lmat_reads;
 typedef struct lmat_ingest lmat_ingest;
+typedef struct lmat_stream lmat_stream;
 
 /* ScoreOptions + the scalar thresholds proc_line takes
  * (src/read_label.cpp:487-497, :1211-1212, getopt cases :1353-1441). */
@@ -178,6 +179,27 @@ int lmat_sync(lmat_ctx* ctx, float* kernel_ms_total, uint64_t* kernel_launches);
 int lmat_last_timing(const lmat_ctx* ctx, float* classify_ms, float* decide_ms, uint64_t* launches);
 int lmat_results_fetch(lmat_ctx* ctx, uint64_t first, uint64_t count, lmat_read_result* results);
 
+/* ---- streamed boundary -------------------------------------------------------
+ * Replaces the reader thread + (read, hdr) queue of main() (src/read_label.cpp:1651-1746): a ring of n_slots batch slots
+ * whose pinned host buffers and device buffers are allocated once.  Host-to-device copy, packing + classification and
+ * the copy of the results back overlap across consecutive batches; nothing is allocated per batch.
+ *   acquire  -> pointers to the next slot's pinned input buffers: bases (concatenated ASCII, up to max_bases) and
+ *               off[n + 1] byte offsets; the caller fills them (LMAT_E_ARG when every slot is in use)
+ *   submit   -> queues the slot: n reads, an opaque tag that comes back with the results; asynchronous
+ *   next     -> waits for the OLDEST submitted batch; pointers into its pinned result buffers (cands in the order of
+ *               lmat_read_result.cand_off), valid until lmat_stream_release; returns 1 when nothing is in flight
+ *   release  -> the batch handed out by lmat_stream_next is consumed, its slot is free again
+ * cands_per_read = 0: calls only; otherwise the slot holds cands_per_read x max_reads candidate pairs and grows itself
+ * when a batch needs more.  Tallies accumulate in the context as with lmat_classify.  One thread drives a stream. */
+int lmat_stream_create(lmat_ctx* ctx, uint64_t max_reads, uint64_t max_bases, uint32_t cands_per_read, int n_slots,
+                       lmat_stream** out);
+int lmat_stream_acquire(lmat_stream* st, uint8_t** bases, uint64_t** off);
+int lmat_stream_submit(lmat_stream* st, uint64_t n_reads, uint64_t tag);
+int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lmat_cand** cands, uint64_t* n_reads,
+                     uint64_t* n_cands, uint64_t* tag);
+int lmat_stream_release(lmat_stream* st);
+void lmat_stream_destroy(lmat_stream* st);
+
 /* ---- tallies (merge step read_label.cpp:1760-1800) --------------------------
  * Dense arrays indexed by the engine's internal taxid index; n_ids = number of
  * internal ids + 1.  counts_device_ptr exposes the device buffer
@@ -188,6 +210,9 @@ int lmat_counts_layout(const lmat_ctx* ctx, uint32_t* n_ids, uint64_t* bytes);
 void* lmat_counts_device_ptr(lmat_ctx* ctx);
 int lmat_counts_get(lmat_ctx* ctx, uint32_t* tid32, uint64_t* count, double* score, uint32_t cap, uint32_t* n_nonzero,
                     uint64_t nomatch3[3]);
+/* The same merge across the contexts of one process (one per GPU, read_label -t N on an N-GPU node): afterwards every
+ * context holds the sum of all.  Host-side sum of the ~50 KB arrays. */
+int lmat_counts_allreduce(lmat_ctx** ctxs, int n_ctx);
 
 /* ---- rand_read_label: the null-model generator (src/rand_read_label.cpp) on the same kernels -----------
  * Replaces its proc_line/construct_labels (:185-213, :372-398) over src/rkmer.hpp's retrieve_kmer_labels, which is

@@ -5,4 +5,4 @@ built from lmat_amd/csrc (hand-written HIP for gfx950).  This package is only th
 thin ctypes mirror of that ABI used by the tests and bench.py; it has no CPU
 implementation and raises if the library is missing.
 """
-from .capi import Engine, Ingest, LmatError, Params, Reads, load_library, READ_RESULT_DTYPE, CAND_DTYPE  # noqa: F401
+from .capi import Engine, Ingest, LmatError, Params, Reads, Stream, load_library, READ_RESULT_DTYPE, CAND_DTYPE  # noqa: F401

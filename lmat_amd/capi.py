@@ -100,6 +100,13 @@ def load_library(path: str | None = None):
         "lmat_counts_device_ptr": (vp, [vp]),
         "lmat_counts_get": (i32, [vp, vp, vp, vp, u32, P(u32), vp]),
         "lmat_gather_bench": (i32, [vp, u64, u64, P(C.c_float), P(u64)]),
+        "lmat_stream_create": (i32, [vp, u64, u64, u32, i32, P(vp)]),
+        "lmat_stream_acquire": (i32, [vp, P(vp), P(vp)]),
+        "lmat_stream_submit": (i32, [vp, u64, u64]),
+        "lmat_stream_next": (i32, [vp, P(vp), P(vp), P(u64), P(u64), P(u64)]),
+        "lmat_stream_release": (i32, [vp]),
+        "lmat_stream_destroy": (None, [vp]),
+        "lmat_counts_allreduce": (i32, [P(vp), i32]),
         "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
     }
@@ -122,7 +129,8 @@ EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
-            "lmat_table_address", "lmat_format_out"]
+            "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit",
+            "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce"]
 
 
 def _ptr(a):
@@ -199,6 +207,50 @@ class Ingest:
     def close(self):
         if self.h:
             self.lib.lmat_ingest_destroy(self.h)
+            self.h = None
+
+
+class Stream:
+    """lmat_stream: a ring of pinned batch slots; copy in, classification and copy out of consecutive batches overlap."""
+
+    def __init__(self, eng, max_reads, max_bases, cands_per_read=0, n_slots=3):
+        self.eng, self.lib = eng, eng.lib
+        self.max_reads, self.max_bases, self.n_slots = int(max_reads), int(max_bases), n_slots
+        h = C.c_void_p()
+        eng._chk(self.lib.lmat_stream_create(eng.ctx, self.max_reads, self.max_bases, cands_per_read, n_slots, C.byref(h)))
+        self.h = h
+        self.in_flight = 0
+
+    def submit(self, blob, off, tag=0):
+        """blob: uint8 ASCII bases, off: uint64[n + 1]; copied into the slot's pinned buffers, then queued."""
+        pb, po = C.c_void_p(), C.c_void_p()
+        self.eng._chk(self.lib.lmat_stream_acquire(self.h, C.byref(pb), C.byref(po)))
+        n = off.size - 1
+        nb = int(off[-1])
+        C.memmove(pb, blob.ctypes.data, nb)
+        C.memmove(po, off.ctypes.data, (n + 1) * 8)
+        self.eng._chk(self.lib.lmat_stream_submit(self.h, n, tag))
+        self.in_flight += 1
+
+    def next(self):
+        """-> (results copy, cands copy or None, tag) of the oldest batch, or None when nothing is in flight."""
+        pr, pc = C.c_void_p(), C.c_void_p()
+        n, nc, tag = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = self.lib.lmat_stream_next(self.h, C.byref(pr), C.byref(pc), C.byref(n), C.byref(nc), C.byref(tag))
+        if rc == 1:
+            return None
+        self.eng._chk(rc)
+        res = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint8)), shape=(n.value * READ_RESULT_DTYPE.itemsize,)).view(READ_RESULT_DTYPE).copy() if n.value else np.zeros(0, READ_RESULT_DTYPE)
+        cands = None
+        if pc.value and nc.value:
+            cands = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint8)), shape=(nc.value * CAND_DTYPE.itemsize,)).view(CAND_DTYPE).copy()
+        self.eng._chk(self.lib.lmat_stream_release(self.h))
+        self.in_flight -= 1
+        return res, cands, int(tag.value)
+
+    def close(self):
+        if self.h:
+            self.lib.lmat_stream_destroy(self.h)
             self.h = None
 
 

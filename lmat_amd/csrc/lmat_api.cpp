@@ -743,6 +743,16 @@ static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
         HIPCHK(c, hipMalloc((void**)&c->d_results, count * sizeof(lmat_read_result)));
         c->results_cap = count;
     }
+    if (cand_cap > c->cands_cap) {
+        if (c->d_cands) hipFree(c->d_cands);
+        c->d_cands = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_cands, cand_cap * sizeof(lmat_cand)));
+        c->cands_cap = cand_cap;
+    }
+    return LMAT_OK;
+}
+// per-batch scratch of the kernels (overflow lists, the K4 hand-off records): sized by the largest batch so far
+static int ensure_scratch(lmat_ctx* c, uint64_t count) {
     if (count > c->ovf_cap) {
         if (c->d_ovf) hipFree(c->d_ovf);
         if (c->d_k4buf) hipFree(c->d_k4buf);
@@ -763,12 +773,6 @@ static int ensure_results(lmat_ctx* c, uint64_t count, uint64_t cand_cap) {
         HIPCHK(c, hipMalloc((void**)&c->d_ovf2, count * sizeof(uint32_t)));
         c->ovf_cap = count;
     }
-    if (cand_cap > c->cands_cap) {
-        if (c->d_cands) hipFree(c->d_cands);
-        c->d_cands = nullptr;
-        HIPCHK(c, hipMalloc((void**)&c->d_cands, cand_cap * sizeof(lmat_cand)));
-        c->cands_cap = cand_cap;
-    }
     return LMAT_OK;
 }
 
@@ -784,11 +788,11 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.first = first;
     a.count = count;
     a.result_base = first;
-    a.results = c->d_results;
-    a.cands = want_cands ? c->d_cands : nullptr;
+    a.results = c->out_results ? c->out_results : c->d_results;
+    a.cands = want_cands ? (c->out_cands ? c->out_cands : c->d_cands) : nullptr;
     a.cand_cap = cand_cap;
     a.cursor = c->d_cursor;
-    a.counts = c->d_counts;
+    a.counts = c->out_counts ? c->out_counts : c->d_counts;
     auto it = c->tax.index_of.find(32630);
     a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
     a.ovf_list = c->d_ovf;
@@ -815,7 +819,8 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     if (first + count > reads->n) return set_err(c, LMAT_E_ARG, "read range out of bounds");
     if (count > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "batch above 2^32 reads");
     hipSetDevice(c->device);
-    int rc = ensure_results(c, count, want_cands ? cand_cap : 0);
+    int rc = ensure_results(c, c->out_results ? 0 : count, want_cands && !c->out_cands ? cand_cap : 0);
+    if (!rc) rc = ensure_scratch(c, count);
     if (rc) return rc;
     if (reads->n > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "read set above 2^32 reads");
     if ((int)reads->max_len > classify_max_read_len())
@@ -844,7 +849,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     {
         lmat_reads* rw = const_cast<lmat_reads*>(reads);
         const uint32_t k = (uint32_t)c->dev.k;
-        if (rw->cls_k != (int)k && rw->lens.size() == rw->n) {
+        if (!rw->preset && rw->cls_k != (int)k && rw->lens.size() == rw->n) {
             for (int j = 0; j < 3; ++j) { rw->cls_host[j].clear(); if (rw->cls_dev[j]) { hipFree(rw->cls_dev[j]); rw->cls_dev[j] = nullptr; } }
             for (uint64_t i = 0; i < rw->n; ++i) {
                 const uint32_t P = rw->lens[i] >= k ? rw->lens[i] - k + 1 : 0;
@@ -862,7 +867,22 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         }
         const uint32_t cls_len[3] = {160 + k - 1, 256 + k - 1, 512 + k - 1};
         bool mixed = rw->cls_dev[0] || rw->cls_dev[1] || rw->cls_dev[2];
-        if (!mixed) {
+        if (rw->preset) {  // a stream slot: lists over the whole batch, already on the device
+            const int used = (rw->cls_n[0] != 0) + (rw->cls_n[1] != 0) + (rw->cls_n[2] != 0);
+            if (used <= 1) {
+                if (!launch_classify(a, std::min<uint32_t>(reads->max_len, 512 + k - 1), 0, c->stream))
+                    return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+            } else {
+                for (int j = 0; j < 3; ++j) {
+                    if (!rw->cls_n[j]) continue;
+                    ClassifyArgs s = a;
+                    s.index = rw->cls_dev[j];
+                    s.count = rw->cls_n[j];
+                    if (!launch_classify(s, cls_len[j], 0, c->stream))
+                        return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+                }
+            }
+        } else if (!mixed) {
             if (!launch_classify(a, std::min<uint32_t>(reads->max_len, 512 + k - 1), 0, c->stream))
                 return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
         } else {
@@ -1187,6 +1207,266 @@ int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, 
     if (ms) *ms = t;
     const uint64_t per_wave = bpp == 128 ? (n_probes / 4096 + 71) / 72 * 72 : (n_probes / 4096 + 143) / 144 * 144;
     if (bytes) *bytes = per_wave * 4096 * (uint64_t)bpp;
+    return LMAT_OK;
+}
+
+// ---------------------------------------------------------------------------------- streamed boundary
+// A ring of batch slots with everything a batch needs allocated once: pinned host buffers (ASCII in, results out) and
+// their device twins.  H2D, pack + classify and D2H of consecutive batches overlap on three HIP streams, which is the
+// overlap upstream gets from its reader thread and (read, hdr) queue (src/read_label.cpp:1651-1746).  Nothing is
+// allocated or freed on the per-batch path.
+struct lmat_stream {
+    struct Slot {
+        uint8_t* h_bases = nullptr;  uint64_t* h_off = nullptr;      // pinned: filled by the caller
+        uint64_t* h_rec_off = nullptr; uint32_t* h_cls[3] = {nullptr, nullptr, nullptr};
+        lmat_read_result* h_results = nullptr; lmat_cand* h_cands = nullptr; uint32_t* h_cursor = nullptr;  // pinned: filled by the engine
+        uint8_t* d_bases = nullptr; uint64_t* d_off = nullptr;
+        lmat_read_result* d_results = nullptr; lmat_cand* d_cands = nullptr;
+        uint64_t cand_cap = 0;
+        lmat_reads reads;            // packed records + class lists (device)
+        hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_out = nullptr;
+        uint64_t n = 0, tag = 0;
+        int state = 0;               // 0 free, 1 acquired, 2 in flight, 3 handed to the caller
+    };
+    lmat_ctx* c = nullptr;
+    std::vector<Slot> slots;
+    uint64_t max_reads = 0, max_bases = 0;
+    uint32_t cands_per_read = 0;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    uint64_t head = 0, tail = 0;     // slot of the next acquire / of the oldest batch in flight (monotonic counters)
+    uint32_t reported = 0;           // device error flags already returned to the caller
+    void* d_scratch_counts = nullptr;  // tallies of a re-run go nowhere
+};
+
+static void stream_free(lmat_stream* st) {
+    if (!st) return;
+    hipSetDevice(st->c->device);
+    hipDeviceSynchronize();
+    for (auto& sl : st->slots) {
+        void* pinned[] = {sl.h_bases, sl.h_off, sl.h_rec_off, sl.h_cls[0], sl.h_cls[1], sl.h_cls[2], sl.h_results, sl.h_cands, sl.h_cursor};
+        for (void* p : pinned) if (p) hipHostFree(p);
+        void* dev[] = {sl.d_bases, sl.d_off, sl.d_results, sl.d_cands, sl.reads.words, sl.reads.rec_off, sl.reads.cls_dev[0], sl.reads.cls_dev[1], sl.reads.cls_dev[2]};
+        for (void* p : dev) if (p) hipFree(p);
+        sl.reads.words = nullptr; sl.reads.rec_off = nullptr;
+        for (int j = 0; j < 3; ++j) sl.reads.cls_dev[j] = nullptr;
+        if (sl.ev_up) hipEventDestroy(sl.ev_up);
+        if (sl.ev_done) hipEventDestroy(sl.ev_done);
+        if (sl.ev_out) hipEventDestroy(sl.ev_out);
+    }
+    if (st->d_scratch_counts) hipFree(st->d_scratch_counts);
+    if (st->s_h2d) hipStreamDestroy(st->s_h2d);
+    if (st->s_d2h) hipStreamDestroy(st->s_d2h);
+    delete st;
+}
+
+int lmat_stream_create(lmat_ctx* c, uint64_t max_reads, uint64_t max_bases, uint32_t cands_per_read, int n_slots, lmat_stream** out) {
+    if (!c || !out || !max_reads || !max_bases || n_slots < 1 || n_slots > 8) return LMAT_E_ARG;
+    *out = nullptr;
+    if (!c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
+    if (max_reads > 0x7FFFFFFFull) return set_err(c, LMAT_E_ARG, "batch above 2^31 reads");
+    hipSetDevice(c->device);
+    lmat_stream* st = new lmat_stream();
+    st->c = c;
+    st->max_reads = max_reads;
+    st->max_bases = max_bases;
+    st->cands_per_read = cands_per_read;
+    st->slots.resize(n_slots);
+    bool ok = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(&st->d_scratch_counts, c->counts_bytes) == hipSuccess;
+    const uint64_t max_words = max_bases / 16 + max_bases / 32 + 3 * max_reads + 16;  // rec_words summed, rounded up per read
+    for (auto& sl : st->slots) {
+        if (!ok) break;
+        sl.cand_cap = (uint64_t)cands_per_read * max_reads;
+        ok = hipHostMalloc((void**)&sl.h_bases, max_bases + 16, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&sl.h_off, (max_reads + 1) * 8, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&sl.h_rec_off, (max_reads + 1) * 8, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&sl.h_results, max_reads * sizeof(lmat_read_result), hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&sl.h_cursor, 64, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void**)&sl.d_bases, max_bases + 16) == hipSuccess && hipMalloc((void**)&sl.d_off, (max_reads + 1) * 8) == hipSuccess &&
+             hipMalloc((void**)&sl.d_results, max_reads * sizeof(lmat_read_result)) == hipSuccess &&
+             hipMalloc((void**)&sl.reads.words, max_words * 4 + 16384) == hipSuccess &&  // kernels read whole-record tiles: pad
+             hipMalloc((void**)&sl.reads.rec_off, (max_reads + 1) * 8) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming) == hipSuccess;
+        for (int j = 0; j < 3 && ok; ++j)
+            ok = hipHostMalloc((void**)&sl.h_cls[j], max_reads * 4, hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void**)&sl.reads.cls_dev[j], max_reads * 4) == hipSuccess;
+        if (ok && sl.cand_cap)
+            ok = hipHostMalloc((void**)&sl.h_cands, sl.cand_cap * sizeof(lmat_cand), hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void**)&sl.d_cands, sl.cand_cap * sizeof(lmat_cand)) == hipSuccess;
+        sl.reads.preset = true;
+    }
+    if (ok) ok = ensure_scratch(c, max_reads) == LMAT_OK;
+    if (!ok) { stream_free(st); return set_err(c, LMAT_E_NOMEM, "out of (pinned or device) memory for the batch ring"); }
+    *out = st;
+    return LMAT_OK;
+}
+
+void lmat_stream_destroy(lmat_stream* st) { stream_free(st); }
+
+int lmat_stream_acquire(lmat_stream* st, uint8_t** bases, uint64_t** off) {
+    if (!st || !bases || !off) return LMAT_E_ARG;
+    lmat_stream::Slot& sl = st->slots[st->head % st->slots.size()];
+    if (sl.state != 0) return set_err(st->c, LMAT_E_ARG, "every slot is in use: take (lmat_stream_next) and release the oldest batch first");
+    sl.state = 1;
+    *bases = sl.h_bases;
+    *off = sl.h_off;
+    return LMAT_OK;
+}
+
+static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch_counts) {
+    lmat_ctx* c = st->c;
+    c->out_results = sl.d_results;
+    c->out_cands = sl.d_cands;
+    c->out_counts = to_scratch_counts ? st->d_scratch_counts : nullptr;
+    const int rc = run_classify(c, &sl.reads, 0, sl.n, sl.cand_cap != 0, sl.cand_cap, false);
+    c->out_results = nullptr; c->out_cands = nullptr; c->out_counts = nullptr;
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(sl.h_cursor, c->d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(sl.ev_done, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_done, 0));
+    HIPCHK(c, hipMemcpyAsync(sl.h_results, sl.d_results, sl.n * sizeof(lmat_read_result), hipMemcpyDeviceToHost, st->s_d2h));
+    HIPCHK(c, hipEventRecord(sl.ev_out, st->s_d2h));
+    return LMAT_OK;
+}
+
+int lmat_stream_submit(lmat_stream* st, uint64_t n, uint64_t tag) {
+    if (!st) return LMAT_E_ARG;
+    lmat_ctx* c = st->c;
+    lmat_stream::Slot& sl = st->slots[st->head % st->slots.size()];
+    if (sl.state != 1) return set_err(c, LMAT_E_ARG, "lmat_stream_acquire first");
+    if (n > st->max_reads || (n && sl.h_off[n] > st->max_bases)) { sl.state = 0; return set_err(c, LMAT_E_ARG, "batch larger than the stream was created for"); }
+    hipSetDevice(c->device);
+    // record offsets and the length classes of the fast kernels (host: a pass over n offsets)
+    const uint32_t k = (uint32_t)c->dev.k;
+    uint32_t max_len = 0;
+    uint64_t cn[3] = {0, 0, 0};
+    sl.h_rec_off[0] = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t len = sl.h_off[i + 1] - sl.h_off[i];
+        if (sl.h_off[i + 1] < sl.h_off[i] || len > 0x7FFFFFFF) { sl.state = 0; return set_err(c, LMAT_E_ARG, "offsets must ascend"); }
+        max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+        sl.h_rec_off[i + 1] = sl.h_rec_off[i] + rec_words((uint32_t)len);
+        const uint32_t P = len >= k ? (uint32_t)len - k + 1 : 0;
+        const int j = P <= 160 ? 0 : (P <= 256 ? 1 : 2);
+        sl.h_cls[j][cn[j]++] = (uint32_t)i;
+    }
+    sl.n = n;
+    sl.tag = tag;
+    sl.reads.n = n;
+    sl.reads.n_words = sl.h_rec_off[n];
+    sl.reads.max_len = max_len;
+    sl.reads.class_len = max_len;
+    const int used = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0);
+    for (int j = 0; j < 3; ++j) sl.reads.cls_n[j] = used > 1 ? cn[j] : 0;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(sl.d_bases, sl.h_bases, sl.h_off[n], hipMemcpyHostToDevice, st->s_h2d));
+        HIPCHK(c, hipMemcpyAsync(sl.d_off, sl.h_off, (n + 1) * 8, hipMemcpyHostToDevice, st->s_h2d));
+        HIPCHK(c, hipMemcpyAsync(sl.reads.rec_off, sl.h_rec_off, (n + 1) * 8, hipMemcpyHostToDevice, st->s_h2d));
+        if (used > 1)
+            for (int j = 0; j < 3; ++j)
+                if (cn[j]) HIPCHK(c, hipMemcpyAsync(sl.reads.cls_dev[j], sl.h_cls[j], cn[j] * 4, hipMemcpyHostToDevice, st->s_h2d));
+        HIPCHK(c, hipEventRecord(sl.ev_up, st->s_h2d));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_up, 0));
+        launch_pack_reads(sl.d_bases, sl.d_off, sl.reads.rec_off, sl.reads.words, n, c->stream);
+        const int rc = stream_launch(st, sl, false);
+        if (rc) { sl.state = 0; return rc; }
+    }
+    sl.state = 2;
+    ++st->head;
+    return LMAT_OK;
+}
+
+int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lmat_cand** cands, uint64_t* n_reads, uint64_t* n_cands,
+                     uint64_t* tag) {
+    if (!st) return LMAT_E_ARG;
+    lmat_ctx* c = st->c;
+    if (st->tail == st->head) return 1;  // nothing in flight
+    lmat_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
+    if (sl.state != 2) return set_err(c, LMAT_E_ARG, "release the batch returned by the previous lmat_stream_next first");
+    hipSetDevice(c->device);
+    uint64_t nc = 0;
+    if (sl.n) {
+        for (;;) {
+            HIPCHK(c, hipEventSynchronize(sl.ev_done));
+            const uint32_t fresh = sl.h_cursor[1] & ~st->reported;
+            st->reported |= fresh & ~(uint32_t)kErrCandOverflow;
+            nc = sl.h_cursor[0];
+            if (!(fresh & kErrCandOverflow)) {
+                if (fresh & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
+                if (fresh & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
+                if (fresh & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
+                if (fresh & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
+                break;
+            }
+            // the batch printed more candidates than the slot holds: wait for the batches queued behind it, grow this slot
+            // fourfold and run it again (packed reads are still resident; its tallies were already counted)
+            HIPCHK(c, hipDeviceSynchronize());
+            HIPCHK(c, hipMemset(c->d_cursor + 1, 0, 4));
+            for (auto& o : st->slots)  // flags of the batches behind it were in the word just cleared
+                if (&o != &sl && o.state == 2) st->reported &= ~(o.h_cursor[1] & ~(uint32_t)kErrCandOverflow);
+            hipFree(sl.d_cands); hipHostFree(sl.h_cands);
+            sl.d_cands = nullptr; sl.h_cands = nullptr;
+            sl.cand_cap *= 4;
+            if (hipMalloc((void**)&sl.d_cands, sl.cand_cap * sizeof(lmat_cand)) != hipSuccess ||
+                hipHostMalloc((void**)&sl.h_cands, sl.cand_cap * sizeof(lmat_cand), hipHostMallocDefault) != hipSuccess)
+                return set_err(c, LMAT_E_NOMEM, "out of memory growing a candidate buffer");
+            const int rc = stream_launch(st, sl, true);
+            if (rc) return rc;
+        }
+        if (sl.cand_cap && nc) HIPCHK(c, hipMemcpyAsync(sl.h_cands, sl.d_cands, nc * sizeof(lmat_cand), hipMemcpyDeviceToHost, st->s_d2h));
+        HIPCHK(c, hipStreamSynchronize(st->s_d2h));
+    }
+    sl.state = 3;
+    if (results) *results = sl.h_results;
+    if (cands) *cands = sl.h_cands;
+    if (n_reads) *n_reads = sl.n;
+    if (n_cands) *n_cands = sl.cand_cap ? nc : 0;
+    if (tag) *tag = sl.tag;
+    return LMAT_OK;
+}
+
+int lmat_stream_release(lmat_stream* st) {
+    if (!st) return LMAT_E_ARG;
+    lmat_stream::Slot& sl = st->slots[st->tail % st->slots.size()];
+    if (sl.state != 3) return set_err(st->c, LMAT_E_ARG, "no batch is checked out");
+    sl.state = 0;
+    ++st->tail;
+    return LMAT_OK;
+}
+
+// ---------------------------------------------------------------------------------- tallies across contexts
+// The merge of read_label.cpp:1760-1800 for several contexts of ONE process (one per GPU): every context ends up
+// holding the sum.  Host-side: the arrays are ~50 KB, so each is copied out, summed and copied back; no collective
+// library is involved (one process per GPU uses RCCL on lmat_counts_device_ptr instead, as bench.py does).
+int lmat_counts_allreduce(lmat_ctx** ctxs, int n) {
+    if (!ctxs || n < 1) return LMAT_E_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || !ctxs[i]->d_counts || ctxs[i]->counts_bytes != ctxs[0]->counts_bytes)
+            return ctxs[i] ? set_err(ctxs[i], LMAT_E_ARG, "contexts must hold the same taxonomy") : LMAT_E_ARG;
+    const uint64_t bytes = ctxs[0]->counts_bytes;
+    const uint32_t ids = ctxs[0]->dev.n_ids;
+    std::vector<unsigned char> sum(bytes, 0), buf(bytes);
+    uint64_t* sc = (uint64_t*)sum.data();
+    double* ss = (double*)(sc + ids);
+    uint64_t* sn = (uint64_t*)(ss + ids);
+    for (int i = 0; i < n; ++i) {
+        lmat_ctx* c = ctxs[i];
+        hipSetDevice(c->device);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(buf.data(), c->d_counts, bytes, hipMemcpyDeviceToHost));
+        const uint64_t* bc = (const uint64_t*)buf.data();
+        const double* bs = (const double*)(bc + ids);
+        const uint64_t* bn = (const uint64_t*)(bs + ids);
+        for (uint32_t j = 0; j < ids; ++j) { sc[j] += bc[j]; ss[j] += bs[j]; }
+        for (int j = 0; j < 3; ++j) sn[j] += bn[j];
+    }
+    for (int i = 0; i < n; ++i) {
+        hipSetDevice(ctxs[i]->device);
+        HIPCHK(ctxs[i], hipMemcpy(ctxs[i]->d_counts, sum.data(), bytes, hipMemcpyHostToDevice));
+    }
     return LMAT_OK;
 }
 

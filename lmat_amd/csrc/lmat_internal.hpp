@@ -94,6 +94,10 @@ struct lmat_reads {
     std::vector<uint32_t> cls_host[3];
     uint32_t* cls_dev[3] = {nullptr, nullptr, nullptr};
     int cls_k = 0;
+    // a batch slot of a lmat_stream: the class lists are filled by the submitter into buffers the slot owns (cls_dev, cls_n
+    // entries each) and always cover the whole batch
+    bool preset = false;
+    uint64_t cls_n[3] = {0, 0, 0};
 };
 
 struct lmat_ingest {
@@ -152,6 +156,10 @@ struct lmat_ctx {
     uint64_t ovf_cap = 0;
     void* d_counts = nullptr;      // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     void* d_counts_bak = nullptr;  // tallies as they were before the current blocking launch (restored when it fails)
+    // where the next launch writes instead of the context's own buffers (set by the streamed boundary around its launches)
+    lmat_read_result* out_results = nullptr;
+    lmat_cand* out_cands = nullptr;
+    void* out_counts = nullptr;
     uint64_t counts_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;   // around the classify kernel

@@ -756,3 +756,69 @@ def test_failed_blocking_launch_leaves_the_tallies_alone(small_dataset):
     assert eng.counts() == once and sum(c for c, _ in once[0].values()) > 100
     dr.free()
     eng.close()
+
+
+# ---- streamed boundary (lmat_stream_*) and the cross-context merge ------------------------------------------
+@pytest.mark.parametrize("prn_all", [1, 0])
+def test_stream_equals_blocking_path(config1, prn_all):
+    """Batches pushed through the ring of pinned slots (mixed lengths, several batches in flight, a candidate buffer
+    that is too small at first) give the text and tallies of the blocking path."""
+    from lmat_amd import Engine, Params, Stream
+    eng = _engine(config1, Params.run_rl(prn_all=prn_all))
+    reads = config1["reads"][:6000]
+    blob, off = _blob(reads)
+    dr = eng.upload_reads((blob, off))
+    eng.counts_reset()
+    res0, cands0 = eng.classify(dr, cand_cap=256 * len(reads))
+    want = eng.format_out(res0, cands0, (blob, off))
+    tallies0 = eng.counts()
+    dr.free()
+    eng.counts_reset()
+    st = Stream(eng, max_reads=1000, max_bases=1000 * 300, cands_per_read=2, n_slots=3)   # 2 per read: forces the grow path
+    bounds = list(range(0, len(reads), 1000)) + [len(reads)]
+    got, pending = {}, 0
+    for bi, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
+        if st.in_flight == st.n_slots:
+            r, cd, tag = st.next()
+            got[tag] = (r, cd)
+        o = (off[lo:hi + 1] - off[lo]).astype(np.uint64)
+        st.submit(np.ascontiguousarray(blob[int(off[lo]):int(off[hi])]), np.ascontiguousarray(o), tag=bi)
+    while True:
+        x = st.next()
+        if x is None:
+            break
+        got[x[2]] = (x[0], x[1])
+    text = ""
+    for bi, (lo, hi) in enumerate(zip(bounds, bounds[1:])):
+        r, cd = got[bi]
+        o = (off[lo:hi + 1] - off[lo]).astype(np.uint64)
+        text += eng.format_out(r, cd, (np.append(blob[int(off[lo]):int(off[hi])], np.uint8(0)), o), first_index=lo)
+    assert text == want
+    assert eng.counts() == tallies0
+    st.close()
+    eng.close()
+
+
+def test_counts_allreduce_across_contexts(small_dataset):
+    """Two contexts (here on one GPU) label disjoint halves; after lmat_counts_allreduce both hold the tallies of the
+    whole set -- the merge of read_label.cpp:1760-1800."""
+    import ctypes as C
+    from lmat_amd import Params
+    ds = small_dataset
+    a, b, whole = _engine(ds, Params.run_rl()), _engine(ds, Params.run_rl()), _engine(ds, Params.run_rl())
+    reads = ds["reads"]
+    h = len(reads) // 2
+    for e in (a, b, whole):
+        e.counts_reset()
+    a.classify(a.upload_reads(reads[:h]))
+    b.classify(b.upload_reads(reads[h:]))
+    whole.classify(whole.upload_reads(reads))
+    arr = (C.c_void_p * 2)(a.ctx, b.ctx)
+    assert a.lib.lmat_counts_allreduce(arr, 2) == 0
+    ca, cb, cw = a.counts(), b.counts(), whole.counts()
+    assert ca[1] == cb[1] == cw[1]
+    assert {t: c for t, (c, s) in ca[0].items()} == {t: c for t, (c, s) in cb[0].items()} == {t: c for t, (c, s) in cw[0].items()}
+    for t, (c, s) in cw[0].items():
+        assert abs(ca[0][t][1] - s) < 1e-6 and abs(cb[0][t][1] - s) < 1e-6
+    for e in (a, b, whole):
+        e.close()
