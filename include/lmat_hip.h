@@ -77,6 +77,7 @@ typedef struct {
 } lmat_cand;
 
 /* ---- context ------------------------------------------------------------ */
+int lmat_device_count(void);   /* usable HIP devices (0 when there is none) */
 int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out);
 void lmat_ctx_destroy(lmat_ctx* ctx);
 const char* lmat_last_error(const lmat_ctx* ctx);

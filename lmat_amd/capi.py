@@ -48,6 +48,7 @@ def load_library(path: str | None = None):
     vp, u64, u32, i32, cp = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p
     P = C.POINTER
     sig = {
+        "lmat_device_count": (i32, []),
         "lmat_ctx_create": (i32, [i32, P(Params), P(vp)]),
         "lmat_ctx_destroy": (None, [vp]),
         "lmat_last_error": (cp, [vp]),
@@ -119,7 +120,7 @@ def load_library(path: str | None = None):
     return lib
 
 
-EXPORTED = ["lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
+EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
             "lmat_db_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
             "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create", "lmat_ingest_idmap_from_tree", "lmat_rand_mode", "lmat_rand_reset", "lmat_rand_label", "lmat_rand_get",
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",

@@ -83,6 +83,11 @@ static void sb_free(lmat_ctx* c);
 static int sb_begin(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k);
 static int sb_push(lmat_ctx* c, Ingest& B);
 
+int lmat_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out) {
     if (!out) return LMAT_E_ARG;
     *out = nullptr;

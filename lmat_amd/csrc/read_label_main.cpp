@@ -15,12 +15,18 @@
 //   * -t N is the number of output shards (<o>0.out .. <o>N-1.out) and of formatter threads; reads
 //     are dealt to shards in contiguous blocks (the reference deals them dynamically, so only the
 //     multiset of lines across shards is defined there; -t 1 gives the reference's -t 1 file).
+//   * GPUs: one context (and one driving thread) per GPU, min(-t, visible GPUs) of them unless LMAT_DEVICE (one
+//     device) or LMAT_DEVICES (a comma list) says otherwise; every GPU holds the whole database, batches are dealt to
+//     the GPUs as they come free, and the writer puts them back in input order, so the output files do not depend
+//     on the number of GPUs.  Each GPU is fed through a ring of pinned batch slots (lmat_stream_*): parsing, copy
+//     in, classification, copy out and formatting of consecutive batches overlap.
 #include <fcntl.h>
 #include <getopt.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -110,6 +116,7 @@ static void parse_fasta_piece(const char* p, const char* end, Batch& b) {
 // format + write + tally (writer thread).  The stages of consecutive batches overlap.
 struct Work {
     Batch b;
+    uint64_t seq = 0;                    // position of the batch in the input
     std::vector<lmat_read_result> res;
     std::unique_ptr<lmat_cand[]> cands;  // uninitialised on purpose: zero-filling 64 candidates per read cost more than the GPU work
 };
@@ -131,6 +138,15 @@ public:
     std::unique_ptr<Work> pop() {  // null = the producer is done
         std::unique_lock<std::mutex> l(m);
         cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        std::unique_ptr<Work> w = std::move(q.front());
+        q.pop();
+        cv.notify_all();
+        return w;
+    }
+    std::unique_ptr<Work> try_pop(bool& done) {  // null + done = the producer is done; null + !done = nothing queued right now
+        std::lock_guard<std::mutex> l(m);
+        done = q.empty() && closed;
         if (q.empty()) return nullptr;
         std::unique_ptr<Work> w = std::move(q.front());
         q.pop();
@@ -199,30 +215,31 @@ int main(int argc, char* argv[]) {
     prm.min_fnd_kmer = min_fnd_kmer;
 
     std::cout << "=== LMAT === read_label === ver. " << LMAT_VERSION << " ===" << std::endl;
-    int device = 0;
-    if (const char* d = getenv("LMAT_DEVICE")) device = atoi(d);
-    lmat_ctx* ctx = nullptr;
-    if (lmat_ctx_create(device, &prm, &ctx) != LMAT_OK) {
-        std::cerr << "ERROR! no usable HIP device (this build has no CPU path)" << std::endl;
-        return -1;
+    // one context per GPU
+    std::vector<int> devices;
+    if (const char* d = getenv("LMAT_DEVICE")) devices.push_back(atoi(d));
+    else if (const char* dl = getenv("LMAT_DEVICES")) {
+        std::stringstream ss(dl);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str()));
+    } else {
+        const int visible = lmat_device_count();
+        for (int d = 0; d < std::max(1, std::min(n_threads, visible)); ++d) devices.push_back(d);
     }
-    auto fail = [&](const char* what) {
-        std::cerr << "ERROR! " << what << ": " << lmat_last_error(ctx) << std::endl;
-        lmat_ctx_destroy(ctx);
-        return -1;
-    };
+    const int n_gpu = (int)devices.size();
+    std::vector<lmat_ctx*> ctxs(n_gpu, nullptr);
+    auto destroy_all = [&]() { for (lmat_ctx* x : ctxs) if (x) lmat_ctx_destroy(x); };
+    for (int g = 0; g < n_gpu; ++g)
+        if (lmat_ctx_create(devices[g], &prm, &ctxs[g]) != LMAT_OK) {
+            std::cerr << "ERROR! no usable HIP device " << devices[g] << " (this build has no CPU path)" << std::endl;
+            destroy_all();
+            return -1;
+        }
+    lmat_ctx* ctx = ctxs[0];
     if (id_bit_conv_fn.length() > 0) std::cout << "Loading map file " << id_bit_conv_fn << "... ";
     std::cout << "Reading taxonomy tree " << tax_tree_fn << std::endl;
     std::cout << "Reading taxonomy depth " << depth_file << std::endl;
-    if (lmat_taxonomy_load_files(ctx, tax_tree_fn.c_str(), depth_file.c_str(), rank_map_file.empty() ? nullptr : rank_map_file.c_str(),
-                                 id_bit_conv_fn.empty() ? nullptr : id_bit_conv_fn.c_str(), plasmid_file.empty() ? nullptr : plasmid_file.c_str()) != LMAT_OK)
-        return fail("taxonomy");
-    std::cout << "OK!" << std::endl;
-    if (!rand_hits_file.empty() && lmat_nullmodel_load(ctx, rand_hits_file.c_str()) != LMAT_OK) return fail("null models");
     if (!rank_table_file.empty() && max_count <= 0) std::cout << "Need to set -h <tid-cutoff> to use rank file map!\n";  // :1544-1545
-    if (lmat_set_label_modes(ctx, permissive, max_count, max_count > 0 && !rank_table_file.empty() ? rank_table_file.c_str() : nullptr) != LMAT_OK)
-        return fail("label modes");
-
     std::cout << "Start kmer DB load..." << std::endl;
     std::vector<std::string> files;
     if (is_list_file(kmer_db_fn)) {
@@ -230,41 +247,67 @@ int main(int argc, char* argv[]) {
         std::string f;
         while (l >> f) files.push_back(f);
     } else files.push_back(kmer_db_fn);
-    if (files.empty()) { std::cerr << "Error: unable to open kmer db [" << kmer_db_fn << "]" << std::endl; return -1; }
+    if (files.empty()) { std::cerr << "Error: unable to open kmer db [" << kmer_db_fn << "]" << std::endl; destroy_all(); return -1; }
     bool is_image = false;
     {
         FILE* f = fopen(files[0].c_str(), "rb");
         char magic[8] = {0};
         if (f) { if (fread(magic, 1, 8, f) == 8 && memcmp(magic, "LMATIMG1", 8) == 0) is_image = true; fclose(f); }
     }
-    if (is_image) {  // image written by make_db_image (the engine's counterpart of the PERM .db file)
-        if (lmat_db_load_image(ctx, files[0].c_str(), 0) != LMAT_OK) return fail("k-mer DB image");
-        if (lmat_db_finalize(ctx) != LMAT_OK) return fail("k-mer DB image");
-        if (k_size < 1) k_size = lmat_db_kmer_length(ctx);
-    } else {
+    uint32_t klen = 0;
+    uint64_t n_total = 0;  // k-mer counts of the headers size the table up front, so the files stream through
+    if (!is_image) {
         // k-mer length comes from the first file's header (KmerFileMetaData.cpp:44-94)
         FILE* f = fopen(files[0].c_str(), "rb");
-        if (!f) { std::cerr << "Error: unable to open kmer db [" << files[0] << "]" << std::endl; return -1; }
-        uint32_t klen = 0;
+        if (!f) { std::cerr << "Error: unable to open kmer db [" << files[0] << "]" << std::endl; destroy_all(); return -1; }
         fseek(f, 25, SEEK_SET);
         if (fread(&klen, 4, 1, f) != 1) klen = 0;
         fclose(f);
-        if (k_size < 1) k_size = (int)klen;
-        uint64_t n_total = 0;  // k-mer counts of the headers size the table up front, so the files stream through
         for (auto& fn : files) {
             FILE* h = fopen(fn.c_str(), "rb");
             uint64_t nk = 0;
             if (h) { fseek(h, 4, SEEK_SET); if (fread(&nk, 8, 1, h) != 1) nk = 0; fclose(h); }
             n_total += nk;
         }
-        if (lmat_db_begin(ctx, (int)klen, n_total, 0) != LMAT_OK) return fail("k-mer DB");
-        for (auto& fn : files)
-            if (lmat_db_add_taxhisto(ctx, fn.c_str()) != LMAT_OK) return fail("k-mer DB");
-        if (lmat_db_finalize(ctx) != LMAT_OK) return fail("k-mer DB");
     }
-    std::cout << "Loaded k-mer DB into a " << (lmat_db_table_bytes(ctx) >> 20) << " MiB GPU hash. Num of k-mers: " << lmat_db_size(ctx)
-              << " of size " << k_size << std::endl;
-    if (k_size <= 0) { std::cerr << "ERROR! Unable to read database, k-mer size=" << k_size << std::endl; return -1; }
+    // every GPU loads the taxonomy and the whole database (the table is replicated, reads are dealt out)
+    std::vector<std::string> setup_err(n_gpu);
+    {
+        std::vector<std::thread> th;
+        for (int g = 0; g < n_gpu; ++g)
+            th.emplace_back([&, g]() {
+                lmat_ctx* x = ctxs[g];
+                auto bad = [&](const char* what) { setup_err[g] = std::string(what) + ": " + lmat_last_error(x); };
+                if (lmat_taxonomy_load_files(x, tax_tree_fn.c_str(), depth_file.c_str(), rank_map_file.empty() ? nullptr : rank_map_file.c_str(),
+                                             id_bit_conv_fn.empty() ? nullptr : id_bit_conv_fn.c_str(), plasmid_file.empty() ? nullptr : plasmid_file.c_str()) != LMAT_OK)
+                    return bad("taxonomy");
+                if (!rand_hits_file.empty() && lmat_nullmodel_load(x, rand_hits_file.c_str()) != LMAT_OK) return bad("null models");
+                if (lmat_set_label_modes(x, permissive, max_count, max_count > 0 && !rank_table_file.empty() ? rank_table_file.c_str() : nullptr) != LMAT_OK)
+                    return bad("label modes");
+                if (is_image) {  // image written by make_db_image (the engine's counterpart of the PERM .db file)
+                    if (lmat_db_load_image(x, files[0].c_str(), 0) != LMAT_OK) return bad("k-mer DB image");
+                    if (lmat_db_finalize(x) != LMAT_OK) return bad("k-mer DB image");
+                } else {
+                    if (lmat_db_begin(x, (int)klen, n_total, 0) != LMAT_OK) return bad("k-mer DB");
+                    for (auto& fn : files)
+                        if (lmat_db_add_taxhisto(x, fn.c_str()) != LMAT_OK) return bad("k-mer DB");
+                    if (lmat_db_finalize(x) != LMAT_OK) return bad("k-mer DB");
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+    for (int g = 0; g < n_gpu; ++g)
+        if (!setup_err[g].empty()) {
+            std::cerr << "ERROR! " << setup_err[g] << std::endl;
+            destroy_all();
+            return -1;
+        }
+    std::cout << "OK!" << std::endl;
+    if (k_size < 1) k_size = is_image ? lmat_db_kmer_length(ctx) : (int)klen;
+    std::cout << "Loaded k-mer DB into a " << (lmat_db_table_bytes(ctx) >> 20) << " MiB GPU hash";
+    if (n_gpu > 1) std::cout << " on each of " << n_gpu << " GPUs";
+    std::cout << ". Num of k-mers: " << lmat_db_size(ctx) << " of size " << k_size << std::endl;
+    if (k_size <= 0) { std::cerr << "ERROR! Unable to read database, k-mer size=" << k_size << std::endl; destroy_all(); return -1; }
 
     auto t_start = std::chrono::steady_clock::now();
     std::ifstream qf;
@@ -285,7 +328,9 @@ int main(int argc, char* argv[]) {
     std::map<uint32_t, int> merge_count;
     std::map<uint32_t, float> merge_score;
     std::map<int, int> nomatch_merge;
-    const size_t kBatch = 1u << 20;
+    const size_t kBatch = 1u << 20;          // reads per batch ...
+    const size_t kBatchBases = 192u << 20;   // ... and bases per batch: what a slot of the GPU feed rings holds
+    uint64_t next_seq = 0;                   // batches are numbered in input order (reader thread only)
     size_t read_count = 0;
     double t_parse = 0, t_gpu = 0, t_fmt = 0, t_write = 0, t_tally = 0;  // LMAT_CLI_TIMING=1 prints the busy time of each stage
     auto now = []() { return std::chrono::steady_clock::now(); };
@@ -351,7 +396,7 @@ int main(int argc, char* argv[]) {
                         b.hoff.swap(ho);
                     }
                     read_count += n;
-                    if (n) { b.bases.push_back(0); parsed.push(std::move(ws[j])); }
+                    if (n) { b.bases.push_back(0); ws[j]->seq = next_seq++; parsed.push(std::move(ws[j])); }
                 }
                 pos = cut.back();
                 t_parse += secs(tp0, now());
@@ -367,7 +412,7 @@ int main(int argc, char* argv[]) {
             auto tp0 = now();
             std::unique_ptr<Work> w(new Work());
             Batch& b = w->b;
-            while (b.n() < kBatch) {
+            while (b.n() < kBatch && b.bases.size() + (64u << 10) < kBatchBases) {
                 if (!rd.next(read, hdr)) { more = false; break; }
                 ++read_count;
                 if (hdr.empty() || hdr[0] == '\0') {
@@ -381,13 +426,24 @@ int main(int argc, char* argv[]) {
             }
             if (!more) std::cout << "Total reads loaded: " << read_count << std::endl;
             t_parse += secs(tp0, now());
-            if (b.n()) { b.bases.push_back(0); parsed.push(std::move(w)); }
+            if (b.n()) { b.bases.push_back(0); w->seq = next_seq++; parsed.push(std::move(w)); }
         }
         parsed.close();
     });
     const int n_fmt = std::max<int>(n_threads, (int)std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
-    std::thread writer([&]() {  // stage 3: text, files, tallies
-        while (std::unique_ptr<Work> w = classified.pop()) {
+    std::thread writer([&]() {  // stage 3: text, files, tallies -- in input order whatever GPU a batch went through
+        std::map<uint64_t, std::unique_ptr<Work>> held;
+        uint64_t want_seq = 0;
+        for (;;) {
+            std::unique_ptr<Work> w;
+            auto it = held.find(want_seq);
+            if (it != held.end()) { w = std::move(it->second); held.erase(it); }
+            else {
+                w = classified.pop();
+                if (!w) break;
+                if (w->seq != want_seq) { const uint64_t sq = w->seq; held[sq] = std::move(w); continue; }
+            }
+            ++want_seq;
             auto tp2 = now();
             const Batch& b = w->b;
             const std::vector<lmat_read_result>& res = w->res;
@@ -436,40 +492,91 @@ int main(int argc, char* argv[]) {
             t_tally += secs(tp4, now());
         }
     });
-    bool failed = false;
-    while (std::unique_ptr<Work> w = parsed.pop()) {  // stage 2: the GPU
-        auto tp1 = now();
-        const size_t n = w->b.n();
-        lmat_reads* dr = nullptr;
-        if (lmat_reads_upload(ctx, w->b.bases.data(), w->b.off.data(), n, &dr) != LMAT_OK) { failed = true; break; }
-        w->res.resize(n);
-        uint64_t ncand = 0;
-        size_t cap = std::max<size_t>(64 * n, 4096);
-        for (;;) {  // grow the candidate buffer until the batch fits
-            w->cands.reset(new lmat_cand[cap]);
-            int rc = lmat_classify(ctx, dr, 0, n, w->res.data(), w->cands.get(), cap, &ncand);
-            if (rc == LMAT_OK) break;
-            if (rc == LMAT_E_CAPACITY && strstr(lmat_last_error(ctx), "cand_cap") && cap < (size_t)1 << 31) { cap *= 4; continue; }
-            failed = true;
-            break;
-        }
-        lmat_reads_free(ctx, dr);
-        if (failed) break;
-        t_gpu += secs(tp1, now());
-        classified.push(std::move(w));
-    }
+    // stage 2: the GPUs.  One thread per context keeps its ring of pinned slots full: a batch is copied into a slot and
+    // queued (copy in, packing, classification and the copy of the results back are asynchronous), the oldest batch in
+    // flight is collected when the ring is full or the input has nothing ready.
+    std::atomic<bool> failed(false);
+    std::mutex fail_m;
+    std::string fail_msg;
+    const int kSlots = 3;
+    const uint32_t cands_per_read = prm.prn_all ? 24 : 8;  // a slot grows itself when a batch prints more
+    std::vector<double> t_gpu_g(n_gpu, 0.0);
+    std::vector<std::thread> gpu_threads;
+    for (int g = 0; g < n_gpu; ++g)
+        gpu_threads.emplace_back([&, g]() {
+            lmat_ctx* x = ctxs[g];
+            lmat_stream* st = nullptr;
+            auto bail = [&](const char* what) {
+                std::lock_guard<std::mutex> l(fail_m);
+                if (!failed.exchange(true)) fail_msg = std::string(what) + ": " + lmat_last_error(x);
+                parsed.close();
+            };
+            if (lmat_stream_create(x, kBatch, kBatchBases, cands_per_read, kSlots, &st) != LMAT_OK) return bail("batch ring");
+            std::queue<std::unique_ptr<Work>> flying;
+            bool input_done = false;
+            while (!failed) {
+                std::unique_ptr<Work> w;
+                if ((int)flying.size() < kSlots && !input_done) {
+                    if (flying.empty()) { w = parsed.pop(); if (!w) input_done = true; }
+                    else w = parsed.try_pop(input_done);
+                }
+                auto tp1 = now();
+                if (w) {
+                    uint8_t* hb = nullptr;
+                    uint64_t* ho = nullptr;
+                    const size_t n = w->b.n();
+                    if (lmat_stream_acquire(st, &hb, &ho) != LMAT_OK) { bail("classify"); break; }
+                    memcpy(hb, w->b.bases.data(), w->b.off[n]);
+                    memcpy(ho, w->b.off.data(), (n + 1) * 8);
+                    if (lmat_stream_submit(st, n, w->seq) != LMAT_OK) { bail("classify"); break; }
+                    flying.push(std::move(w));
+                    t_gpu_g[g] += secs(tp1, now());
+                    continue;
+                }
+                if (flying.empty()) break;  // input done, nothing in flight
+                const lmat_read_result* res = nullptr;
+                const lmat_cand* cd = nullptr;
+                uint64_t n = 0, nc = 0, tag = 0;
+                if (lmat_stream_next(st, &res, &cd, &n, &nc, &tag) != LMAT_OK) { bail("classify"); break; }
+                std::unique_ptr<Work> done = std::move(flying.front());
+                flying.pop();
+                done->res.assign(res, res + n);
+                done->cands.reset(new lmat_cand[std::max<uint64_t>(nc, 1)]);
+                if (nc) memcpy(done->cands.get(), cd, nc * sizeof(lmat_cand));
+                lmat_stream_release(st);
+                t_gpu_g[g] += secs(tp1, now());
+                classified.push(std::move(done));
+            }
+            lmat_stream_destroy(st);
+        });
+    for (auto& x : gpu_threads) x.join();
+    for (double v : t_gpu_g) t_gpu = std::max(t_gpu, v);
     if (failed) parsed.close();
     classified.close();
     reader.join();
     writer.join();
-    if (failed) return fail("classify");
-    if (getenv("LMAT_CLI_TIMING"))
-        std::cerr << "[read_label] stage busy time: parse " << t_parse << " s, upload+classify+fetch " << t_gpu << " s, format " << t_fmt
-                  << " s, write " << t_write << " s, tally " << t_tally << " s" << std::endl;
+    if (failed) {
+        std::cerr << "ERROR! " << fail_msg << std::endl;
+        destroy_all();
+        return -1;
+    }
+    // the device-side tallies of the contexts, merged (read_label.cpp:1760-1800): every context now holds the totals,
+    // and their read counts must be the ones the writer summed on the host in input order
+    if (lmat_counts_allreduce(ctxs.data(), n_gpu) != LMAT_OK) { std::cerr << "ERROR! merge: " << lmat_last_error(ctx) << std::endl; destroy_all(); return -1; }
+    {
+        std::vector<uint32_t> tids(70000);
+        std::vector<uint64_t> cnts(70000);
+        uint32_t nz = 0;
+        uint64_t nm3[3] = {0, 0, 0};
+        bool same = lmat_counts_get(ctx, tids.data(), cnts.data(), nullptr, 70000, &nz, nm3) == LMAT_OK && nz == merge_count.size();
+        for (uint32_t i = 0; same && i < nz; ++i) same = merge_count.count(tids[i]) && (uint64_t)merge_count[tids[i]] == cnts[i];
+        for (int j = 0; same && j < 3; ++j) same = (uint64_t)(nomatch_merge.count(j) ? nomatch_merge[j] : 0) == nm3[j];
+        if (!same) { std::cerr << "ERROR! the merged device tallies differ from the per-record tallies" << std::endl; destroy_all(); return -1; }
+    }
     for (auto& o : ofs) o.close();
     if (getenv("LMAT_CLI_TIMING"))
-        std::cerr << "[read_label] parse " << t_parse << " s, upload+classify+fetch " << t_gpu << " s, format " << t_fmt << " s, write "
-                  << t_write << " s, tally " << t_tally << " s" << std::endl;
+        std::cerr << "[read_label] stage busy time: parse " << t_parse << " s, GPU feed (copy into the pinned slots + waiting for results, busiest of "
+                  << n_gpu << " GPUs) " << t_gpu << " s, format " << t_fmt << " s, write " << t_write << " s, tally " << t_tally << " s" << std::endl;
     std::cout << "Finished classifing reads, doing final steps sequentially..." << std::endl;
 
     // names for the called taxids from the -u file (:1812-1835)
@@ -521,7 +628,7 @@ int main(int argc, char* argv[]) {
         static const char* names[3] = {"ReadTooShort", "NoDbHits", "LowScore"};
         for (auto& p : nomatch_merge) nom_ofs << names[p.first] << "\t" << p.second << std::endl;
     }
-    lmat_ctx_destroy(ctx);
+    destroy_all();
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     std::cout << "DONE! Total query time: " << el << " sec = " << el / 60 << " min" << std::endl;
     return 0;

@@ -45,6 +45,22 @@ def test_cli_shards_are_a_partition(small_dataset, tmp_path):
     assert open(str(tmp_path / "a") + ".0.30.fastsummary").read() == open(str(tmp_path / "b") + ".0.30.fastsummary").read()
 
 
+def test_cli_with_several_contexts_writes_the_same_files(small_dataset, tmp_path, monkeypatch):
+    """read_label drives one context per GPU (src/read_label.cpp:1637-1800 is its OpenMP fan-out + merge); here two
+    contexts share the one GPU of the box (LMAT_DEVICES=0,0), tiny FASTA pieces make many batches so that both get
+    work, and the writer restores input order: the .out shards and both summaries equal the single-context run."""
+    ds = small_dataset
+    monkeypatch.setenv("LMAT_FASTA_PIECE", "4000")
+    monkeypatch.setenv("LMAT_DEVICES", "0")
+    _run_cli(ds, str(tmp_path / "a"), ds["fasta"], 2)
+    monkeypatch.setenv("LMAT_DEVICES", "0,0")
+    out = _run_cli(ds, str(tmp_path / "b"), ds["fasta"], 2)
+    assert "on each of 2 GPUs" in out
+    for suffix in ("0.out", "1.out", ".0.30.fastsummary", ".0.30.nomatchsum"):
+        assert open(str(tmp_path / "a") + suffix).read() == open(str(tmp_path / "b") + suffix).read(), suffix
+    assert len(open(str(tmp_path / "b") + "0.out").read()) > 10000
+
+
 def test_cli_refuses_unsupported_and_missing_args(small_dataset, tmp_path):
     ds = small_dataset
     r = subprocess.run([EXE, "-t", "1", "-o", str(tmp_path / "x"), "-i", ds["fasta"]], capture_output=True, text=True)
