@@ -196,6 +196,13 @@ int lmat_stream_create(lmat_ctx* ctx, uint64_t max_reads, uint64_t max_bases, ui
                        lmat_stream** out);
 int lmat_stream_acquire(lmat_stream* st, uint8_t** bases, uint64_t** off);
 int lmat_stream_submit(lmat_stream* st, uint64_t n_reads, uint64_t tag);
+/* As lmat_stream_submit, but the reads are off[0..n_reads] inside the caller's OWN pinned buffer `bases` (from
+ * lmat_host_alloc; off need not start at 0), which the device reads directly: no copy into the slot.  The buffer must
+ * stay untouched until lmat_stream_next has returned this batch. */
+int lmat_stream_submit_from(lmat_stream* st, const uint8_t* bases, const uint64_t* off, uint64_t n_reads, uint64_t tag);
+/* Page-locked host memory for buffers handed to lmat_stream_submit_from. */
+int lmat_host_alloc(uint64_t bytes, void** out);
+void lmat_host_free(void* p);
 int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lmat_cand** cands, uint64_t* n_reads,
                      uint64_t* n_cands, uint64_t* tag);
 int lmat_stream_release(lmat_stream* st);

@@ -104,6 +104,9 @@ def load_library(path: str | None = None):
         "lmat_stream_create": (i32, [vp, u64, u64, u32, i32, P(vp)]),
         "lmat_stream_acquire": (i32, [vp, P(vp), P(vp)]),
         "lmat_stream_submit": (i32, [vp, u64, u64]),
+        "lmat_stream_submit_from": (i32, [vp, vp, vp, u64, u64]),
+        "lmat_host_alloc": (i32, [u64, P(vp)]),
+        "lmat_host_free": (None, [vp]),
         "lmat_stream_next": (i32, [vp, P(vp), P(vp), P(u64), P(u64), P(u64)]),
         "lmat_stream_release": (i32, [vp]),
         "lmat_stream_destroy": (None, [vp]),
@@ -130,7 +133,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
-            "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit",
+            "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce"]
 
 

@@ -1337,11 +1337,19 @@ static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch
     return LMAT_OK;
 }
 
-int lmat_stream_submit(lmat_stream* st, uint64_t n, uint64_t tag) {
+// queues the acquired slot; ext_bases != nullptr: the reads are ext_off[0..n] (any base offset) inside the caller's own
+// pinned buffer ext_bases instead of the slot's input buffers
+static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_t* ext_bases, const uint64_t* ext_off) {
     if (!st) return LMAT_E_ARG;
     lmat_ctx* c = st->c;
     lmat_stream::Slot& sl = st->slots[st->head % st->slots.size()];
     if (sl.state != 1) return set_err(c, LMAT_E_ARG, "lmat_stream_acquire first");
+    if (ext_bases) {
+        if (n > st->max_reads) { sl.state = 0; return set_err(c, LMAT_E_ARG, "batch larger than the stream was created for"); }
+        const uint64_t base = n ? ext_off[0] : 0;
+        for (uint64_t i = 0; i <= n; ++i) sl.h_off[i] = ext_off[i] - base;
+        ext_bases += base;
+    }
     if (n > st->max_reads || (n && sl.h_off[n] > st->max_bases)) { sl.state = 0; return set_err(c, LMAT_E_ARG, "batch larger than the stream was created for"); }
     hipSetDevice(c->device);
     // record offsets and the length classes of the fast kernels (host: a pass over n offsets)
@@ -1367,7 +1375,7 @@ int lmat_stream_submit(lmat_stream* st, uint64_t n, uint64_t tag) {
     const int used = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0);
     for (int j = 0; j < 3; ++j) sl.reads.cls_n[j] = used > 1 ? cn[j] : 0;
     if (n) {
-        HIPCHK(c, hipMemcpyAsync(sl.d_bases, sl.h_bases, sl.h_off[n], hipMemcpyHostToDevice, st->s_h2d));
+        HIPCHK(c, hipMemcpyAsync(sl.d_bases, ext_bases ? ext_bases : sl.h_bases, sl.h_off[n], hipMemcpyHostToDevice, st->s_h2d));
         HIPCHK(c, hipMemcpyAsync(sl.d_off, sl.h_off, (n + 1) * 8, hipMemcpyHostToDevice, st->s_h2d));
         HIPCHK(c, hipMemcpyAsync(sl.reads.rec_off, sl.h_rec_off, (n + 1) * 8, hipMemcpyHostToDevice, st->s_h2d));
         if (used > 1)
@@ -1383,6 +1391,17 @@ int lmat_stream_submit(lmat_stream* st, uint64_t n, uint64_t tag) {
     ++st->head;
     return LMAT_OK;
 }
+int lmat_stream_submit(lmat_stream* st, uint64_t n, uint64_t tag) { return stream_submit(st, n, tag, nullptr, nullptr); }
+int lmat_stream_submit_from(lmat_stream* st, const uint8_t* bases, const uint64_t* off, uint64_t n, uint64_t tag) {
+    if (!st || (n && (!bases || !off))) return LMAT_E_ARG;
+    return stream_submit(st, n, tag, bases ? bases : (const uint8_t*)"", off);
+}
+int lmat_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return LMAT_E_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? LMAT_OK : LMAT_E_NOMEM;
+}
+void lmat_host_free(void* p) { if (p) hipHostFree(p); }
 
 int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lmat_cand** cands, uint64_t* n_reads, uint64_t* n_cands,
                      uint64_t* tag) {

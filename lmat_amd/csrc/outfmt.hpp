@@ -15,13 +15,96 @@
 
 namespace lmat {
 
-// std::to_chars(general, 6) is specified as printf's "%.6g" in the C locale, i.e. operator<<(float) with the default
-// precision; it is several times faster than snprintf, which dominated the CLI's run time (tests/test_host_logic.py
-// checks it against "%g" on a sweep of bit patterns).
+// operator<<(float) with the default precision is printf's "%g": 6 significant digits, correctly rounded, trailing zeros
+// dropped, exponent form below 1e-4 and from 1e6.  libstdc++'s std::to_chars(general, 6) gives the same text but does
+// not scale across threads (eight formatter threads ran no faster than one), and the CLI writes ~12 floats per read,
+// so the common range is formatted here with exact integer arithmetic: the float is m * 2^e, and m * 2^e * 10^k is
+// rounded half-to-even to an integer of 6 digits in 128-bit arithmetic.  Anything outside that range (and inf / nan)
+// still goes through std::to_chars.  tests/test_host_logic.py checks the result against "%g" on a sweep of bit patterns.
+inline int fmt_g6(char* out, float f) {
+    uint32_t bits;
+    __builtin_memcpy(&bits, &f, 4);
+    const uint32_t ex = (bits >> 23) & 0xFF, man = bits & 0x7FFFFF;
+    char* p = out;
+    if (ex == 0xFF) return -1;
+    if (bits >> 31) *p++ = '-';
+    if (ex == 0 && man == 0) { *p++ = '0'; return (int)(p - out); }
+    const uint64_t m = ex ? (man | 0x800000u) : man;
+    const int e2 = (ex ? (int)ex : 1) - 150;               // value = m * 2^e2
+    if (e2 < -90 || e2 > 40) return -1;                     // ~1e-20 .. ~1e19: everything a score or a statistic can be
+    // decimal exponent d with 10^d <= value < 10^(d+1): estimate from the binary exponent, then correct
+    const double v = (double)m * __builtin_ldexp(1.0, e2);
+    int d = (int)__builtin_floor(__builtin_log10(v));
+    static const uint64_t kPow10[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull,
+                                        1000000000ull, 10000000000ull, 100000000000ull, 1000000000000ull, 10000000000000ull,
+                                        100000000000000ull, 1000000000000000ull, 10000000000000000ull, 100000000000000000ull,
+                                        1000000000000000000ull, 10000000000000000000ull};
+    unsigned __int128 q = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const int k = 5 - d;                                // digits = round(value * 10^k)
+        if (k > 27 || k < -19) return -1;
+        unsigned __int128 num = m, den = 1;
+        // value * 10^k = m * 2^e2 * 2^k * 5^k
+        if (k >= 0) { for (int i = 0; i < k; ++i) num *= 5; } else den = kPow10[-k] >> (-k), den = 1;
+        int sh = e2 + k;                                    // remaining power of two
+        if (k < 0) {                                        // divide by 10^-k = 5^-k * 2^-k
+            den = 1;
+            for (int i = 0; i < -k; ++i) den *= 5;
+        }
+        if (sh >= 0) num <<= sh; else den <<= -sh;
+        q = num / den;
+        const unsigned __int128 r = num - q * den;
+        const unsigned __int128 twice = r << 1;
+        if (twice > den || (twice == den && (q & 1))) ++q;
+        if (q >= 1000000) { ++d; continue; }                // the estimate was one low, or rounding carried
+        if (q < 100000) { --d; continue; }
+        break;
+    }
+    if (q < 100000 || q >= 1000000) return -1;
+    uint32_t dig = (uint32_t)q;
+    char ds[6];
+    for (int i = 5; i >= 0; --i) { ds[i] = (char)('0' + dig % 10); dig /= 10; }
+    int nd = 6;
+    while (nd > 1 && ds[nd - 1] == '0') --nd;               // %g drops trailing zeros
+    if (d < -4 || d >= 6) {                                 // d.ddddde[+-]XX
+        *p++ = ds[0];
+        if (nd > 1) { *p++ = '.'; for (int i = 1; i < nd; ++i) *p++ = ds[i]; }
+        *p++ = 'e';
+        int a = d;
+        if (a < 0) { *p++ = '-'; a = -a; } else *p++ = '+';
+        if (a >= 100) { *p++ = (char)('0' + a / 100); a %= 100; }
+        *p++ = (char)('0' + a / 10);
+        *p++ = (char)('0' + a % 10);
+    } else if (d >= 0) {                                    // ddd.ddd
+        for (int i = 0; i <= d; ++i) *p++ = i < nd ? ds[i] : '0';
+        if (nd > d + 1) { *p++ = '.'; for (int i = d + 1; i < nd; ++i) *p++ = ds[i]; }
+    } else {                                                // 0.000ddd
+        *p++ = '0'; *p++ = '.';
+        for (int i = 0; i < -d - 1; ++i) *p++ = '0';
+        for (int i = 0; i < nd; ++i) *p++ = ds[i];
+    }
+    return (int)(p - out);
+}
+inline int fmt_float(char* b, float f) {  // b: at least 48 bytes
+    const int n = fmt_g6(b, f);
+    if (n > 0) return n;
+    return (int)(std::to_chars(b, b + 48, f, std::chars_format::general, 6).ptr - b);
+}
+// Scores are k-mer fractions: a few thousand distinct floats make up almost every score of a run, so each thread keeps
+// the text of the floats it has formatted in a small direct-mapped table keyed by the float's bits.
 inline void put_float(std::string& s, float f) {
+    struct Ent { uint32_t bits; uint8_t len; char txt[19]; };
+    static thread_local Ent cache[4096];
+    static thread_local bool init = false;
+    if (!init) { for (auto& e : cache) { e.bits = 0x7FC00001u; e.len = 0; } init = true; }  // a NaN payload no score has
+    uint32_t bits;
+    __builtin_memcpy(&bits, &f, 4);
+    Ent& e = cache[(bits * 0x9E3779B1u) >> 20];
+    if (e.bits == bits && e.len) { s.append(e.txt, e.len); return; }
     char b[48];
-    const auto r = std::to_chars(b, b + sizeof b, f, std::chars_format::general, 6);
-    s.append(b, r.ptr);
+    const int n = fmt_float(b, f);
+    if (n <= (int)sizeof e.txt) { e.bits = bits; e.len = (uint8_t)n; __builtin_memcpy(e.txt, b, (size_t)n); }
+    s.append(b, (size_t)n);
 }
 inline void put_int(std::string& s, long long v) {
     char b[32];

@@ -73,15 +73,70 @@ static bool is_list_file(const std::string& fn) {
     return false;
 }
 
+// Base buffers of the batches: pinned host memory (lmat_host_alloc), so that the GPU feed copies straight out of
+// what the parser wrote; allocated once, recycled through a pool.
+class BasePool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<uint8_t*> free_;
+    std::vector<uint8_t*> all_;
+public:
+    size_t cap = 0;  // bytes per buffer
+    bool init(size_t count, size_t bytes) {
+        cap = bytes;
+        for (size_t i = 0; i < count; ++i) {
+            void* p = nullptr;
+            if (lmat_host_alloc(bytes, &p) != LMAT_OK) return false;
+            all_.push_back((uint8_t*)p);
+            free_.push_back((uint8_t*)p);
+        }
+        return true;
+    }
+    uint8_t* get() {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !free_.empty(); });
+        uint8_t* p = free_.back();
+        free_.pop_back();
+        return p;
+    }
+    void put(uint8_t* p) { std::lock_guard<std::mutex> l(m); free_.push_back(p); cv.notify_one(); }
+    ~BasePool() { for (uint8_t* p : all_) lmat_host_free(p); }
+};
+static BasePool g_pool;
+
 struct Batch {
-    std::vector<uint8_t> bases;
+    uint8_t* bases = nullptr;         // pooled, pinned; nb bytes used
+    size_t nb = 0;
     std::vector<uint64_t> off{0};
     std::string hdr_blob;             // headers back to back
     std::vector<uint64_t> hoff{0};    // [n+1] into hdr_blob
+    Batch() { bases = g_pool.get(); }
+    ~Batch() { if (bases) g_pool.put(bases); }
+    Batch(const Batch&) = delete;
+    Batch& operator=(const Batch&) = delete;
     size_t n() const { return hoff.size() - 1; }
+    size_t room() const { return g_pool.cap - nb; }
+    void add_bases(const void* p, size_t len) { memcpy(bases + nb, p, len); nb += len; }
     void add_hdr(const char* p, size_t len) { hdr_blob.append(p, len); hoff.push_back(hdr_blob.size()); }
-    void clear() { bases.clear(); off.assign(1, 0); hdr_blob.clear(); hoff.assign(1, 0); }
+    void clear() { nb = 0; off.assign(1, 0); hdr_blob.clear(); hoff.assign(1, 0); }
 };
+
+// CPUs this process may actually use: the cgroup quota when there is one (a container with 16 CPUs on a 256-thread host
+// must not start 256-thread pools), else the hardware count
+static unsigned usable_cpus() {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[32];
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return hw;
+}
 
 // A contiguous piece of a FASTA file that starts at a '>' line -> one batch, with the record rules of FastxReader
 // (fastx.hpp; src/read_label.cpp:1651-1713): a record is its header line and the following lines up to the next '>'
@@ -92,7 +147,7 @@ static void parse_fasta_piece(const char* p, const char* end, Batch& b) {
     size_t hdr_len = 0;
     bool open = false;  // sequence bytes of the current record already appended
     auto close = [&]() {
-        if (open) { b.off.push_back(b.bases.size()); b.add_hdr(hdr ? hdr : "", hdr ? hdr_len : 0); }
+        if (open) { b.off.push_back(b.nb); b.add_hdr(hdr ? hdr : "", hdr ? hdr_len : 0); }
         open = false;
     };
     while (p < end) {
@@ -104,7 +159,7 @@ static void parse_fasta_piece(const char* p, const char* end, Batch& b) {
             hdr = p + 1;
             hdr_len = len - 1;
         } else if (len > 1) {
-            b.bases.insert(b.bases.end(), (const uint8_t*)p, (const uint8_t*)le);
+            b.add_bases(p, len);  // a piece is never larger than a pool buffer
             open = true;
         }
         p = nl ? nl + 1 : end;
@@ -119,6 +174,8 @@ struct Work {
     uint64_t seq = 0;                    // position of the batch in the input
     std::vector<lmat_read_result> res;
     std::unique_ptr<lmat_cand[]> cands;  // uninitialised on purpose: zero-filling 64 candidates per read cost more than the GPU work
+    size_t ncand = 0;
+    std::vector<std::string> text;       // per output shard, once formatted
 };
 class WorkQueue {
     std::mutex m;
@@ -228,7 +285,11 @@ int main(int argc, char* argv[]) {
     }
     const int n_gpu = (int)devices.size();
     std::vector<lmat_ctx*> ctxs(n_gpu, nullptr);
-    auto destroy_all = [&]() { for (lmat_ctx* x : ctxs) if (x) lmat_ctx_destroy(x); };
+    std::vector<lmat_stream*>* rings_p = nullptr;
+    auto destroy_all = [&]() {
+        if (rings_p) for (lmat_stream*& r : *rings_p) { if (r) lmat_stream_destroy(r); r = nullptr; }
+        for (lmat_ctx*& x : ctxs) { if (x) lmat_ctx_destroy(x); x = nullptr; }
+    };
     for (int g = 0; g < n_gpu; ++g)
         if (lmat_ctx_create(devices[g], &prm, &ctxs[g]) != LMAT_OK) {
             std::cerr << "ERROR! no usable HIP device " << devices[g] << " (this build has no CPU path)" << std::endl;
@@ -270,10 +331,27 @@ int main(int argc, char* argv[]) {
             n_total += nk;
         }
     }
-    // every GPU loads the taxonomy and the whole database (the table is replicated, reads are dealt out)
+    // host pipeline sizes: parser and formatter pools follow the CPUs this process may use; a batch is one FASTA piece
+    size_t kPiece = 8u << 20;
+    if (const char* e = getenv("LMAT_FASTA_PIECE")) kPiece = std::max<size_t>(16, strtoull(e, nullptr, 10));  // tests: force many pieces
+    const unsigned n_cpu = usable_cpus();
+    unsigned n_parse = std::max(1u, std::min(8u, n_cpu / 4));
+    if (const char* e = getenv("LMAT_PARSE_THREADS")) n_parse = std::max(1, atoi(e));
+    const size_t kBatch = 1u << 20;                                   // reads per GPU batch ...
+    const size_t kBatchBases = std::max<size_t>(kPiece, 1u << 20) + (1u << 20);  // ... and bases: one piece (+ the tail of its last record)
+    const int kSlots = 3;
+    const uint32_t cands_per_read = prm.prn_all ? 16 : 8;  // a slot grows itself when a batch prints more
+    int n_fmt_plan = std::max<int>(1, (int)std::min<unsigned>(n_cpu > 6 ? n_cpu - n_parse - 2 : n_cpu, 32u));
+    if (const char* e = getenv("LMAT_FORMAT_THREADS")) n_fmt_plan = std::max(1, atoi(e));
+    std::vector<lmat_stream*> rings(n_gpu, nullptr);
+    rings_p = &rings;
+    // every GPU loads the taxonomy and the whole database (the table is replicated, reads are dealt out); the pinned
+    // batch buffers are allocated meanwhile
     std::vector<std::string> setup_err(n_gpu);
+    bool pool_ok = true;
     {
         std::vector<std::thread> th;
+        th.emplace_back([&]() { pool_ok = g_pool.init(n_parse + 4 + (size_t)(kSlots + 1) * n_gpu + 4 + n_fmt_plan + 8 + 2, kBatchBases); });
         for (int g = 0; g < n_gpu; ++g)
             th.emplace_back([&, g]() {
                 lmat_ctx* x = ctxs[g];
@@ -293,9 +371,11 @@ int main(int argc, char* argv[]) {
                         if (lmat_db_add_taxhisto(x, fn.c_str()) != LMAT_OK) return bad("k-mer DB");
                     if (lmat_db_finalize(x) != LMAT_OK) return bad("k-mer DB");
                 }
+                if (lmat_stream_create(x, kBatch, kBatchBases, cands_per_read, kSlots, &rings[g]) != LMAT_OK) return bad("batch ring");
             });
         for (auto& x : th) x.join();
     }
+    if (!pool_ok) { std::cerr << "ERROR! out of pinned host memory for the batch buffers" << std::endl; destroy_all(); return -1; }
     for (int g = 0; g < n_gpu; ++g)
         if (!setup_err[g].empty()) {
             std::cerr << "ERROR! " << setup_err[g] << std::endl;
@@ -328,16 +408,14 @@ int main(int argc, char* argv[]) {
     std::map<uint32_t, int> merge_count;
     std::map<uint32_t, float> merge_score;
     std::map<int, int> nomatch_merge;
-    const size_t kBatch = 1u << 20;          // reads per batch ...
-    const size_t kBatchBases = 192u << 20;   // ... and bases per batch: what a slot of the GPU feed rings holds
-    uint64_t next_seq = 0;                   // batches are numbered in input order (reader thread only)
-    size_t read_count = 0;
+    std::atomic<size_t> read_count(0);
     double t_parse = 0, t_gpu = 0, t_fmt = 0, t_write = 0, t_tally = 0;  // LMAT_CLI_TIMING=1 prints the busy time of each stage
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b_) { return std::chrono::duration<double>(b_ - a).count(); };
-    WorkQueue parsed(2), classified(2);
-    // A FASTA query in a regular file is mapped and cut at '>' lines into 32 MB pieces that are parsed in parallel,
-    // one batch per piece (FASTQ and stdin keep the sequential reader: its header pairing is line-order dependent).
+    WorkQueue parsed(4), classified(8);
+    // A FASTA query in a regular file is mapped and cut at '>' lines into pieces that a pool of threads parses, one
+    // batch per piece, numbered in file order (FASTQ and stdin keep the sequential reader: its header pairing is
+    // line-order dependent).  Batches may reach the writer out of order; it puts them back.
     const char* map_base = nullptr;
     size_t map_size = 0;
     if (!fastq && query_fn != "-") {
@@ -345,62 +423,45 @@ int main(int argc, char* argv[]) {
         struct stat sb;
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
             void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) { map_base = (const char*)m; map_size = (size_t)sb.st_size; madvise(m, map_size, MADV_SEQUENTIAL); }
+            if (m != MAP_FAILED) { map_base = (const char*)m; map_size = (size_t)sb.st_size; madvise(m, map_size, MADV_WILLNEED); }
         }
         if (fd >= 0) close(fd);
     }
     std::thread reader([&]() {  // stage 1: FASTA/FASTQ -> batches
         if (map_base) {
-            size_t kPiece = 32u << 20;
-            if (const char* e = getenv("LMAT_FASTA_PIECE")) kPiece = std::max<size_t>(16, strtoull(e, nullptr, 10));  // tests: force many pieces
-            const unsigned P = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-            size_t pos = 0;
-            while (pos < map_size) {
-                auto tp0 = now();
-                std::vector<size_t> cut(1, pos);
-                for (unsigned j = 1; j <= P && cut.back() < map_size; ++j) {
-                    size_t target = cut.back() + kPiece;
-                    size_t c = map_size;
-                    while (target < map_size) {  // next line that starts with '>'
-                        const char* nl = (const char*)memchr(map_base + target, '\n', map_size - target);
-                        if (!nl) break;
-                        const size_t at = (size_t)(nl - map_base) + 1;
-                        if (at >= map_size) break;
-                        if (map_base[at] == '>') { c = at; break; }
-                        target = at;
-                    }
-                    cut.push_back(c);
+            auto tp0 = now();
+            std::vector<size_t> cut(1, 0);
+            while (cut.back() < map_size) {
+                size_t target = cut.back() + kPiece;
+                size_t c = map_size;
+                while (target < map_size) {  // next line that starts with '>'
+                    const char* nl = (const char*)memchr(map_base + target, '\n', map_size - target);
+                    if (!nl) break;
+                    const size_t at = (size_t)(nl - map_base) + 1;
+                    if (at >= map_size) break;
+                    if (map_base[at] == '>' && at - cut.back() + (64u << 10) < kBatchBases) { c = at; break; }
+                    if (at - cut.back() + (64u << 10) >= kBatchBases) { c = at; break; }  // one record longer than a piece: cut inside it (reads of that size are refused anyway)
+                    target = at;
                 }
-                const size_t np = cut.size() - 1;
-                std::vector<std::unique_ptr<Work>> ws(np);
-                std::vector<std::thread> th;
-                for (size_t j = 0; j < np; ++j) {
-                    ws[j].reset(new Work());
-                    th.emplace_back([&, j]() { parse_fasta_piece(map_base + cut[j], map_base + cut[j + 1], ws[j]->b); });
-                }
-                for (auto& x : th) x.join();
-                for (size_t j = 0; j < np; ++j) {
-                    Batch& b = ws[j]->b;
-                    const size_t n = b.n();
-                    bool unnamed = false;
-                    for (size_t i = 0; i < n && !unnamed; ++i) unnamed = b.hoff[i + 1] == b.hoff[i] || b.hdr_blob[b.hoff[i]] == '\0';
-                    if (unnamed) {  // "unknown_hdr:<running read number>" (:1728-1732)
-                        std::string blob;
-                        std::vector<uint64_t> ho(1, 0);
-                        for (size_t i = 0; i < n; ++i) {
-                            if (b.hoff[i + 1] == b.hoff[i] || b.hdr_blob[b.hoff[i]] == '\0') blob += "unknown_hdr:" + std::to_string(read_count + i + 1);
-                            else blob.append(b.hdr_blob, b.hoff[i], b.hoff[i + 1] - b.hoff[i]);
-                            ho.push_back(blob.size());
-                        }
-                        b.hdr_blob.swap(blob);
-                        b.hoff.swap(ho);
-                    }
-                    read_count += n;
-                    if (n) { b.bases.push_back(0); ws[j]->seq = next_seq++; parsed.push(std::move(ws[j])); }
-                }
-                pos = cut.back();
-                t_parse += secs(tp0, now());
+                cut.push_back(c);
             }
+            const size_t np = cut.size() - 1;
+            std::atomic<size_t> next_piece(0);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < n_parse; ++t)
+                th.emplace_back([&]() {
+                    for (;;) {
+                        std::unique_ptr<Work> w(new Work());  // takes its base buffer BEFORE its piece: whoever holds piece i can always finish it
+                        const size_t j = next_piece.fetch_add(1);
+                        if (j >= np) break;
+                        parse_fasta_piece(map_base + cut[j], map_base + cut[j + 1], w->b);
+                        w->seq = j;
+                        read_count += w->b.n();
+                        parsed.push(std::move(w));
+                    }
+                });
+            for (auto& x : th) x.join();
+            t_parse += secs(tp0, now());
             std::cout << "Total reads loaded: " << read_count << std::endl;
             parsed.close();
             return;
@@ -408,30 +469,73 @@ int main(int argc, char* argv[]) {
         FastxReader rd(*in, fastq);
         std::string read, hdr;
         bool more = true;
+        uint64_t next_seq = 0;
+        bool have_pending = false;
         while (more) {
             auto tp0 = now();
             std::unique_ptr<Work> w(new Work());
             Batch& b = w->b;
-            while (b.n() < kBatch && b.bases.size() + (64u << 10) < kBatchBases) {
-                if (!rd.next(read, hdr)) { more = false; break; }
-                ++read_count;
-                if (hdr.empty() || hdr[0] == '\0') {
-                    std::ostringstream o;
-                    o << "unknown_hdr:" << read_count;
-                    hdr = o.str();
+            while (b.n() < kBatch) {
+                if (!have_pending && !rd.next(read, hdr)) { more = false; break; }
+                have_pending = false;
+                if (read.size() > b.room()) {
+                    if (b.n() == 0) { std::cerr << "ERROR! a read of " << read.size() << " bases exceeds the batch buffer" << std::endl; more = false; }
+                    else have_pending = true;  // goes into the next batch
+                    break;
                 }
-                b.add_hdr(hdr.data(), hdr.size());
-                b.bases.insert(b.bases.end(), read.begin(), read.end());
-                b.off.push_back(b.bases.size());
+                ++read_count;
+                b.add_hdr(hdr.data(), hdr.size());   // an empty header is named by the writer, which knows the read's number
+                b.add_bases(read.data(), read.size());
+                b.off.push_back(b.nb);
             }
             if (!more) std::cout << "Total reads loaded: " << read_count << std::endl;
             t_parse += secs(tp0, now());
-            if (b.n()) { b.bases.push_back(0); w->seq = next_seq++; parsed.push(std::move(w)); }
+            if (b.n()) { w->seq = next_seq++; parsed.push(std::move(w)); }
         }
         parsed.close();
     });
-    const int n_fmt = std::max<int>(n_threads, (int)std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
-    std::thread writer([&]() {  // stage 3: text, files, tallies -- in input order whatever GPU a batch went through
+    const int n_fmt = n_fmt_plan;
+    size_t reads_before = 0;  // reads of the batches already written (writer thread only)
+    // stage 3a: formatter pool.  Each worker turns whole batches into the text of the n_threads output shards (shard t
+    // holds a contiguous block of every batch); batches are independent, so any number of them is formatted at once.
+    WorkQueue formatted(8);
+    std::mutex fmt_m;
+    auto format_batch = [&](Work& w) {
+        const Batch& b = w.b;
+        const lmat_cand* cands = w.cands.get();
+        const size_t n = b.n();
+        const size_t per = (n + n_threads - 1) / n_threads;
+        w.text.assign(n_threads, std::string());
+        for (int t = 0; t < n_threads; ++t) {
+            const size_t lo = std::min(n, t * per), hi = std::min(n, lo + per);
+            std::string s;  // built locally: neighbouring std::string headers in a vector share cache lines
+            s.reserve((hi - lo) * (prn_read ? 384 : 200));
+            for (size_t i = lo; i < hi; ++i) {
+                s.append(b.hdr_blob.data() + b.hoff[i], b.hoff[i + 1] - b.hoff[i]);
+                s += '\t';
+                if (prn_read) s.append((const char*)b.bases + b.off[i], b.off[i + 1] - b.off[i]);
+                else s += 'X';
+                s += '\t';
+                format_call(s, prm, k_size, w.res[i], cands);
+            }
+            w.text[t] = std::move(s);
+        }
+    };
+    std::vector<std::thread> formatters;
+    std::atomic<int> fmt_live(n_fmt);
+    for (int f = 0; f < n_fmt; ++f)
+        formatters.emplace_back([&]() {
+            double busy = 0;
+            while (std::unique_ptr<Work> w = classified.pop()) {
+                auto tp2 = now();
+                format_batch(*w);
+                busy += secs(tp2, now());
+                formatted.push(std::move(w));
+            }
+            { std::lock_guard<std::mutex> l(fmt_m); t_fmt = std::max(t_fmt, busy); }
+            if (--fmt_live == 0) formatted.close();
+        });
+    std::thread writer([&]() {  // stage 3b: files and tallies, in input order whatever GPU and formatter a batch went through
         std::map<uint64_t, std::unique_ptr<Work>> held;
         uint64_t want_seq = 0;
         for (;;) {
@@ -439,43 +543,35 @@ int main(int argc, char* argv[]) {
             auto it = held.find(want_seq);
             if (it != held.end()) { w = std::move(it->second); held.erase(it); }
             else {
-                w = classified.pop();
+                w = formatted.pop();
                 if (!w) break;
                 if (w->seq != want_seq) { const uint64_t sq = w->seq; held[sq] = std::move(w); continue; }
             }
             ++want_seq;
-            auto tp2 = now();
-            const Batch& b = w->b;
-            const std::vector<lmat_read_result>& res = w->res;
-            const lmat_cand* cands = w->cands.get();
-            const size_t n = b.n();
-            // shard t holds a contiguous block of every batch; a block is formatted in slices by several threads
-            const size_t per = (n + n_threads - 1) / n_threads;
-            const int slices = std::max(1, n_fmt / n_threads);
-            std::vector<std::string> text((size_t)n_threads * slices);
-            std::vector<std::thread> th;
-            for (int j = 0; j < n_threads * slices; ++j) {
-                th.emplace_back([&, j]() {
-                    const int t = j / slices, sl = j % slices;
-                    const size_t lo0 = std::min(n, t * per), hi0 = std::min(n, lo0 + per);
-                    const size_t sper = (hi0 - lo0 + slices - 1) / slices;
-                    const size_t lo = std::min(hi0, lo0 + sl * sper), hi = std::min(hi0, lo + sper);
-                    std::string& s = text[j];
-                    s.reserve((hi - lo) * (prn_read ? 384 : 200));
-                    for (size_t i = lo; i < hi; ++i) {
-                        s.append(b.hdr_blob.data() + b.hoff[i], b.hoff[i + 1] - b.hoff[i]);
-                        s += '\t';
-                        if (prn_read) s.append((const char*)b.bases.data() + b.off[i], b.off[i + 1] - b.off[i]);
-                        else s += 'X';
-                        s += '\t';
-                        format_call(s, prm, k_size, res[i], cands);
-                    }
-                });
-            }
-            for (auto& x : th) x.join();
             auto tp3 = now();
-            t_fmt += secs(tp2, tp3);
-            for (int j = 0; j < n_threads * slices; ++j) ofs[j / slices] << text[j];
+            {   // "unknown_hdr:<running read number>" for records without a header (:1728-1732): only the writer knows the
+                // read's number, so such a batch (rare) gets its headers now and is formatted again
+                Batch& bb = w->b;
+                const size_t nn = bb.n();
+                bool unnamed = false;
+                for (size_t i = 0; i < nn && !unnamed; ++i) unnamed = bb.hoff[i + 1] == bb.hoff[i] || bb.hdr_blob[bb.hoff[i]] == '\0';
+                if (unnamed) {
+                    std::string blob;
+                    std::vector<uint64_t> ho(1, 0);
+                    for (size_t i = 0; i < nn; ++i) {
+                        if (bb.hoff[i + 1] == bb.hoff[i] || bb.hdr_blob[bb.hoff[i]] == '\0') blob += "unknown_hdr:" + std::to_string(reads_before + i + 1);
+                        else blob.append(bb.hdr_blob, bb.hoff[i], bb.hoff[i + 1] - bb.hoff[i]);
+                        ho.push_back(blob.size());
+                    }
+                    bb.hdr_blob.swap(blob);
+                    bb.hoff.swap(ho);
+                    format_batch(*w);
+                }
+                reads_before += nn;
+            }
+            const std::vector<lmat_read_result>& res = w->res;
+            const size_t n = w->b.n();
+            for (int t = 0; t < n_threads; ++t) ofs[t] << w->text[t];
             auto tp4 = now();
             t_write += secs(tp3, tp4);
             // tallies in read order (proc_line :1241-1276), float sums like a -t 1 run
@@ -498,20 +594,32 @@ int main(int argc, char* argv[]) {
     std::atomic<bool> failed(false);
     std::mutex fail_m;
     std::string fail_msg;
-    const int kSlots = 3;
-    const uint32_t cands_per_read = prm.prn_all ? 24 : 8;  // a slot grows itself when a batch prints more
     std::vector<double> t_gpu_g(n_gpu, 0.0);
     std::vector<std::thread> gpu_threads;
     for (int g = 0; g < n_gpu; ++g)
         gpu_threads.emplace_back([&, g]() {
             lmat_ctx* x = ctxs[g];
-            lmat_stream* st = nullptr;
+            lmat_stream* st = rings[g];
             auto bail = [&](const char* what) {
                 std::lock_guard<std::mutex> l(fail_m);
                 if (!failed.exchange(true)) fail_msg = std::string(what) + ": " + lmat_last_error(x);
                 parsed.close();
             };
-            if (lmat_stream_create(x, kBatch, kBatchBases, cands_per_read, kSlots, &st) != LMAT_OK) return bail("batch ring");
+            auto collect = [&](Work& w, size_t at) -> bool {  // oldest batch in flight -> w.res[at..], candidates appended
+                const lmat_read_result* res = nullptr;
+                const lmat_cand* cd = nullptr;
+                uint64_t n = 0, nc = 0, tag = 0;
+                if (lmat_stream_next(st, &res, &cd, &n, &nc, &tag) != LMAT_OK) return false;
+                const size_t c0 = w.ncand;
+                std::unique_ptr<lmat_cand[]> grown(new lmat_cand[std::max<uint64_t>(c0 + nc, 1)]);
+                if (c0) memcpy(grown.get(), w.cands.get(), c0 * sizeof(lmat_cand));
+                if (nc) memcpy(grown.get() + c0, cd, nc * sizeof(lmat_cand));
+                w.cands = std::move(grown);
+                w.ncand = c0 + nc;
+                for (uint64_t i = 0; i < n; ++i) { w.res[at + i] = res[i]; w.res[at + i].cand_off += (uint32_t)c0; }
+                lmat_stream_release(st);
+                return true;
+            };
             std::queue<std::unique_ptr<Work>> flying;
             bool input_done = false;
             while (!failed) {
@@ -522,38 +630,41 @@ int main(int argc, char* argv[]) {
                 }
                 auto tp1 = now();
                 if (w) {
+                    const size_t n = w->b.n();
+                    w->res.resize(n);
+                    if (n == 0) { classified.push(std::move(w)); continue; }  // an empty piece keeps its place in the order
                     uint8_t* hb = nullptr;
                     uint64_t* ho = nullptr;
-                    const size_t n = w->b.n();
-                    if (lmat_stream_acquire(st, &hb, &ho) != LMAT_OK) { bail("classify"); break; }
-                    memcpy(hb, w->b.bases.data(), w->b.off[n]);
-                    memcpy(ho, w->b.off.data(), (n + 1) * 8);
-                    if (lmat_stream_submit(st, n, w->seq) != LMAT_OK) { bail("classify"); break; }
-                    flying.push(std::move(w));
+                    if (n <= kBatch) {
+                        if (lmat_stream_acquire(st, &hb, &ho) != LMAT_OK || lmat_stream_submit_from(st, w->b.bases, w->b.off.data(), n, w->seq) != LMAT_OK) { bail("classify"); break; }
+                        flying.push(std::move(w));
+                    } else {  // a piece of very short reads: more reads than a slot takes, in sub-batches one after the other
+                        bool ok = true;
+                        while (ok && !flying.empty()) { ok = collect(*flying.front(), 0); if (ok) { classified.push(std::move(flying.front())); flying.pop(); } }
+                        for (size_t lo = 0; ok && lo < n; lo += kBatch) {
+                            const size_t m = std::min(kBatch, n - lo);
+                            ok = lmat_stream_acquire(st, &hb, &ho) == LMAT_OK && lmat_stream_submit_from(st, w->b.bases, w->b.off.data() + lo, m, w->seq) == LMAT_OK && collect(*w, lo);
+                        }
+                        if (!ok) { bail("classify"); break; }
+                        classified.push(std::move(w));
+                    }
                     t_gpu_g[g] += secs(tp1, now());
                     continue;
                 }
                 if (flying.empty()) break;  // input done, nothing in flight
-                const lmat_read_result* res = nullptr;
-                const lmat_cand* cd = nullptr;
-                uint64_t n = 0, nc = 0, tag = 0;
-                if (lmat_stream_next(st, &res, &cd, &n, &nc, &tag) != LMAT_OK) { bail("classify"); break; }
+                if (!collect(*flying.front(), 0)) { bail("classify"); break; }
                 std::unique_ptr<Work> done = std::move(flying.front());
                 flying.pop();
-                done->res.assign(res, res + n);
-                done->cands.reset(new lmat_cand[std::max<uint64_t>(nc, 1)]);
-                if (nc) memcpy(done->cands.get(), cd, nc * sizeof(lmat_cand));
-                lmat_stream_release(st);
                 t_gpu_g[g] += secs(tp1, now());
                 classified.push(std::move(done));
             }
-            lmat_stream_destroy(st);
         });
     for (auto& x : gpu_threads) x.join();
     for (double v : t_gpu_g) t_gpu = std::max(t_gpu, v);
     if (failed) parsed.close();
     classified.close();
     reader.join();
+    for (auto& x : formatters) x.join();
     writer.join();
     if (failed) {
         std::cerr << "ERROR! " << fail_msg << std::endl;
@@ -576,7 +687,8 @@ int main(int argc, char* argv[]) {
     for (auto& o : ofs) o.close();
     if (getenv("LMAT_CLI_TIMING"))
         std::cerr << "[read_label] stage busy time: parse " << t_parse << " s, GPU feed (copy into the pinned slots + waiting for results, busiest of "
-                  << n_gpu << " GPUs) " << t_gpu << " s, format " << t_fmt << " s, write " << t_write << " s, tally " << t_tally << " s" << std::endl;
+                  << n_gpu << " GPUs) " << t_gpu << " s, format (busiest of " << n_fmt << " workers) " << t_fmt << " s, write " << t_write << " s, tally " << t_tally << " s" << std::endl;
+    const double t_pipeline = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     std::cout << "Finished classifing reads, doing final steps sequentially..." << std::endl;
 
     // names for the called taxids from the -u file (:1812-1835)
@@ -628,8 +740,10 @@ int main(int argc, char* argv[]) {
         static const char* names[3] = {"ReadTooShort", "NoDbHits", "LowScore"};
         for (auto& p : nomatch_merge) nom_ofs << names[p.first] << "\t" << p.second << std::endl;
     }
-    destroy_all();
+    // the query timer stops where upstream's does (read_label.cpp:1868): after the summaries, before teardown
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (getenv("LMAT_CLI_TIMING")) std::cerr << "[read_label] timeline: pipeline drained at " << t_pipeline << " s, summaries written at " << el << " s" << std::endl;
     std::cout << "DONE! Total query time: " << el << " sec = " << el / 60 << " min" << std::endl;
+    destroy_all();
     return 0;
 }
