@@ -214,6 +214,20 @@ class Ingest:
             self.h = None
 
 
+def host_alloc(nbytes):
+    """Page-locked host memory (lmat_host_alloc) -> address; free with host_free."""
+    lib = load_library()
+    p = C.c_void_p()
+    rc = lib.lmat_host_alloc(int(nbytes), C.byref(p))
+    if rc != 0:
+        raise LmatError(rc, "out of pinned host memory")
+    return p.value
+
+
+def host_free(addr):
+    load_library().lmat_host_free(C.c_void_p(addr))
+
+
 class Stream:
     """lmat_stream: a ring of pinned batch slots; copy in, classification and copy out of consecutive batches overlap."""
 
@@ -235,6 +249,25 @@ class Stream:
         C.memmove(po, off.ctypes.data, (n + 1) * 8)
         self.eng._chk(self.lib.lmat_stream_submit(self.h, n, tag))
         self.in_flight += 1
+
+    def submit_pinned(self, bases_ptr, off, n, tag=0):
+        """bases_ptr: address of the caller's own pinned buffer (host_alloc); off: uint64[n + 1] numpy array.  No copy."""
+        pb, po = C.c_void_p(), C.c_void_p()
+        self.eng._chk(self.lib.lmat_stream_acquire(self.h, C.byref(pb), C.byref(po)))
+        self.eng._chk(self.lib.lmat_stream_submit_from(self.h, bases_ptr, off.ctypes.data, n, tag))
+        self.in_flight += 1
+
+    def next_nocopy(self):
+        """Waits for the oldest batch and releases it at once -> (n_reads, n_cands, tag), or None."""
+        pr, pc = C.c_void_p(), C.c_void_p()
+        n, nc, tag = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        rc = self.lib.lmat_stream_next(self.h, C.byref(pr), C.byref(pc), C.byref(n), C.byref(nc), C.byref(tag))
+        if rc == 1:
+            return None
+        self.eng._chk(rc)
+        self.eng._chk(self.lib.lmat_stream_release(self.h))
+        self.in_flight -= 1
+        return int(n.value), int(nc.value), int(tag.value)
 
     def next(self):
         """-> (results copy, cands copy or None, tag) of the oldest batch, or None when nothing is in flight."""

@@ -59,7 +59,9 @@ __device__ __forceinline__ uint32_t hash32(uint64_t x) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K0: ASCII -> packed records.  One wave per read, 16 bases per lane per step.
+// K0: ASCII -> packed records.  One wave per read, one base per lane and step (coalesced 64-byte loads): the 2-bit
+// codes of 16 neighbouring lanes are OR-ed into a word with row-wide DPP shifts, the validity bits of all 64 lanes
+// are one ballot.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t* __restrict__ bases,
                                                          const uint64_t* __restrict__ off,
@@ -73,32 +75,27 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t* __restri
         const uint32_t len = (uint32_t)(off[r + 1] - b0);
         uint32_t* rec = words + rec_off[r];
         if (lane == 0) rec[0] = len;
-        const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
-        for (uint32_t w0 = 0; w0 < nb; w0 += 64) {
-            const uint32_t w = w0 + lane;
-            uint32_t code = 0, valid = 0;
-            if (w < nb) {
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t p = w * 16 + j;
-                    if (p < len) {
-                        uint8_t ch = bases[b0 + p];
-                        uint32_t t = 4;
-                        switch (ch) {  // ENCODE, read_label.cpp:943-950
-                            case 'a': case 'A': t = 0; break;
-                            case 'c': case 'C': t = 1; break;
-                            case 'g': case 'G': t = 2; break;
-                            case 't': case 'T': t = 3; break;
-                        }
-                        if (t < 4) { code |= t << (2 * j); valid |= 1u << j; }
-                    }
-                }
-                rec[1 + w] = code;
+        const uint32_t nb = (len + 15) / 16;
+        for (uint32_t p0 = 0; p0 < len; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            uint32_t t = 4;
+            if (p < len) {
+                const uint32_t ch = bases[b0 + p] & 0xDFu;  // ENCODE is case-insensitive (read_label.cpp:943-950)
+                t = ch == 'A' ? 0u : (ch == 'C' ? 1u : (ch == 'G' ? 2u : (ch == 'T' ? 3u : 4u)));
             }
-            // two neighbouring lanes hold the 32 validity bits of one mask word
-            uint32_t other = __shfl_down(valid, 1);
-            if (w < nb && (w & 1) == 0) rec[1 + nb + (w >> 1)] = valid | (((w + 1 < nb) ? other : 0u) << 16);
+            const bool ok = t < 4;
+            uint32_t code = ok ? t << (2 * (lane & 15)) : 0u;
+            // OR over each row of 16 lanes: row_shr 8, 4, 2, 1 (lanes without a source keep 0)
+            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x118, 0xf, 0xf, false);
+            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x114, 0xf, 0xf, false);
+            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x112, 0xf, 0xf, false);
+            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x111, 0xf, 0xf, false);
+            const uint32_t w = (p0 >> 4) + ((uint32_t)lane >> 4);
+            if ((lane & 15) == 15 && w < nb) rec[1 + w] = code;   // the last lane of a row holds the row's OR
+            const uint64_t v = __ballot(ok);
+            if (lane == 0) rec[1 + nb + (p0 >> 5)] = (uint32_t)v;
+            if (lane == 32 && p0 + 32 < len) rec[1 + nb + (p0 >> 5) + 1] = (uint32_t)(v >> 32);
         }
-        (void)nm;
     }
 }
 

@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <string>
+#include <thread>
 #include "kernels.hpp"
 #include "outfmt.hpp"
 
@@ -1260,7 +1262,6 @@ static void stream_free(lmat_stream* st) {
     }
     if (st->d_scratch_counts) hipFree(st->d_scratch_counts);
     if (st->s_h2d) hipStreamDestroy(st->s_h2d);
-    if (st->s_d2h) hipStreamDestroy(st->s_d2h);
     delete st;
 }
 
@@ -1276,8 +1277,13 @@ int lmat_stream_create(lmat_ctx* c, uint64_t max_reads, uint64_t max_bases, uint
     st->max_bases = max_bases;
     st->cands_per_read = cands_per_read;
     st->slots.resize(n_slots);
+    if (!c->stream2) {  // also the side stream of the K4 kernels (run_classify)
+        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { delete st; return set_err(c, LMAT_E_DEVICE, "cannot create a stream"); }
+    }
+    st->s_d2h = c->stream2;
     bool ok = hipStreamCreateWithFlags(&st->s_h2d, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&st->s_d2h, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc(&st->d_scratch_counts, c->counts_bytes) == hipSuccess;
     const uint64_t max_words = max_bases / 16 + max_bases / 32 + 3 * max_reads + 16;  // rec_words summed, rounded up per read
     for (auto& sl : st->slots) {
@@ -1331,6 +1337,9 @@ static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(sl.h_cursor, c->d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(sl.ev_done, c->stream));
+    // The copy back rides the context's second stream (idle once the K4 kernels have joined).  A stream of its own
+    // would be the fifth of the process: the runtime multiplexes streams onto 4 hardware queues, and a copy that shares
+    // its queue with the compute stream holds up the next batch's kernels behind it.
     HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_done, 0));
     HIPCHK(c, hipMemcpyAsync(sl.h_results, sl.d_results, sl.n * sizeof(lmat_read_result), hipMemcpyDeviceToHost, st->s_d2h));
     HIPCHK(c, hipEventRecord(sl.ev_out, st->s_d2h));
@@ -1341,6 +1350,9 @@ static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch
 // pinned buffer ext_bases instead of the slot's input buffers
 static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_t* ext_bases, const uint64_t* ext_off) {
     if (!st) return LMAT_E_ARG;
+    static const bool dbg = getenv("LMAT_DEBUG_STREAM") != nullptr;
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (dbg) fprintf(stderr, "[stream] %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count()); };
     lmat_ctx* c = st->c;
     lmat_stream::Slot& sl = st->slots[st->head % st->slots.size()];
     if (sl.state != 1) return set_err(c, LMAT_E_ARG, "lmat_stream_acquire first");
@@ -1352,20 +1364,59 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
     }
     if (n > st->max_reads || (n && sl.h_off[n] > st->max_bases)) { sl.state = 0; return set_err(c, LMAT_E_ARG, "batch larger than the stream was created for"); }
     hipSetDevice(c->device);
-    // record offsets and the length classes of the fast kernels (host: a pass over n offsets)
+    // record offsets and the length classes of the fast kernels: two passes over the n offsets, split over a few host
+    // threads when the batch is large (2 M reads took 12 ms in one thread, longer than the GPU needs for them)
     const uint32_t k = (uint32_t)c->dev.k;
+    const int nt = n >= (1u << 18) ? 4 : 1;
+    struct Part { uint64_t words = 0, cn[3] = {0, 0, 0}; uint32_t max_len = 0; bool bad = false; };
+    std::vector<Part> part(nt);
+    auto span = [&](int t, uint64_t& lo, uint64_t& hi) { lo = n * (uint64_t)t / nt; hi = n * (uint64_t)(t + 1) / nt; };
+    auto pass1 = [&](int t) {
+        uint64_t lo, hi;
+        span(t, lo, hi);
+        Part& p = part[t];
+        for (uint64_t i = lo; i < hi; ++i) {
+            const uint64_t len = sl.h_off[i + 1] - sl.h_off[i];
+            if (sl.h_off[i + 1] < sl.h_off[i] || len > 0x7FFFFFFF) { p.bad = true; return; }
+            p.max_len = std::max<uint32_t>(p.max_len, (uint32_t)len);
+            p.words += rec_words((uint32_t)len);
+            const uint32_t P = len >= k ? (uint32_t)len - k + 1 : 0;
+            p.cn[P <= 160 ? 0 : (P <= 256 ? 1 : 2)]++;
+        }
+    };
+    std::vector<uint64_t> wbase(nt + 1, 0), cbase(3 * (nt + 1), 0);
+    auto pass2 = [&](int t) {
+        uint64_t lo, hi;
+        span(t, lo, hi);
+        uint64_t w = wbase[t], cpos[3] = {cbase[3 * t], cbase[3 * t + 1], cbase[3 * t + 2]};
+        for (uint64_t i = lo; i < hi; ++i) {
+            const uint32_t len = (uint32_t)(sl.h_off[i + 1] - sl.h_off[i]);
+            sl.h_rec_off[i] = w;
+            w += rec_words(len);
+            const uint32_t P = len >= k ? len - k + 1 : 0;
+            const int j = P <= 160 ? 0 : (P <= 256 ? 1 : 2);
+            sl.h_cls[j][cpos[j]++] = (uint32_t)i;
+        }
+    };
+    auto run_parts = [&](auto&& fn) {
+        if (nt == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(fn, t);
+        fn(0);
+        for (auto& x : th) x.join();
+    };
+    run_parts(pass1);
     uint32_t max_len = 0;
     uint64_t cn[3] = {0, 0, 0};
-    sl.h_rec_off[0] = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t len = sl.h_off[i + 1] - sl.h_off[i];
-        if (sl.h_off[i + 1] < sl.h_off[i] || len > 0x7FFFFFFF) { sl.state = 0; return set_err(c, LMAT_E_ARG, "offsets must ascend"); }
-        max_len = std::max<uint32_t>(max_len, (uint32_t)len);
-        sl.h_rec_off[i + 1] = sl.h_rec_off[i] + rec_words((uint32_t)len);
-        const uint32_t P = len >= k ? (uint32_t)len - k + 1 : 0;
-        const int j = P <= 160 ? 0 : (P <= 256 ? 1 : 2);
-        sl.h_cls[j][cn[j]++] = (uint32_t)i;
+    for (int t = 0; t < nt; ++t) {
+        if (part[t].bad) { sl.state = 0; return set_err(c, LMAT_E_ARG, "offsets must ascend"); }
+        max_len = std::max(max_len, part[t].max_len);
+        wbase[t + 1] = wbase[t] + part[t].words;
+        for (int j = 0; j < 3; ++j) { cbase[3 * (t + 1) + j] = cbase[3 * t + j] + part[t].cn[j]; cn[j] += part[t].cn[j]; }
     }
+    run_parts(pass2);
+    sl.h_rec_off[n] = wbase[nt];
+    lap("offsets done");
     sl.n = n;
     sl.tag = tag;
     sl.reads.n = n;
@@ -1383,9 +1434,11 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
                 if (cn[j]) HIPCHK(c, hipMemcpyAsync(sl.reads.cls_dev[j], sl.h_cls[j], cn[j] * 4, hipMemcpyHostToDevice, st->s_h2d));
         HIPCHK(c, hipEventRecord(sl.ev_up, st->s_h2d));
         HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_up, 0));
+        lap("copies queued");
         launch_pack_reads(sl.d_bases, sl.d_off, sl.reads.rec_off, sl.reads.words, n, c->stream);
         const int rc = stream_launch(st, sl, false);
         if (rc) { sl.state = 0; return rc; }
+        lap("kernels queued");
     }
     sl.state = 2;
     ++st->head;
@@ -1440,8 +1493,14 @@ int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lm
             const int rc = stream_launch(st, sl, true);
             if (rc) return rc;
         }
-        if (sl.cand_cap && nc) HIPCHK(c, hipMemcpyAsync(sl.h_cands, sl.d_cands, nc * sizeof(lmat_cand), hipMemcpyDeviceToHost, st->s_d2h));
-        HIPCHK(c, hipStreamSynchronize(st->s_d2h));
+        // wait on this batch's own events, never on a whole stream: both streams already carry work of the batches behind it.
+        // The candidates (their number is only known now) go over the copy-in stream, whose queued copies are short.
+        if (sl.cand_cap && nc) {
+            HIPCHK(c, hipMemcpyAsync(sl.h_cands, sl.d_cands, nc * sizeof(lmat_cand), hipMemcpyDeviceToHost, st->s_h2d));
+            HIPCHK(c, hipEventRecord(sl.ev_up, st->s_h2d));  // ev_up of this slot is long past: reuse it as "candidates copied"
+            HIPCHK(c, hipEventSynchronize(sl.ev_up));
+        }
+        HIPCHK(c, hipEventSynchronize(sl.ev_out));
     }
     sl.state = 3;
     if (results) *results = sl.h_results;

@@ -40,5 +40,7 @@ if gat:
                           "note": "random 64-B bucket gather, 4 lanes x 16 B (8 x 8 B up to r01e): FETCH_SIZE x 1024 equals the byte count "
                                   "(the x2 correction of the guide applies to 16-B/lane streaming reads, not to this shape)"}
 json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
-json.dump({"hbm_bytes_per_launch": fetch + write, "from": f"profiles/{tag}_traffic.json"}, open("profiles/traffic_latest.json", "w"))
+json.dump({"hbm_bytes_per_launch": fetch + write, "from": f"profiles/{tag}_traffic.json", "reads_per_launch": bench["roofline"]["reads_per_launch"],
+           "db_gib": bench["config"]["db_gib"], "read_len": bench["config"]["read_len"], "kernel_avg_ms": bench["roofline"]["kernel_avg_ms"]},
+          open("profiles/traffic_latest.json", "w"))
 print(json.dumps({k: out[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "algorithmic_bytes_per_launch", "calibration")}, indent=1))
