@@ -128,6 +128,11 @@ int lmat_db_lookup(lmat_ctx* ctx, const uint64_t* kmers, uint64_t n, uint32_t* c
  * strain genome. */
 int lmat_synth_taxonomy(lmat_ctx* ctx, const uint32_t* branching6);
 int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes);
+/* ... with the share (in 1/1000) of every genome that is a block shared by the species of its genus (SURVEY 8d asks
+ * for 10 %: lmat_synth_db_build passes 100) and the number of copies of the taxid-list records the payloads are spread
+ * over (1 = every list once; more make the arena as large as a real database's, beyond the caches). */
+int lmat_synth_db_build2(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes,
+                         uint32_t genus_block_permille, uint32_t list_replicas);
 
 /* ---- label modes -------------------------------------------------------------------
  * -s permissive match (gPERMISSIVE_MATCH, read_label.cpp:1050-1058,1075-1102,1143) and run-time pruning of

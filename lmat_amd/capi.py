@@ -85,6 +85,7 @@ def load_library(path: str | None = None):
         "lmat_db_lookup": (i32, [vp, vp, u64, vp, vp, u32]),
         "lmat_synth_taxonomy": (i32, [vp, vp]),
         "lmat_synth_db_build": (i32, [vp, i32, u64, u64, u64]),
+        "lmat_synth_db_build2": (i32, [vp, i32, u64, u64, u64, u32, u32]),
         "lmat_reads_upload": (i32, [vp, vp, vp, u64, P(vp)]),
         "lmat_reads_synth": (i32, [vp, u64, vp, u32, u64, P(vp)]),
         "lmat_reads_download_ascii": (i32, [vp, vp, u64, u64, vp, vp]),
@@ -129,7 +130,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
             "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
             "lmat_ingest_lookup", "lmat_db_from_ingest", "lmat_nullmodel_load", "lmat_nullmodel_clear", "lmat_set_label_modes",
-            "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_reads_upload",
+            "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_synth_db_build2", "lmat_reads_upload",
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
@@ -380,8 +381,9 @@ class Engine:
         b = np.asarray(branching, dtype=np.uint32)
         self._chk(self.lib.lmat_synth_taxonomy(self.ctx, _ptr(b)))
 
-    def synth_db(self, genome_len, k=20, seed=2002, table_bytes=0):
-        self._chk(self.lib.lmat_synth_db_build(self.ctx, k, int(genome_len), seed, int(table_bytes)))
+    def synth_db(self, genome_len, k=20, seed=2002, table_bytes=0, genus_block_permille=100, list_replicas=1):
+        """Synthetic database on the device: a tenth of every genome is a block shared within its genus."""
+        self._chk(self.lib.lmat_synth_db_build2(self.ctx, k, int(genome_len), seed, int(table_bytes), genus_block_permille, list_replicas))
 
     @property
     def k(self):

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t* __restri
 // wide layout: 8 x (k-mer << 24 | payload) per bucket, linear probing over buckets from b
 __device__ __forceinline__ bool wide_insert(uint64_t* slots, uint32_t nbuckets, uint32_t b, uint64_t kmer, uint32_t payload) {
     const uint64_t val = (kmer << kPayloadBits) | payload;
-    for (uint32_t tries = 0; tries < nbuckets; ++tries) {
+    const uint32_t max_tries = nbuckets < (1u << 14) ? nbuckets : (1u << 14);  // a chain this long means the table is as good as full: fail, do not crawl
+    for (uint32_t tries = 0; tries < max_tries; ++tries) {
         unsigned long long* s = (unsigned long long*)(slots + (uint64_t)b * kSlotsPerBucket);
         for (int j = 0; j < kSlotsPerBucket; ++j) {
             unsigned long long old = s[j];
@@ -255,26 +256,27 @@ __global__ void cpt_merge_overflow_kernel(DeviceTables tb, unsigned long long* t
         local += merged ? 0 : 1;
     }
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(total, local);
+    if ((threadIdx.x & 63) == 0 && local) { atomicAdd(total, local); atomicAdd(total + 1, local); }  // total[1]: overflow entries alone
 }
 
 // ------------------------------------------------------------------------------------------
-// Synthetic genomes (bench configs): species ancestor = iid bases from a
-// counter-based PRNG; strain = ancestor with 1% substitutions.  All pure functions of
-// (seed, species/strain, position) so host code can reproduce any window.
+// Synthetic genomes (bench configs): species ancestor = iid bases from a counter-based PRNG, except
+// that the first `blk` bases are a block shared by all species of a genus (copied from a genus ancestor: the source of
+// k-mers with many taxids); strain = ancestor with 1% substitutions.  All pure functions of (seed, species / strain,
+// position) so host code can reproduce any window.
 // ------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint32_t synth_anc_base(uint64_t seed, uint32_t species, uint64_t pos) {
-    return (uint32_t)(splitmix(seed ^ ((uint64_t)(species + 1) << 40) ^ pos) >> 13) & 3u;
+__host__ __device__ __forceinline__ uint32_t synth_anc_base(const SynthGeo& g, uint32_t species, uint64_t pos) {
+    if (pos < g.blk) return (uint32_t)(splitmix(g.seed ^ 0x47454E5553ull ^ ((uint64_t)(species / g.spg + 1) << 40) ^ pos) >> 13) & 3u;
+    return (uint32_t)(splitmix(g.seed ^ ((uint64_t)(species + 1) << 40) ^ pos) >> 13) & 3u;
 }
-__host__ __device__ __forceinline__ uint32_t synth_strain_base(uint64_t seed, uint32_t species, uint32_t strain_global,
-                                                               uint64_t pos) {
-    uint32_t b = synth_anc_base(seed, species, pos);
-    uint64_t h = splitmix((seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
+__host__ __device__ __forceinline__ uint32_t synth_strain_base(const SynthGeo& g, uint32_t species, uint32_t strain_global, uint64_t pos) {
+    uint32_t b = synth_anc_base(g, species, pos);
+    uint64_t h = splitmix((g.seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
     if ((h % 100) == 0) b = (b + 1 + (uint32_t)((h >> 32) % 3)) & 3u;
     return b;
 }
-__host__ __device__ __forceinline__ bool synth_strain_mut(uint64_t seed, uint32_t strain_global, uint64_t pos) {
-    uint64_t h = splitmix((seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
+__host__ __device__ __forceinline__ bool synth_strain_mut(const SynthGeo& g, uint32_t strain_global, uint64_t pos) {
+    uint64_t h = splitmix((g.seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
     return (h % 100) == 0;
 }
 __host__ __device__ __forceinline__ uint64_t canon_from_fwd(uint64_t fwd, int k) {
@@ -282,38 +284,46 @@ __host__ __device__ __forceinline__ uint64_t canon_from_fwd(uint64_t fwd, int k)
     return fwd < x ? fwd : x;
 }
 
-// one thread per (species, window start); S strains per species (S <= 8)
-__global__ void synth_db_kernel(DeviceTables tb, uint64_t seed, uint32_t n_species, uint32_t S,
-                                uint64_t G, int k, const uint16_t* __restrict__ strain_idx,
-                                const uint32_t* __restrict__ list_payload /*[species*(1<<S)+mask]*/, uint32_t* fail,
-                                unsigned long long* inserted) {
-    const uint64_t npos = G - k + 1;
-    const uint64_t total = (uint64_t)n_species * npos;
+// one thread per (species, window start).  A window inside the genus block belongs to all spg * S strains of the genus:
+// the genus' first species handles it with a mask over those strains; any other window to the S strains of its species.
+// list_payload: [species << S | mask] for species windows, then at g_off [genus << (spg * S) | mask] for block windows.
+// rep > 1: a list payload points at one of rep copies of the arena (rep_stride payload units apart), picked by the k-mer.
+__global__ void synth_db_kernel(DeviceTables tb, SynthGeo g, int k, const uint16_t* __restrict__ strain_idx,
+                                const uint32_t* __restrict__ list_payload, uint64_t g_off, uint32_t rep, uint32_t rep_stride,
+                                uint32_t* fail, unsigned long long* inserted) {
+    const uint64_t npos = g.G - k + 1;
+    const uint64_t total = (uint64_t)g.n_species * npos;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long local = 0;
     for (; i < total; i += stride) {
         const uint32_t sp = (uint32_t)(i / npos);
         const uint64_t pos = i % npos;
+        const bool inblk = pos + k <= g.blk;
+        if (inblk && sp % g.spg != 0) continue;
         uint64_t anc = 0;
-        for (int j = 0; j < k; ++j) anc = (anc << 2) | synth_anc_base(seed, sp, pos + j);
+        for (int j = 0; j < k; ++j) anc = (anc << 2) | synth_anc_base(g, sp, pos + j);
+        const uint32_t ns = inblk ? g.spg * g.S : g.S;   // strains that carry this window; they are numbered from sp * S
         uint32_t mask = 0;
-        for (uint32_t s = 0; s < S; ++s) {
-            const uint32_t sg = sp * S + s;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const uint32_t sg = sp * g.S + s;
             bool mut = false;
-            for (int j = 0; j < k; ++j) mut |= synth_strain_mut(seed, sg, pos + j);
+            for (int j = 0; j < k; ++j) mut |= synth_strain_mut(g, sg, pos + j);
             if (!mut) {
                 mask |= 1u << s;
             } else {
                 uint64_t f = 0;
-                for (int j = 0; j < k; ++j) f = (f << 2) | synth_strain_base(seed, sp, sg, pos + j);
+                for (int j = 0; j < k; ++j) f = (f << 2) | synth_strain_base(g, sg / g.S, sg, pos + j);
                 if (!table_insert(tb, canon_from_fwd(f, k), strain_idx[sg])) atomicAdd(fail, 1u);
                 ++local;
             }
         }
         if (mask) {
-            if (!table_insert(tb, canon_from_fwd(anc, k), list_payload[(uint64_t)sp * (1u << S) + mask]))
-                atomicAdd(fail, 1u);
+            const uint64_t km = canon_from_fwd(anc, k);
+            uint32_t pay = inblk ? list_payload[g_off + ((uint64_t)(sp / g.spg) << (g.spg * g.S)) + mask]
+                                 : list_payload[((uint64_t)sp << g.S) + mask];
+            if (rep > 1 && pay >= kListBase) pay += (uint32_t)(mix64(km) % rep) * rep_stride;
+            if (!table_insert(tb, km, pay)) atomicAdd(fail, 1u);
             ++local;
         }
     }
@@ -333,8 +343,9 @@ __global__ void count_slots_kernel(const uint64_t* __restrict__ slots, uint64_t 
 // implicit in rec_off.  Mix per SURVEY 8d: 88% genome samples with 1% substitutions, 10%
 // iid random, 1% with a single N, 1% low-complexity (25-base period).
 __global__ void synth_reads_kernel(uint32_t* words, const uint64_t* __restrict__ rec_off,
-                                   const uint32_t* __restrict__ lengths, uint32_t n_lengths, uint64_t n, uint64_t seed,
-                                   uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G) {
+                                   const uint32_t* __restrict__ lengths, uint32_t n_lengths, uint64_t n, uint64_t seed, SynthGeo g) {
+    const uint32_t n_species = g.n_species, S = g.S;
+    const uint64_t G = g.G;
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -365,7 +376,7 @@ __global__ void synth_reads_kernel(uint32_t* words, const uint64_t* __restrict__
                         b = (uint32_t)(splitmix(h0 ^ ((uint64_t)(p % 25) << 20) ^ 0x7654321) >> 9) & 3u;
                     } else {
                         const uint64_t gp = rc ? goff + (len - 1 - p) : goff + p;
-                        b = synth_strain_base(db_seed, sp, sg, gp < G ? gp : G - 1);
+                        b = synth_strain_base(g, sp, sg, gp < G ? gp : G - 1);
                         if (rc) b ^= 3u;
                         const uint64_t e = splitmix(h0 ^ ((uint64_t)p << 24) ^ 0xABCDEF);
                         if ((e % 100) == 0) b = (b + 1 + (uint32_t)((e >> 32) % 3)) & 3u;
@@ -396,7 +407,7 @@ __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmer
         if (stride) tids[i * stride] = tb.tid32[pay];
         return;
     }
-    const uint32_t eoff = 2 * (pay - kListBase);
+    const uint32_t eoff = kListUnit * (pay - kListBase);
     const uint32_t nk = tb.arena[eoff + 1], nr = tb.arena[eoff + 2];
     counts[i] = nr;
     for (uint32_t j = 0; j < nr && j < stride; ++j) tids[i * stride + j] = tb.conv[tb.arena[eoff + kListHdr + 2 * nk + j]];
@@ -885,6 +896,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         return;
     }
     const uint32_t P = len - k + 1;
+    if (P < A.p_min || P > A.p_max) return;  // another launch over the same list takes this read
     if (P > (uint32_t)U) {  // the host sizes U from the batch's longest read
         if (lane == 0) {
             emit(255, 0);
@@ -1468,7 +1480,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             n = 1;
             w3 = w4 = pay;
             if (pay >= kListBase) {
-                const u32x4_a4 ch = *(const GAS u32x4_a4*)(arena + 2 * (pay - kListBase));  // [flags][n_kept][n_raw][ids...]
+                const u32x4 ch = *(const GAS u32x4*)(arena + (size_t)kListUnit * (pay - kListBase));  // [flags][n_kept][n_raw][ids...]
                 fl = ch.x & 0xFFFFu;
                 n = ch.x >> 16;
                 w3 = ch.y >> 16; w4 = ch.z & 0xFFFFu; w5 = ch.z >> 16; w6 = ch.w & 0xFFFFu;
@@ -1523,7 +1535,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             if (e < nel) {
                 const uint32_t d = el_d[e], n = dn[d];
                 if (n > 2) {
-                    const uint32_t eoff = 2 * (dpay[d] - kListBase) + kListHdr, j = e - dstart[d];
+                    const uint32_t eoff = kListUnit * (dpay[d] - kListBase) + kListHdr, j = e - dstart[d];
                     el_t[e] = arena[eoff + j];
                     el_ta[e] = arena[eoff + n + j];
                 }
@@ -2141,8 +2153,10 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #pragma push_macro("WSYNC")
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
+// resident waves per SIMD each class is compiled for: what its LDS footprint allows (and no more registers than that needs)
+constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > 128 ? (U <= 160 ? 3 : 2) : (U <= 160 ? (CPT ? 7 : 5) : (U <= 256 ? 5 : 3))); }
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
-__global__ __launch_bounds__(64, INK4 ? 1 : (CPT ? 7 : 5)) void classify_kernel(ClassifyArgs A) {
+__global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
     // U > 2048: the per-read tables of this workgroup live in global memory
     unsigned char* smem = U > 2048 ? A.gscratch + (size_t)blockIdx.x * WL<U, T, E, INK4, false>::BYTES : lds_smem;
@@ -2204,12 +2218,11 @@ void launch_insert_pairs(const DeviceTables& tb, const uint64_t* kmers, const ui
                          uint32_t* fail, hipStream_t stream) {
     hipLaunchKernelGGL(insert_pairs_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, tb, kmers, payload, n, fail);
 }
-void launch_synth_db(const DeviceTables& tb, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
-                     const uint16_t* strain_idx, const uint32_t* list_payload, uint32_t* fail,
-                     unsigned long long* inserted, hipStream_t stream) {
-    const uint64_t total = (uint64_t)n_species * (G - k + 1);
-    hipLaunchKernelGGL(synth_db_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, stream, tb, seed,
-                       n_species, S, G, k, strain_idx, list_payload, fail, inserted);
+void launch_synth_db(const DeviceTables& tb, const SynthGeo& g, int k, const uint16_t* strain_idx, const uint32_t* list_payload,
+                     uint64_t g_off, uint32_t rep, uint32_t rep_stride, uint32_t* fail, unsigned long long* inserted, hipStream_t stream) {
+    const uint64_t total = (uint64_t)g.n_species * (g.G - k + 1);
+    hipLaunchKernelGGL(synth_db_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, stream, tb, g, k, strain_idx, list_payload,
+                       g_off, rep, rep_stride, fail, inserted);
 }
 // number of k-mers in the table -> *out (after a build; the compact layout is tidied on the way)
 void launch_table_count(const DeviceTables& tb, unsigned long long* out, hipStream_t stream) {
@@ -2222,9 +2235,9 @@ void launch_table_count(const DeviceTables& tb, unsigned long long* out, hipStre
     hipLaunchKernelGGL(cpt_merge_overflow_kernel, dim3(grid_for((uint64_t)tb.ovf_nbuckets * kSlotsPerBucket, 256, 16384)), dim3(256), 0, stream, tb, out);
 }
 void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t* lengths, uint32_t n_lengths, uint64_t n,
-                        uint64_t seed, uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G, hipStream_t stream) {
+                        uint64_t seed, const SynthGeo& g, hipStream_t stream) {
     hipLaunchKernelGGL(synth_reads_kernel, dim3(grid_for(n, 4, 16384)), dim3(256), 0, stream, words, rec_off, lengths,
-                       n_lengths, n, seed, db_seed, n_species, S, G);
+                       n_lengths, n, seed, g);
 }
 void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids,
                    uint32_t stride, hipStream_t stream) {
@@ -2297,7 +2310,7 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     const int per_cu = 160 * 1024 / lds_bytes;
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * 2;
     if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)a.count;
-    if (a.count_ptr && grid > 512) grid = 512;
+    if (a.count_ptr && INK4 && grid > 512) grid = 512;  // the lists of the large classes are short; the E = 512 class may get a tenth of a batch
     if (grid < 1) grid = 1;
     classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
@@ -2312,7 +2325,9 @@ size_t classify_gmem_scratch_bytes() { return (size_t)kGmemGrid * WL<kGmemU, 409
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream) {
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
-    if (P <= 160 && tcap_class == 0) {
+    if (tcap_class == 2) {  // reads whose kept lists add up to more than 128 elements (many strains per k-mer): 512 of them
+        if (P <= 160) LC(160, 64, 512, false); else LC(512, 64, 512, false);
+    } else if (P <= 160 && tcap_class == 0) {
         LC(160, 64, 128, false);
     } else if (P <= 256) {
         if (tcap_class == 0) LC(256, 64, 128, false); else LC(256, 1024, 4096, true);
@@ -2328,8 +2343,8 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
     return true;
 }
 
-uint32_t synth_strain_base_host(uint64_t seed, uint32_t species, uint32_t strain_global, uint64_t pos) {
-    return synth_strain_base(seed, species, strain_global, pos);
+uint32_t synth_strain_base_host(const SynthGeo& g, uint32_t species, uint32_t strain_global, uint64_t pos) {
+    return synth_strain_base(g, species, strain_global, pos);
 }
 
 }  // namespace lmat

@@ -10,6 +10,7 @@ struct ClassifyArgs {
     const uint32_t* words;     // packed read records
     const uint64_t* rec_off;   // [n+1] word offsets
     const uint32_t* index;     // optional explicit read list (re-runs), else first+i
+    uint32_t p_min = 0, p_max = 0xFFFFFFFFu;  // a re-run launch only takes the listed reads with this many k-mer positions
     uint64_t first, count;
     uint64_t result_base;      // results[r - result_base]
     lmat_read_result* results;
@@ -19,7 +20,7 @@ struct ClassifyArgs {
     void* counts;              // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint32_t phix_call_idx;    // internal index of 32630
     uint32_t* ovf_list;        // reads that exceed this launch's capacities are appended here (count in cursor[ovf_slot])
-    uint32_t ovf_slot;         // 2: fast class -> large LDS class; 3: large LDS class -> global-memory class
+    uint32_t ovf_slot;         // cursor word that counts ovf_list: 2 fast -> E=512 class, 3 -> large LDS class, 7 -> global-memory class
     const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
     uint32_t* k4buf;           // per-read records handed from the fast classify kernel to the K4 kernels
     uint32_t* k4_small;        // read indices awaiting K4, small tables (count in cursor[4])
@@ -47,15 +48,14 @@ void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t
                        hipStream_t stream);
 void launch_insert_pairs(const DeviceTables& tb, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
                          uint32_t* fail, hipStream_t stream);
-void launch_synth_db(const DeviceTables& tb, uint64_t seed, uint32_t n_species, uint32_t S, uint64_t G, int k,
-                     const uint16_t* strain_idx, const uint32_t* list_payload, uint32_t* fail,
-                     unsigned long long* inserted, hipStream_t stream);
+void launch_synth_db(const DeviceTables& tb, const SynthGeo& g, int k, const uint16_t* strain_idx, const uint32_t* list_payload,
+                     uint64_t g_off, uint32_t rep, uint32_t rep_stride, uint32_t* fail, unsigned long long* inserted, hipStream_t stream);
 void launch_table_count(const DeviceTables& tb, unsigned long long* out, hipStream_t stream);
 void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t* lengths, uint32_t n_lengths, uint64_t n,
-                        uint64_t seed, uint64_t db_seed, uint32_t n_species, uint32_t S, uint64_t G, hipStream_t stream);
+                        uint64_t seed, const SynthGeo& g, hipStream_t stream);
 void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids,
                    uint32_t stride, hipStream_t stream);
-// tcap_class: 0 = fast (T=128), 1 = large (T=1024).  Returns false if max_len exceeds every U class.
+// tcap_class: 0 = fast (T=64, E=128), 2 = the same with E=512, 1 = large (T=1024).  Returns false if max_len exceeds every U class.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
 void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipEvent_t forked, hipEvent_t joined);
 int classify_max_read_len();
@@ -66,6 +66,6 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
 
 
 // host-callable copies of the synthetic genome functions (tests / oracle cross-checks)
-uint32_t synth_strain_base_host(uint64_t seed, uint32_t species, uint32_t strain_global, uint64_t pos);
+uint32_t synth_strain_base_host(const SynthGeo& g, uint32_t species, uint32_t strain_global, uint64_t pos);
 
 }  // namespace lmat

@@ -115,7 +115,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
+                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
     for (void* p : ptrs)
         if (p) hipFree(p);
     sb_free(c);
@@ -269,7 +269,12 @@ int lmat_db_load_image(lmat_ctx* c, const char* fn, uint64_t table_bytes) {
 
 // Share of the k-mers that do not fit their 12-slot bucket at an average of `load` k-mers per bucket (k-mers arrive in
 // minimizer groups of ~2.5, so the tail is heavier than Poisson; scripts/minimizer_sim.py: 6.1 % at 6.4).
-static double cpt_displaced_share(double load) { return std::min(0.6, 0.061 * std::pow(load / 6.4, 3.2)); }
+// Share of the k-mers that do not fit their 12-slot bucket at an average of `load` k-mers per bucket.  K-mers arrive in
+// minimizer groups (~2.5 per genome, several times that where many strains share a region), so the tail is far heavier
+// than Poisson: scripts/minimizer_sim.py gives 6.1 % at 6.4 for three strains per species.  The overflow table is sized
+// for twice this estimate plus 1 % at a load of 0.6, and the build refuses a table that ends up more than 85 % full
+// (linear probing there means probe chains of thousands of buckets).
+static double cpt_displaced_share(double load) { return std::min(0.6, 0.061 * std::pow(load / 6.4, 2.5) + 0.01); }
 
 static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k) {
     if (c->dev.slots) { hipFree(c->dev.slots); c->dev.slots = nullptr; }
@@ -279,23 +284,37 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int 
     const char* fmt = getenv("LMAT_TABLE_FORMAT");  // "wide": the 8 x 64-bit-slot layout for every table (A/B runs)
     if (!(fmt && !strcmp(fmt, "wide"))) {
         // compact layout, ~10 bytes per k-mer: 6.4 k-mers on average in a 12-slot bucket
-        const uint64_t want = table_bytes ? table_bytes / 64 : (uint64_t)((double)n_kmers / 6.4) + 1;
-        const CptGeom g = cpt_geometry(k, want);
-        if (g.nb) {
+        uint64_t want = table_bytes ? table_bytes / 64 : (uint64_t)((double)n_kmers / 6.4) + 1;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = ~(size_t)0;
+        for (int attempt = 0; attempt < 8; ++attempt) {  // the bucket count is quantised: step down while table + overflow exceed the free memory
+            CptGeom g = cpt_geometry(k, want);
+            if (!g.nb) break;
+            // 2^32 buckets (256 GiB) address correctly, but a 20 G k-mer build into them did not finish on a 288 GiB
+            // device (cause not established): stop at 2^31 buckets unless asked, the rest of the k-mers goes to the overflow table
+            if (g.nb > (1ull << 31) && !getenv("LMAT_ALLOW_4G_BUCKETS")) { want = 1ull << 31; g = cpt_geometry(k, want); }
             const double n_est = n_kmers ? (double)n_kmers : 6.4 * (double)g.nb;
             const double load = n_est / (double)g.nb;
-            if (load > 11.0) return set_err(c, LMAT_E_CAPACITY, "table_bytes too small for the number of k-mers");
-            double share = cpt_displaced_share(load) * 1.6;
+            if (load > 10.0) return set_err(c, LMAT_E_CAPACITY, "table_bytes (or the free device memory) too small for the number of k-mers");
+            double share = cpt_displaced_share(load) * 2.0;
             if (const char* e = getenv("LMAT_OVERFLOW_SHARE")) share = atof(e);
-            uint64_t onb = (uint64_t)(n_est * share / (0.7 * kSlotsPerBucket)) + 1024;
+            const uint64_t onb = (uint64_t)(n_est * share / (0.6 * kSlotsPerBucket)) + 1024;
             if (onb > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "overflow table above 2^32 buckets");
-            HIPCHK(c, hipMalloc((void**)&c->dev.slots, (uint64_t)g.nb * 64));
+            if ((double)(g.nb + onb) * 64.0 + 6.0 * (double)(1ull << 30) > (double)free_b && g.W < (127u >> g.lowbits)) {
+                want = (1ull << (2 * g.m - g.lowbits)) / (g.W + 1);  // the next smaller table
+                if (want < 1) break;
+                continue;
+            }
+            HIPCHK(c, hipMalloc((void**)&c->dev.slots, g.nb * 64));
             HIPCHK(c, hipMalloc((void**)&c->dev.ovf_slots, onb * 64));
-            HIPCHK(c, hipMemsetAsync(c->dev.slots, 0, (uint64_t)g.nb * 64, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->dev.slots, 0, g.nb * 64, c->stream));
             HIPCHK(c, hipMemsetAsync(c->dev.ovf_slots, 0, onb * 64, c->stream));
-            c->dev.nbuckets = g.nb;
+            c->dev.nbuckets = (uint32_t)std::min<uint64_t>(g.nb, 0xFFFFFFFFull);  // (the gather microbenchmark's range)
             c->dev.cpt = g;
             c->dev.ovf_nbuckets = (uint32_t)onb;
+            if (getenv("LMAT_DEBUG"))
+                fprintf(stderr, "[lmat] compact table: %llu buckets (W=%u, %.1f GiB), expected load %.2f, overflow table %llu buckets (%.1f GiB)\n",
+                        (unsigned long long)g.nb, g.W, g.nb * 64.0 / (1ull << 30), load, (unsigned long long)onb, onb * 64.0 / (1ull << 30));
             return LMAT_OK;
         }
     }
@@ -315,9 +334,16 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int 
 // canonical payloads (16-bit DB id / list number) -> device payloads (internal taxid index / arena offset), chunk by
 // chunk: list records are built the first time a list is seen, so a database streams through without the whole
 // (k-mer, payload) array ever being resident on the host.
+// appends a list record on the next 16-byte boundary of the arena; returns its payload
+static uint32_t arena_append(std::vector<uint16_t>& arena, const std::vector<uint16_t>& rec) {
+    arena.resize((arena.size() + kListUnit - 1) / kListUnit * kListUnit, 0);
+    const uint32_t pay = kListBase + (uint32_t)(arena.size() / kListUnit);
+    arena.insert(arena.end(), rec.begin(), rec.end());
+    return pay;
+}
 namespace lmat {
 struct StreamBuild {
-    std::vector<uint16_t> arena{0, 0};  // offset 0 reserved
+    std::vector<uint16_t> arena = std::vector<uint16_t>(kListUnit, 0);  // record 0 reserved
     std::vector<uint32_t> list_pay;     // per canonical list: device payload (0 = not built yet)
     std::vector<uint32_t> single_pay = std::vector<uint32_t>(65536, 0);
     std::vector<uint32_t> pay;
@@ -366,8 +392,7 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
                 uint32_t& lp = S.list_pay[p - kListBase];
                 if (!lp) {
                     if (!build_list_record(c, B.lists[p - kListBase], rec)) return LMAT_E_TAXONOMY;
-                    lp = kListBase + (uint32_t)(S.arena.size() / 2);
-                    S.arena.insert(S.arena.end(), rec.begin(), rec.end());
+                    lp = arena_append(S.arena, rec);
                 }
                 dp = lp;
             } else {
@@ -384,15 +409,14 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
                     } else {
                         one[0] = (uint16_t)p;
                         if (!build_list_record(c, one, rec)) return LMAT_E_TAXONOMY;
-                        sp = kListBase + (uint32_t)(S.arena.size() / 2);
-                        S.arena.insert(S.arena.end(), rec.begin(), rec.end());
+                        sp = arena_append(S.arena, rec);
                     }
                 }
                 dp = sp;
             }
             S.pay[i] = dp;
         }
-        if (S.arena.size() / 2 + kListBase > kPayloadMask)
+        if (S.arena.size() / kListUnit + kListBase > kPayloadMask)
             return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
         HIPCHK(c, hipMemcpyAsync(S.d_k, B.kmers.data() + s, m * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(S.d_p, S.pay.data(), m * 4, hipMemcpyHostToDevice, c->stream));
@@ -403,6 +427,15 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
     B.flushed += n;
     B.kmers.clear();
     B.payload.clear();
+    return LMAT_OK;
+}
+// an overflow table that is nearly full answers every miss with a probe chain of thousands of buckets: refuse it
+static int check_overflow_fill(lmat_ctx* c, uint64_t entries) {
+    const double fill = c->dev.ovf_nbuckets ? (double)entries / ((double)c->dev.ovf_nbuckets * kSlotsPerBucket) : 0.0;
+    if (getenv("LMAT_DEBUG")) fprintf(stderr, "[lmat] overflow table: %llu k-mers, %.1f %% full\n", (unsigned long long)entries, 100.0 * fill);
+    if (fill > 0.85)
+        return set_err(c, LMAT_E_CAPACITY, "the overflow table of the compact layout is " + std::to_string((int)(100 * fill)) +
+                                           " % full: give the table more room (table_bytes) or raise LMAT_OVERFLOW_SHARE");
     return LMAT_OK;
 }
 static int sb_finish(lmat_ctx* c) {
@@ -419,14 +452,16 @@ static int sb_finish(lmat_ctx* c) {
     if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during insert (n_kmers_hint / table_bytes too small)");
     if (c->dev.cpt.nb) {  // tidy the compact buckets (slot counts; a key fed twice keeps its smaller payload) and count
         unsigned long long* d_n = nullptr;
-        unsigned long long cnt = 0;
-        HIPCHK(c, hipMalloc((void**)&d_n, 8));
-        HIPCHK(c, hipMemsetAsync(d_n, 0, 8, c->stream));
+        unsigned long long cnt[2] = {0, 0};
+        HIPCHK(c, hipMalloc((void**)&d_n, 16));
+        HIPCHK(c, hipMemsetAsync(d_n, 0, 16, c->stream));
         launch_table_count(c->dev, d_n, c->stream);
-        HIPCHK(c, hipMemcpyAsync(&cnt, d_n, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(cnt, d_n, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         hipFree(d_n);
-        n = cnt;
+        n = cnt[0];
+        int rc2 = check_overflow_fill(c, cnt[1]);
+        if (rc2) return rc2;
     }
     c->n_kmers = n;
     c->db_ready = true;
@@ -479,7 +514,9 @@ int lmat_db_from_ingest(lmat_ctx* c, lmat_ingest* g, uint64_t table_bytes) {
 
 int lmat_db_kmer_length(const lmat_ctx* c) { return c ? c->dev.k : 0; }
 uint64_t lmat_db_size(const lmat_ctx* c) { return c ? c->n_kmers : 0; }
-uint64_t lmat_db_table_bytes(const lmat_ctx* c) { return c ? ((uint64_t)c->dev.nbuckets + c->dev.ovf_nbuckets) * 64 : 0; }
+uint64_t lmat_db_table_bytes(const lmat_ctx* c) {
+    return c ? ((c->dev.cpt.nb ? c->dev.cpt.nb : (uint64_t)c->dev.nbuckets) + c->dev.ovf_nbuckets) * 64 : 0;
+}
 
 int lmat_db_lookup(lmat_ctx* c, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids, uint32_t stride) {
     if (!c || !c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
@@ -561,62 +598,126 @@ int lmat_synth_taxonomy(lmat_ctx* c, const uint32_t* br) {
 }
 
 int lmat_synth_db_build(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t table_bytes) {
+    return lmat_synth_db_build2(c, k, G, seed, table_bytes, 100, 1);
+}
+
+int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t table_bytes, uint32_t genus_block_permille,
+                         uint32_t list_replicas) {
     if (!c || !c->tax.loaded || !c->synth_n_species) return set_err(c, LMAT_E_ARG, "lmat_synth_taxonomy first");
     if (k < 1 || k > 20 || G < (uint64_t)k) return set_err(c, LMAT_E_ARG, "bad k / genome length");
+    if (genus_block_permille > 1000 || list_replicas < 1) return set_err(c, LMAT_E_ARG, "bad genus block share / replica count");
     hipSetDevice(c->device);
     const uint32_t S = c->synth_strains_per_species, NS = c->synth_n_species;
     if (S > 8) return set_err(c, LMAT_E_ARG, "at most 8 strains per species");
-    // one list per (species, non-empty strain subset): owners + the species when >= 2 owners,
-    // i.e. what tax_histo's LCA closure yields (src/kmerdb/TaxTree.hpp:160-260)
-    std::vector<uint16_t> arena(2, 0), rec;
-    std::vector<uint32_t> list_payload((size_t)NS << S, 0);
+    const uint32_t spg = std::max<uint32_t>(c->synth_branching[4], 1);
+    const uint32_t GB = spg * S;  // strains of a genus
+    SynthGeo geo;
+    geo.seed = seed; geo.G = G; geo.n_species = NS; geo.S = S; geo.spg = spg;
+    geo.blk = GB <= 12 && NS % spg == 0 ? G * genus_block_permille / 1000 : 0;  // the genus lists are a table over 2^GB strain subsets
+    if (geo.blk < (uint64_t)k) geo.blk = 0;
+    const uint32_t NG = NS / spg;
     const HostTaxonomy& T = c->tax;
-    for (uint32_t sp = 0; sp < NS; ++sp)
-        for (uint32_t mask = 1; mask < (1u << S); ++mask) {
-            std::vector<uint16_t> raw;
-            for (uint32_t s = 0; s < S; ++s)
-                if (mask & (1u << s)) raw.push_back(T.br.at(T.tid32[c->synth_strain_idx[sp * S + s]]));
-            if (raw.size() == 1) {
-                list_payload[((size_t)sp << S) + mask] = c->synth_strain_idx[sp * S + __builtin_ctz(mask)];
-                continue;
+    auto id16 = [&](uint16_t internal) { return T.br.at(T.tid32[internal]); };
+    // one list per (species, non-empty strain subset): owners + the species when >= 2 owners, and, for the windows of the
+    // genus block, per (genus, non-empty subset of its strains): owners + their species + the genus when the owners span
+    // species -- what tax_histo's LCA closure yields (src/kmerdb/TaxTree.hpp:160-260).  Records are built on all host cores.
+    const uint64_t g_off = (uint64_t)NS << S;
+    std::vector<uint32_t> list_payload(g_off + (geo.blk ? (uint64_t)NG << GB : 0), 0);
+    struct Made { uint64_t slot; std::vector<uint16_t> rec; };
+    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<Made>> made(nthr);
+    std::vector<int> bad(nthr, 0);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthr; ++t)
+            th.emplace_back([&, t]() {
+                std::vector<uint16_t> raw, rec;
+                for (uint32_t sp = t; sp < NS; sp += nthr)
+                    for (uint32_t mask = 1; mask < (1u << S); ++mask) {
+                        if (__builtin_popcount(mask) == 1) continue;
+                        raw.clear();
+                        for (uint32_t s = 0; s < S; ++s) if (mask & (1u << s)) raw.push_back(id16(c->synth_strain_idx[sp * S + s]));
+                        raw.push_back(id16(c->synth_species_idx[sp]));
+                        if (!build_list_record(c, raw, rec)) { bad[t] = 1; return; }
+                        made[t].push_back({((uint64_t)sp << S) + mask, rec});
+                    }
+                if (!geo.blk) return;
+                for (uint32_t ge = t; ge < NG; ge += nthr)
+                    for (uint32_t mask = 1; mask < (1u << GB); ++mask) {
+                        uint32_t spmask = 0;
+                        for (uint32_t s = 0; s < GB; ++s) if (mask & (1u << s)) spmask |= 1u << (s / S);
+                        if (__builtin_popcount(spmask) < 2) continue;  // owners within one species: the species list (or a single strain)
+                        raw.clear();
+                        for (uint32_t s = 0; s < GB; ++s) if (mask & (1u << s)) raw.push_back(id16(c->synth_strain_idx[ge * GB + s]));
+                        for (uint32_t q = 0; q < spg; ++q) if (spmask & (1u << q)) raw.push_back(id16(c->synth_species_idx[ge * spg + q]));
+                        const uint16_t sp0 = c->synth_species_idx[ge * spg];
+                        raw.push_back(id16(T.paths[T.path_off[sp0]]));  // the genus: parent of its species
+                        if (!build_list_record(c, raw, rec)) { bad[t] = 1; return; }
+                        made[t].push_back({g_off + ((uint64_t)ge << GB) + mask, rec});
+                    }
+            });
+        for (auto& x : th) x.join();
+    }
+    for (int b_ : bad) if (b_) return LMAT_E_TAXONOMY;
+    std::vector<uint16_t> arena(kListUnit, 0);  // record 0 reserved
+    for (auto& v : made)
+        for (auto& m : v) list_payload[m.slot] = arena_append(arena, m.rec);
+    made.clear();
+    for (uint32_t sp = 0; sp < NS; ++sp)  // single owners: plain strain payloads
+        for (uint32_t s = 0; s < S; ++s) list_payload[((uint64_t)sp << S) + (1u << s)] = c->synth_strain_idx[sp * S + s];
+    if (geo.blk)
+        for (uint32_t ge = 0; ge < NG; ++ge)
+            for (uint32_t mask = 1; mask < (1u << GB); ++mask) {
+                uint32_t spmask = 0;
+                for (uint32_t s = 0; s < GB; ++s) if (mask & (1u << s)) spmask |= 1u << (s / S);
+                if (__builtin_popcount(spmask) >= 2) continue;
+                const uint32_t q = (uint32_t)__builtin_ctz(spmask);  // all owners in species q of the genus: that species' list
+                list_payload[g_off + ((uint64_t)ge << GB) + mask] = list_payload[((uint64_t)(ge * spg + q) << S) + ((mask >> (q * S)) & ((1u << S) - 1))];
             }
-            raw.push_back(T.br.at(T.tid32[c->synth_species_idx[sp]]));
-            if (!build_list_record(c, raw, rec)) return LMAT_E_TAXONOMY;
-            list_payload[((size_t)sp << S) + mask] = kListBase + (uint32_t)(arena.size() / 2);
-            arena.insert(arena.end(), rec.begin(), rec.end());
-        }
-    if (arena.size() / 2 + kListBase > kPayloadMask) return set_err(c, LMAT_E_CAPACITY, "arena too large");
+    arena.resize((arena.size() + kListUnit - 1) / kListUnit * kListUnit, 0);
+    const uint64_t block_units = arena.size() / kListUnit;   // payload units of one copy of the records
+    if (block_units * list_replicas + kListBase > kPayloadMask) return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
     int rc;
-    const size_t arena_words = arena.size();
-    arena.resize(arena_words + 8, 0);  // the kernels read a record's first 16 bytes in one load
-    if ((rc = dev_upload(c, &c->dev.arena, arena))) return rc;
-    c->arena_words = arena_words;
+    {   // the device arena: list_replicas copies back to back (+ 16 bytes of slack: a record's first 16 bytes are one load)
+        if (c->dev.arena) { hipFree(c->dev.arena); c->dev.arena = nullptr; }
+        const size_t bytes = arena.size() * 2;
+        HIPCHK(c, hipMalloc((void**)&c->dev.arena, bytes * list_replicas + 64));
+        HIPCHK(c, hipMemset((char*)c->dev.arena + bytes * list_replicas, 0, 64));
+        HIPCHK(c, hipMemcpy(c->dev.arena, arena.data(), bytes, hipMemcpyHostToDevice));
+        for (uint32_t r = 1; r < list_replicas; ++r)
+            HIPCHK(c, hipMemcpy((char*)c->dev.arena + bytes * r, c->dev.arena, bytes, hipMemcpyDeviceToDevice));
+        c->arena_words = arena.size() * list_replicas;
+    }
     uint32_t* d_lp = nullptr;
     if ((rc = dev_upload(c, &d_lp, list_payload))) return rc;
     if ((rc = dev_upload(c, &c->d_synth_strain_idx, c->synth_strain_idx))) return rc;
-    // expected distinct k-mers ~ species * positions * (1 + S * P(window mutated)); size the table from that
+    // expected distinct k-mers ~ windows * (1 + owners * P(window mutated)); size the table from that
     const double pm = 1.0 - std::pow(0.99, k);
-    const uint64_t est = (uint64_t)((double)NS * (double)(G - k + 1) * (1.0 + S * pm));
+    const double npos = (double)(G - k + 1), nblk = geo.blk ? (double)(geo.blk - k + 1) : 0.0;
+    const uint64_t est = (uint64_t)((double)NS * (npos - nblk) * (1.0 + S * pm) + (double)NG * nblk * (1.0 + GB * pm));
     if ((rc = alloc_table(c, est, table_bytes, k))) return rc;
     c->dev.k = k;
     uint32_t* d_fail = nullptr;
     unsigned long long* d_ins = nullptr;
     HIPCHK(c, hipMalloc((void**)&d_fail, 4));
-    HIPCHK(c, hipMalloc((void**)&d_ins, 16));
+    HIPCHK(c, hipMalloc((void**)&d_ins, 32));
     HIPCHK(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(d_ins, 0, 16, c->stream));
-    launch_synth_db(c->dev, seed, NS, S, G, k, c->d_synth_strain_idx, d_lp, d_fail, d_ins, c->stream);
+    HIPCHK(c, hipMemsetAsync(d_ins, 0, 32, c->stream));
+    launch_synth_db(c->dev, geo, k, c->d_synth_strain_idx, d_lp, g_off, list_replicas, (uint32_t)block_units, d_fail, d_ins, c->stream);
     launch_table_count(c->dev, d_ins + 1, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint32_t fail = 0;
-    unsigned long long ins[2] = {0, 0};
+    unsigned long long ins[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(ins, d_ins, 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ins, d_ins, 32, hipMemcpyDeviceToHost));
     hipFree(d_fail); hipFree(d_ins); hipFree(d_lp);
     if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during synthetic build");
+    if (c->dev.cpt.nb && (rc = check_overflow_fill(c, ins[2]))) return rc;
     c->n_kmers = ins[1];
     c->synth_genome_len = G;
     c->synth_seed = seed;
+    c->synth_geo = geo;
+    c->n_lists = block_units ? (uint64_t)list_payload.size() : 0;
     c->db_ready = true;
     return LMAT_OK;
 }
@@ -699,8 +800,7 @@ int lmat_reads_synth(lmat_ctx* c, uint64_t n, const uint32_t* lengths, uint32_t 
     uint32_t* d_len = nullptr;
     HIPCHK(c, hipMalloc((void**)&d_len, n_lengths * 4));
     HIPCHK(c, hipMemcpyAsync(d_len, lengths, n_lengths * 4, hipMemcpyHostToDevice, c->stream));
-    launch_synth_reads((*out)->words, (*out)->rec_off, d_len, n_lengths, n, seed, c->synth_seed, c->synth_n_species,
-                       c->synth_strains_per_species, c->synth_genome_len, c->stream);
+    launch_synth_reads((*out)->words, (*out)->rec_off, d_len, n_lengths, n, seed, c->synth_geo, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(d_len);
     return LMAT_OK;
@@ -776,8 +876,10 @@ static int ensure_scratch(lmat_ctx* c, uint64_t count) {
         HIPCHK(c, hipMalloc((void**)&c->d_k4bail, count * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_ovf, count * sizeof(uint32_t)));
         if (c->d_ovf2) hipFree(c->d_ovf2);
-        c->d_ovf2 = nullptr;
+        if (c->d_ovf3) hipFree(c->d_ovf3);
+        c->d_ovf2 = c->d_ovf3 = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_ovf2, count * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_ovf3, count * sizeof(uint32_t)));
         c->ovf_cap = count;
     }
     return LMAT_OK;
@@ -910,6 +1012,20 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipEventRecord(e2, c->stream));
     }
+    {   // reads the fast classes could not hold (length, taxids, list elements), listed on the device: first the fast
+        // kernel with room for 512 list elements -- reads over k-mers shared by many strains --, whose own leftovers go on
+        ClassifyArgs m = a;
+        m.index = c->d_ovf;
+        m.count_ptr = c->d_cursor + 2;
+        m.count = 0;
+        m.ovf_list = c->d_ovf2;
+        m.ovf_slot = 3;
+        m.p_max = 160;   // two launches over the one list: reads of up to 160 k-mers in the leaner variant, the rest in the 512 one
+        launch_classify(m, 160 + (uint32_t)c->dev.k - 1, 2, c->stream);
+        m.p_min = 161;
+        m.p_max = 0xFFFFFFFFu;
+        launch_classify(m, 512 + (uint32_t)c->dev.k - 1, 2, c->stream);
+    }
     if (a.prm.stop_after == 0) {  // score + LCA decision, one lane per read
         if (!c->stream2) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -918,20 +1034,21 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         }
         launch_k4(a, c->stream, c->stream2, c->ev_fork, c->ev_join);
     }
-    {   // reads that exceeded the fast class (length, taxids, list elements), listed on the device: the large LDS class,
-        // or directly the global-memory class when the batch holds reads beyond 2067 bp
+    {   // ... to the large LDS class (1024 taxids, reads up to 2067 bp), or directly to the global-memory class when the
+        // batch holds reads beyond that
+        const bool lds_class = reads->max_len <= 2048 + 19;
         ClassifyArgs b = a;
-        b.index = c->d_ovf;
-        b.count_ptr = c->d_cursor + 2;
-        b.ovf_list = reads->max_len <= 2048 + 19 ? c->d_ovf2 : nullptr;  // the global-memory class is the last resort
-        b.ovf_slot = 3;
+        b.index = c->d_ovf2;
+        b.count_ptr = c->d_cursor + 3;
+        b.ovf_list = lds_class ? c->d_ovf3 : nullptr;  // the global-memory class is the last resort
+        b.ovf_slot = 7;
         b.count = 0;
         b.gscratch = c->d_gscratch;
         launch_classify(b, reads->max_len, 1, c->stream);
-        if (reads->max_len <= 2048 + 19) {  // what even that class cannot hold goes to the global-memory class
+        if (lds_class) {  // what even that class cannot hold goes to the global-memory class
             ClassifyArgs g = b;
-            g.index = c->d_ovf2;
-            g.count_ptr = c->d_cursor + 3;
+            g.index = c->d_ovf3;
+            g.count_ptr = c->d_cursor + 7;
             g.ovf_list = nullptr;
             launch_classify(g, 2048 + 20, 1, c->stream);
         }

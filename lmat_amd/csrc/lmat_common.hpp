@@ -13,20 +13,22 @@ namespace lmat {
 // ---- device hash of the k-mer database -------------------------------------------------
 // slot (u64) = canonical k-mer (40 bits for k<=20) << 24 | payload (24 bits); 0 = empty.
 // payload 1..65535          : plain singleton, value = internal taxid index
-// payload 65536 + o         : taxid-list record at arena[2*o] (arena in u16 units)
+// payload 65536 + o         : taxid-list record at arena[kListUnit*o] (arena in u16 units)
 // bucket = 8 slots = 64 B = one HBM sector read by 4 lanes (16 B each); slots fill front to back; linear probing over buckets.
 static const int kPayloadBits = 24;
 static const uint32_t kPayloadMask = (1u << kPayloadBits) - 1;
 static const uint32_t kListBase = 65536;
 static const int kSlotsPerBucket = 8;
 
-// list record in the arena (u16 units, record starts 4-byte aligned):
+// list record in the arena (u16 units; a record starts on a 16-byte boundary and payload 65536 + o is the record at
+// arena[kListUnit * o], so 2^24 payloads address 256 MB of records and a record's first 16 bytes are one aligned load):
 //   [0] flags  bit0: raw count >= 32768 (label_vec.first goes negative, read_label.cpp:49,1045)
 //   [1] n_kept [2] n_raw
 //   [3 .. 3+n_kept)            kept ids, registration order (depth-sorted leaf-most set)
 //   [3+n_kept .. 3+2*n_kept)   kept ids ascending by 32-bit taxid
 //   [3+2*n_kept .. +n_raw)     raw list as stored in the DB (16-bit DB ids), for lookups
 static const int kListHdr = 3;
+static const int kListUnit = 8;   // u16 units per payload step
 static const uint16_t kListNegFirst = 1;
 
 // per-taxid flags (internal index space)
@@ -74,7 +76,7 @@ static const uint32_t kCptOvfFlag = 0x80000000u;
 static const uint32_t kCptCountMask = 0x00FFFFFFu;
 
 struct CptGeom {
-    uint32_t nb = 0;       // buckets; 0 = the table is in the wide layout
+    uint64_t nb = 0;       // buckets (up to 2^32: bucket indices are 32 bits wide); 0 = the table is in the wide layout
     uint32_t W = 0;        // bucket width in hi-space
     double invW = 0;       // 1.0 / W
     int k = 0, m = 0, lowbits = 0;
@@ -124,8 +126,7 @@ LM_HD CptGeom cpt_geometry(int k, uint64_t want_buckets) {
     if (W < 1) W = 1;
     if (W > wmax) W = wmax;
     const uint64_t nb = (space + W - 1) / W;
-    if (nb > 0xFFFFFFFFull) return g;
-    g.nb = (uint32_t)nb; g.W = (uint32_t)W; g.invW = 1.0 / (double)W; g.k = k; g.m = m; g.lowbits = lowbits;
+    g.nb = nb; g.W = (uint32_t)W; g.invW = 1.0 / (double)W; g.k = k; g.m = m; g.lowbits = lowbits;
     return g;
 }
 

@@ -70,6 +70,12 @@ struct NullModelDev {
     int n_len = 0, n_tables = 0, nb_max = 0, n_cls = 0, active = 0;
 };
 
+// geometry of the synthetic genomes
+struct SynthGeo {
+    uint64_t seed = 0, G = 0, blk = 0;   // genome length; the first blk bases are shared by the species of a genus
+    uint32_t n_species = 0, S = 0, spg = 1;  // strains per species, species per genus
+};
+
 struct KernelParams {
     float sdiff, hbias, min_score;
     int min_kmer, min_fnd_kmer, prn_all, screen_phix;
@@ -133,6 +139,8 @@ struct lmat_ctx {
     uint32_t synth_branching[6] = {0, 0, 0, 0, 0, 0};
     uint32_t synth_n_species = 0, synth_strains_per_species = 0;
     uint64_t synth_genome_len = 0, synth_seed = 0;
+    lmat::SynthGeo synth_geo;
+    uint64_t n_lists = 0;
     std::vector<uint16_t> synth_strain_idx;   // [species*S + s] internal index
     std::vector<uint16_t> synth_species_idx;  // [species]
     uint16_t* d_synth_strain_idx = nullptr;
@@ -144,7 +152,8 @@ struct lmat_ctx {
     uint32_t* d_cursor = nullptr;  // [0] cand cursor, [1] error flags, [2] overflow-list length
     uint32_t* d_ovf = nullptr;     // reads to re-run with the large-capacity kernel
     uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to the K4 kernels
-    uint32_t* d_ovf2 = nullptr;    // second overflow list: reads beyond the large LDS class
+    uint32_t* d_ovf2 = nullptr;    // second overflow list: reads beyond the E=512 class
+    uint32_t* d_ovf3 = nullptr;    // third: reads beyond the large LDS class
     unsigned char* d_gscratch = nullptr;  // tables of the global-memory class, allocated on first use
     uint32_t* d_k4small = nullptr; // index lists of the reads awaiting K4 (k4_compact_kernel)
     uint32_t* d_k4large = nullptr;

@@ -260,8 +260,8 @@ def test_full_size_sample_parity(tmp_path, gb, n_reads, lens):
     orc.set_options()
     blob, off = reads.ascii(0, ns)
     kms = np.unique(np.concatenate([orc.extract(bytes(blob[int(off[i]):int(off[i + 1])]), 20)[0] for i in range(ns)]))
-    cnts, tids = eng.lookup(kms, stride=8)
-    assert (cnts > 0).mean() > 0.5 and cnts.max() <= 4
+    cnts, tids = eng.lookup(kms, stride=32)
+    assert (cnts > 0).mean() > 0.5 and 4 < cnts.max() <= 17  # strains + species + genus of a genus-block k-mer
     orc.add_lists32(kms, cnts, tids)
     want, _, _ = orc.classify(np.append(blob, np.uint8(0)), off, 20)
     got = eng.format_out(res[:ns], cands, (np.append(blob, np.uint8(0)), off))
