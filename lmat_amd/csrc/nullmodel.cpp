@@ -86,42 +86,49 @@ int load_null_models(lmat_ctx* c, const char* list_fn) {
             nbins.push_back(nb);
             len_to_table.push_back(std::make_pair(read_len, t));
         } else if (nbins[t] != nb) { gzclose(gz); return set_err(c, LMAT_E_IO, "null models of one class disagree on the number of bins"); }
-        std::vector<float> save_ecoli(nb, 0.5f);
+        // One row per taxid: `<taxid> <class>-<...>` then, per GC bin, (reads observed, largest score seen, k-mers of the
+        // genome).  The row's value per bin (loadRandHits, src/read_label.cpp:585-665):
+        //   observed            -> the largest score seen
+        //   unobserved, k-mers >= 100000 -> 0.5
+        //   unobserved, smaller genome   -> a "hole": the larger positive value among the two bins at the smallest
+        //                                   distance that has one, 0.5 when the whole row is empty; holes are filled left
+        //                                   to right and a filled hole serves the next ones
+        //   taxid 28384 (the synthetic-construct bin) -> the row E. coli (562) has so far, class "genus"; its own holes are
+        //                                   then filled over that copy
+        std::vector<float> ecoli_row(nb, 0.5f);  // bins of taxid 562 seen so far in this file
         while (gz_getline(gz, line)) {
             std::istringstream is(line);
             uint32_t taxid = 0;
-            float max_val = 0;
-            std::string class_str;
-            is >> taxid >> class_str;
-            const size_t pos = class_str.find("-");
-            if (pos == std::string::npos) { gzclose(gz); return set_err(c, LMAT_E_IO, "null-model class without '-': " + class_str); }
-            std::string val = class_str.substr(0, pos);
-            if (val.size() >= 3 && val[0] == 'n' && val[1] == 'o' && val[2] == '_') val = "genus";
-            std::list<unsigned> revisit;
-            std::vector<float> cutoff(nb, 0);
+            std::string label;
+            is >> taxid >> label;
+            const size_t dash = label.find("-");
+            if (dash == std::string::npos) { gzclose(gz); return set_err(c, LMAT_E_IO, "null-model class without '-': " + label); }
+            std::string val = label.substr(0, dash);
+            if (val.compare(0, 3, "no_") == 0) val = "genus";
+            std::vector<float> cutoff(nb, 0.0f);
+            std::vector<int> holes;
+            float seen_max = 0;  // a field that fails to parse keeps the previous bin's value, as operator>> leaves it
             for (int bin = 0; bin < nb; ++bin) {
-                int num_obs = 0, kmer_cnt = 0;
-                is >> num_obs >> max_val >> kmer_cnt;
-                if (num_obs == 0 && kmer_cnt >= 100000) { max_val = 0.5; cutoff[bin] = max_val; }
-                else if (num_obs == 0 && kmer_cnt < 100000) revisit.push_back(bin);
-                if (num_obs > 0) { cutoff[bin] = max_val; if (taxid == 562) save_ecoli[bin] = cutoff[bin]; }
-                if (taxid == 28384) { val = "genus"; cutoff = save_ecoli; }
-            }
-            for (unsigned b : revisit) {
-                int j = (int)b - 1;
-                unsigned i = b + 1;
-                while (j >= 0 || i < cutoff.size()) {
-                    float a_val = 0.0, b_val = 0.0;
-                    if (j >= 0) a_val = cutoff[j];
-                    if (i < cutoff.size()) b_val = cutoff[i];
-                    if (a_val > 0 && b_val > 0) cutoff[b] = std::max(a_val, b_val);
-                    else if (a_val > 0) cutoff[b] = a_val;
-                    else if (b_val > 0) cutoff[b] = b_val;
-                    if (cutoff[b] > 0) break;
-                    --j;
-                    ++i;
+                int observed = 0, genome_kmers = 0;
+                is >> observed >> seen_max >> genome_kmers;
+                if (observed > 0) {
+                    cutoff[bin] = seen_max;
+                    if (taxid == 562) ecoli_row[bin] = seen_max;
+                } else if (genome_kmers >= 100000) {
+                    seen_max = 0.5f;
+                    cutoff[bin] = 0.5f;
+                } else {
+                    holes.push_back(bin);
                 }
-                if (cutoff[b] <= 0) cutoff[b] = 0.5;
+            }
+            if (taxid == 28384) { val = "genus"; cutoff = ecoli_row; }
+            for (int h : holes) {
+                for (int dist = 1; h - dist >= 0 || h + dist < nb; ++dist) {
+                    const float left = h - dist >= 0 ? cutoff[h - dist] : 0.0f, right = h + dist < nb ? cutoff[h + dist] : 0.0f;
+                    if (left > 0 || right > 0) cutoff[h] = std::max(left, right);
+                    if (cutoff[h] > 0) break;
+                }
+                if (cutoff[h] <= 0) cutoff[h] = 0.5f;
             }
             auto it = c->tax.index_of.find(taxid);
             if (it == c->tax.index_of.end()) continue;  // taxid the database cannot produce
