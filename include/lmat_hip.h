@@ -134,6 +134,17 @@ int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed
 int lmat_synth_db_build2(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes,
                          uint32_t genus_block_permille, uint32_t list_replicas);
 
+/* ---- gene databases (src/gene_label.cpp) ---------------------------------------------------
+ * gene_label runs the same lookup against a database whose lists are 32-bit GENE ids (INDEXDB<uint32_t>, TaxNodeStat
+ * <uint32_t>, gene_label.cpp:15-22,218-267) and has no taxonomy step.  A context opened with lmat_genedb_begin (instead of a
+ * taxonomy + lmat_db_begin) ingests such a database -- same tax_histo record format, ids stored as read --; then
+ * lmat_db_add_taxhisto / lmat_db_finalize / lmat_db_lookup work as usual, and every classification entry point (lmat_classify,
+ * lmat_stream_*) returns gene_label's vote instead of the taxonomic call (proc_line, gene_label.cpp:269-313):
+ *   status LMAT_ST_CALL: call_tid = the gene std::sort(Cmp) puts first, n_cand = its vote count, cand_kmer_cnt = distinct
+ *   valid k-mers of the read, call_score = n_cand / cand_kmer_cnt;  LMAT_ST_NODBHITS / LMAT_ST_SHORT_LEN: no gene (upstream
+ *   prints nothing for such a read). */
+int lmat_genedb_begin(lmat_ctx* ctx, int k, uint64_t n_kmers_hint, uint64_t table_bytes);
+
 /* ---- label modes -------------------------------------------------------------------
  * -s permissive match (gPERMISSIVE_MATCH, read_label.cpp:1050-1058,1075-1102,1143) and run-time pruning of
  * lists longer than tid_cutoff (-g N [-m numeric ranks]; TaxNodeStat::begin, TaxNodeStat.hpp:76-203).  Both are

@@ -55,6 +55,7 @@ def load_library(path: str | None = None):
         "lmat_set_params": (i32, [vp, P(Params)]),
         "lmat_taxonomy_load_files": (i32, [vp, cp, cp, cp, cp, cp]),
         "lmat_db_begin": (i32, [vp, i32, u64, u64]),
+        "lmat_genedb_begin": (i32, [vp, i32, u64, u64]),
         "lmat_db_add_taxhisto": (i32, [vp, cp]),
         "lmat_db_finalize": (i32, [vp]),
         "lmat_db_set_build_options": (i32, [vp, i32, cp, cp, cp, u32]),
@@ -125,7 +126,7 @@ def load_library(path: str | None = None):
 
 
 EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
-            "lmat_db_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
+            "lmat_db_begin", "lmat_genedb_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
             "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create", "lmat_ingest_idmap_from_tree", "lmat_rand_mode", "lmat_rand_reset", "lmat_rand_label", "lmat_rand_get",
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
             "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
@@ -321,6 +322,13 @@ class Engine:
     def load_taxonomy(self, tree, depth, rank, idmap, plasmids=None):
         e = lambda s: s.encode() if s else None
         self._chk(self.lib.lmat_taxonomy_load_files(self.ctx, e(tree), e(depth), e(rank), e(idmap), e(plasmids)))
+
+    def build_gene_db(self, files, k=20, table_bytes=0, n_kmers_hint=0):
+        """A gene database (gene_label): tax_histo-format files whose lists are 32-bit gene ids; no taxonomy needed."""
+        self._chk(self.lib.lmat_genedb_begin(self.ctx, k, n_kmers_hint, table_bytes))
+        for f in ([files] if isinstance(files, str) else files):
+            self._chk(self.lib.lmat_db_add_taxhisto(self.ctx, f.encode()))
+        self._chk(self.lib.lmat_db_finalize(self.ctx))
 
     def build_db(self, files, k=20, table_bytes=0, tid_cutoff=0, rank_map=None, human_kmers=None, adaptor_kmers=None,
                  save_image=None, n_kmers_hint=0):

@@ -174,6 +174,15 @@ bool Ingest::add_taxhisto(const char* fn) {
         tids.resize(tid_count);
         if (tid_count && fread(tids.data(), 4, tid_count, in) != tid_count) { err = "truncated taxid list"; good = false; break; }
         lst.clear();
+        if (raw32) {  // SortedDb<uint32_t>::add_data without a 32->16 map (SortedDb.cpp:503-515,678-690): ids stored as read
+            for (uint16_t j = 0; j < tid_count; ++j) { lst.push_back((uint16_t)tids[j]); lst.push_back((uint16_t)(tids[j] >> 16)); }
+            if (tid_count) push(kmer, lst);
+            if ((i + 1) % 1500 == 0) {
+                if (fread(&test, 8, 1, in) != 1 || test != ~0ull) { err = "tax_histo sanity word missing"; good = false; break; }
+            }
+            last_kmer = kmer;
+            continue;
+        }
         if (adaptor_loaded && adaptor_set.count(kmer)) {  // SortedDb.cpp:275-292
             lst.push_back(adaptor_store);
         } else {

@@ -25,6 +25,7 @@ bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string&
 
 struct Ingest {
     int k = 0;
+    bool raw32 = false;  // gene databases (gene_label): 32-bit ids stored as they come, two u16 (low, high) per id, no options
     std::unordered_map<uint32_t, uint16_t> br;  // 32 -> 16
     // options
     int tid_cutoff = 0;

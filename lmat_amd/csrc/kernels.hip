@@ -408,6 +408,13 @@ __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmer
         return;
     }
     const uint32_t eoff = kListUnit * (pay - kListBase);
+    if (tb.arena[eoff] & 0x8000u) {  // gene database: [0x8000][n][0][id lo, id hi]...
+        const uint32_t n = tb.arena[eoff + 1];
+        counts[i] = n;
+        for (uint32_t j = 0; j < n && j < stride; ++j)
+            tids[i * stride + j] = (uint32_t)tb.arena[eoff + kListHdr + 2 * j] | ((uint32_t)tb.arena[eoff + kListHdr + 2 * j + 1] << 16);
+        return;
+    }
     const uint32_t nk = tb.arena[eoff + 1], nr = tb.arena[eoff + 2];
     counts[i] = nr;
     for (uint32_t j = 0; j < nr && j < stride; ++j) tids[i * stride + j] = tb.conv[tb.arena[eoff + kListHdr + 2 * nk + j]];
@@ -447,7 +454,7 @@ struct WL {
     static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T + 4 * T + 4 * T + T : 0);
     static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
     static constexpr int R2_K = CPT ? 0 : 8 * U + 4 * U;               // ukmer, ubucket (wide layout only)
-    static constexpr int R2_D = 4 * D + 2 * D + 2 * D + 2 * D + D;     // dpay, dmult, dn, dstart, dfl
+    static constexpr int R2_D = 4 * D + 2 * D + 2 * D + 2 * D + D + 2 * T + 2;  // dpay, dmult, dn, dstart, dfl (+ gene mode: sort order of the registered genes)
     static constexpr int R2_L = INK4 ? 12 * LIN : 0;                   // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
@@ -1463,6 +1470,104 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         return;
     }
     RELANE();
+    if (A.gene_mode) {
+        // ---- gene_label (src/gene_label.cpp:218-267, 288-313): the database maps a k-mer to a list of 32-bit gene ids;
+        //      every distinct k-mer of the read votes for each gene of its list, genes are registered in first-seen order
+        //      (k-mers in position order, then list order), and the call is the gene std::sort(Cmp: count descending) puts
+        //      first, scored count / distinct valid k-mers.  List records here are [0x8000][n][0][id lo, id hi]...
+        uint32_t* gkey = (uint32_t*)hent;     // gene id + 1 per hash slot (0 = empty)
+        uint32_t* gval = (uint32_t*)best;     // registration slot of that gene; 0x80000000 | lane while a chunk decides; 0xFFFFFFFF = none yet
+        uint32_t* greg = (uint32_t*)reg;      // [T] gene id per slot (reg + stamp)
+        uint32_t* gcnt = (uint32_t*)cnt;      // [T] votes per slot (cnt + leaf)
+        uint32_t* el_gid = el_poff;           // [E]
+        uint16_t* gord = (uint16_t*)(lds + L::OFF_R2 + ((11 * L::D + 1) & ~1));  // [T] sort order, behind the d-arrays
+        const GAS uint16_t* arena = g_arena;
+        uint32_t nel = 0;
+        bool overflow = false;
+        for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
+            const uint32_t d = d0 + lane;
+            uint32_t n = 0;
+            if (d < ndist) n = arena[(size_t)kListUnit * (dpay[d] - kListBase) + 1];
+            uint32_t incl = n;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const uint32_t s0 = nel + incl - n;
+            if (d < ndist) {
+                dstart[d] = (uint16_t)s0;
+                if (s0 + n <= (uint32_t)E)
+                    for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (uint16_t)d;
+            }
+            nel += __shfl(incl, 63);
+        }
+        if (nel > (uint32_t)E) overflow = true;
+        for (int i = lane; i < L::TH; i += 64) { gkey[i] = 0; gval[i] = 0xFFFFFFFFu; }
+        WSYNC();
+        uint32_t nT = 0;
+        for (uint32_t e0 = 0; e0 < nel && !overflow; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool act = e < nel;
+            uint32_t gid = 0, h = 0, m = 0;
+            if (act) {
+                const uint32_t d = el_d[e];
+                const size_t at = (size_t)kListUnit * (dpay[d] - kListBase) + kListHdr + 2 * (e - dstart[d]);
+                gid = (uint32_t)arena[at] | ((uint32_t)arena[at + 1] << 16);
+                m = dmult[d];
+                const uint32_t key = gid + 1u;
+                h = ((key * 0x9E3779B1u) >> 12) & THM;
+                while (true) {
+                    const uint32_t cur = gkey[h];
+                    if (cur == key) break;
+                    if (cur == 0) {
+                        const uint32_t prev = atomicCAS(&gkey[h], 0u, key);
+                        if (prev == 0 || prev == key) break;
+                    }
+                    h = (h + 1) & THM;
+                }
+                if (gval[h] >= 0x80000000u) atomicMin(&gval[h], 0x80000000u | (uint32_t)lane);
+            }
+            WSYNC();
+            const bool isnew = act && gval[h] == (0x80000000u | (uint32_t)lane);
+            const uint64_t nm_ = __ballot(isnew);
+            const uint32_t newcnt = popc64(nm_);
+            if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
+            if (isnew) {
+                const uint32_t sl = nT + popc64(nm_ & lt_mask(lane));
+                gval[h] = sl;
+                greg[sl] = gid;
+                gcnt[sl] = 0;
+            }
+            nT += newcnt;
+            WSYNC();
+            if (act) atomicAdd(&gcnt[gval[h]], m);
+            WSYNC();
+        }
+        if (overflow) {
+            if (lane == 0) {
+                emit(255, 0);
+                if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;
+                else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+            }
+            return;
+        }
+        if (lane == 0) {
+            for (uint32_t i = 0; i < nT; ++i) gord[i] = (uint16_t)i;
+            struct VoteCmp {  // Cmp, gene_label.cpp:102-106
+                const uint32_t* c;
+                __device__ bool operator()(uint16_t a, uint16_t b) const { return c[a] > c[b]; }
+            };
+            ss_sort(gord, (int)nT, VoteCmp{gcnt});
+            lmat_read_result q;
+            q.status = LMAT_ST_CALL; q.match_type = LMAT_MT_DIRECT; q.cand_kmer_cnt = (uint16_t)nuniq;
+            q.valid_kmers = valid_kmers; q.read_len = (int)len; q.log_avg = 0; q.stdev = 0;
+            q.call_tid = greg[gord[0]];
+            q.call_score = (float)gcnt[gord[0]] / (float)nuniq;
+            q.cand_off = 0; q.n_cand = gcnt[gord[0]]; q.bin_sel = 0;
+            store_result(out, q);
+        }
+        return;
+    }
     // ---- K3b stage 1: the first 16 bytes of every distinct payload's list record in one round of loads: header
     //      and, for lists that keep at most two ids (most do), both id orders.  Singletons are their own element.
     //      Each round trip to memory costs this kernel ~2 us whatever it carries, so the header and the ids come

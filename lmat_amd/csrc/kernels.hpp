@@ -35,6 +35,7 @@ struct ClassifyArgs {
     uint32_t rand_nb;
     unsigned char* gscratch;   // per-workgroup tables of the global-memory class (reads beyond the LDS classes), or null
     NullModelDev nm;           // -n null models (active == 0: scores are plain k-mer fractions)
+    uint32_t gene_mode = 0;    // the database holds 32-bit gene-id lists: gene_label's vote instead of the taxonomic call
 };
 
 // record handed to the K4 kernels: word0 = nT | cand << 16, word1 reserved, then K4T words reg | cnt << 16

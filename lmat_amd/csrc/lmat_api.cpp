@@ -189,9 +189,24 @@ int lmat_ingest_lookup(const lmat_ingest* g, uint64_t kmer, uint16_t* tids16, in
     return (int)l.size();
 }
 
+int lmat_genedb_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_bytes) {
+    if (!c) return LMAT_E_ARG;
+    if (c->db_ready || c->ingest) return set_err(c, LMAT_E_ARG, "a context holds one database: use a fresh context for a gene database");
+    c->gene_mode = 1;
+    if (!c->d_counts) {  // no taxonomy in this mode: the kernels still expect a (minimal) tally buffer
+        c->dev.n_ids = 1;
+        c->counts_bytes = 16 + 24;
+        HIPCHK(c, hipMalloc(&c->d_counts, c->counts_bytes));
+        HIPCHK(c, hipMemset(c->d_counts, 0, c->counts_bytes));
+    }
+    const int rc = lmat_db_begin(c, k, n_kmers_hint, table_bytes);
+    if (rc == LMAT_OK) c->ingest->raw32 = true;
+    return rc;
+}
+
 int lmat_db_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_bytes) {
     if (!c) return LMAT_E_ARG;
-    if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
+    if (!c->tax.loaded && !c->gene_mode) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
     if (k < 1 || k > 20) return set_err(c, LMAT_E_ARG, "k must be in 1..20 (40-bit keys)");
     delete c->ingest;
     c->ingest = new Ingest();
@@ -391,10 +406,19 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
             if (p >= kListBase) {
                 uint32_t& lp = S.list_pay[p - kListBase];
                 if (!lp) {
-                    if (!build_list_record(c, B.lists[p - kListBase], rec)) return LMAT_E_TAXONOMY;
+                    if (c->gene_mode) {  // [0x8000][n][0][id low, id high]...: the ids as stored, nothing derived from a taxonomy
+                        const std::vector<uint16_t>& l = B.lists[p - kListBase];
+                        if (l.size() / 2 > 0xFFFF) return set_err(c, LMAT_E_CAPACITY, "gene list above 65535 ids");
+                        rec.assign(kListHdr, 0);
+                        rec[0] = 0x8000;
+                        rec[1] = (uint16_t)(l.size() / 2);
+                        rec.insert(rec.end(), l.begin(), l.end());
+                    } else if (!build_list_record(c, B.lists[p - kListBase], rec)) return LMAT_E_TAXONOMY;
                     lp = arena_append(S.arena, rec);
                 }
                 dp = lp;
+            } else if (c->gene_mode) {
+                return set_err(c, LMAT_E_IO, "gene database record without a list");
             } else {
                 uint32_t& sp = S.single_pay[p];
                 if (!sp) {
@@ -919,6 +943,8 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.k4_bail = c->d_k4bail;
     a.k4_slot = 5;
     a.nm = c->nm;
+    a.gene_mode = (uint32_t)c->gene_mode;
+    if (c->gene_mode) a.prm.min_kmer = 0;  // gene_label looks every read of >= k bases up (gene_label.cpp:276-288)
     return a;
 }
 

@@ -129,6 +129,7 @@ struct lmat_ctx {
     std::unordered_map<uint32_t, uint32_t> rt_rank_map;  // -m: taxid -> numeric rank (read_label.cpp:1547-1553)
     int permissive = 0;                                  // -s (gPERMISSIVE_MATCH)
     int rand_mode = 0;                                   // list records as src/rkmer.hpp builds them (no human folding)
+    int gene_mode = 0;                                   // gene database (gene_label): lists of 32-bit gene ids, no taxonomy involved
     uint32_t* d_rand_max = nullptr;                      // rand_read_label tables [n_ids][rand_nb]
     uint32_t* d_rand_cnt = nullptr;
     uint8_t* d_rand_gc = nullptr;

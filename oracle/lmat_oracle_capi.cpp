@@ -3,6 +3,7 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker.
 #include <thread>
 #include "lmat_oracle.hpp"
+#include "gene_oracle.hpp"
 
 using namespace orc;
 
@@ -295,6 +296,32 @@ long orc_run_file(orc_ctx* c, const char* query, int k_size, const char* rank_id
     if (fastsummary) snprintf(fastsummary, fs_cap, "%s", ro.fastsummary.c_str());
     if (nomatchsum) snprintf(nomatchsum, nm_cap, "%s", ro.nomatchsum.c_str());
     return (long)c->text.size();
+}
+
+// ---- gene_label (gene_oracle.hpp) -----------------------------------------------------------------------------
+void* orc_gene_create() { return new gene_oracle::GeneDb(); }
+void orc_gene_destroy(void* g) { delete (gene_oracle::GeneDb*)g; }
+int orc_gene_add(void* g, const char* fn) { std::string e; return ((gene_oracle::GeneDb*)g)->add_taxhisto(fn, &e) ? 0 : -1; }
+int orc_gene_k(void* g) { return ((gene_oracle::GeneDb*)g)->k; }
+uint64_t orc_gene_size(void* g) { return ((gene_oracle::GeneDb*)g)->table.size(); }
+int orc_gene_lookup(void* g, uint64_t kmer, uint32_t* out, int cap) {
+    auto& t = ((gene_oracle::GeneDb*)g)->table;
+    auto it = t.find(kmer);
+    if (it == t.end()) return 0;
+    for (int i = 0; i < (int)it->second.size() && i < cap; ++i) out[i] = it->second[i];
+    return (int)it->second.size();
+}
+// per read: any (0/1), gene id, top votes, distinct valid k-mers, score
+void orc_gene_label(void* g, const char* blob, const uint64_t* off, long n, int k, uint8_t* any, uint32_t* gid, uint32_t* top,
+                    uint32_t* cnt, float* score) {
+    for (long i = 0; i < n; ++i) {
+        const gene_oracle::GeneCall c = gene_oracle::label_read(*(gene_oracle::GeneDb*)g, blob + off[i], (int)(off[i + 1] - off[i]), k);
+        any[i] = c.any; gid[i] = c.gid; top[i] = c.top; cnt[i] = c.cnt; score[i] = c.score;
+    }
+}
+int orc_gene_run(void* g, const char* list_fn, const char* ofbase, const char* genefile, float min_score, int min_kmer, float min_tax_score) {
+    std::string e;
+    return gene_oracle::run_files(*(gene_oracle::GeneDb*)g, list_fn, ofbase, genefile, min_score, min_kmer, min_tax_score, &e) ? 0 : -1;
 }
 
 }  // extern "C"

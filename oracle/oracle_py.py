@@ -59,9 +59,60 @@ def _load():
     L.orc_rand_label.restype = i32
     L.orc_rand_label.argtypes = [vp, vp, vp, u64, i32, vp, C.c_uint32, vp, vp, vp, C.c_uint32]
     L.orc_run_file.restype = C.c_long
+    L.orc_gene_create.restype = vp
+    L.orc_gene_destroy.argtypes = [vp]
+    L.orc_gene_add.argtypes = [vp, cp]
+    L.orc_gene_k.argtypes = [vp]
+    L.orc_gene_size.argtypes = [vp]
+    L.orc_gene_size.restype = u64
+    L.orc_gene_lookup.argtypes = [vp, u64, vp, i32]
+    L.orc_gene_label.argtypes = [vp, vp, vp, C.c_long, i32, vp, vp, vp, vp, vp]
+    L.orc_gene_run.argtypes = [vp, cp, cp, cp, C.c_float, i32, C.c_float]
     L.orc_replay_decision.argtypes = [vp, vp, vp, i32, C.c_float, vp, vp, vp]
     L.orc_run_file.argtypes = [vp, cp, i32, cp, vp, C.c_long, vp, C.c_long]
     return L
+
+
+class GeneOracle:
+    """gene_oracle.hpp: the CPU restatement of src/gene_label.cpp (test infrastructure)."""
+
+    def __init__(self, files):
+        self.L = _load()
+        self.h = self.L.orc_gene_create()
+        for f in ([files] if isinstance(files, str) else files):
+            if self.L.orc_gene_add(self.h, f.encode()) != 0:
+                raise RuntimeError("gene oracle: cannot read " + f)
+
+    @property
+    def k(self):
+        return self.L.orc_gene_k(self.h)
+
+    def __len__(self):
+        return int(self.L.orc_gene_size(self.h))
+
+    def lookup(self, kmer, cap=4096):
+        out = np.zeros(cap, dtype=np.uint32)
+        n = self.L.orc_gene_lookup(self.h, int(kmer), out.ctypes.data_as(C.c_void_p), cap)
+        return out[:n].tolist()
+
+    def label(self, blob, off, k):
+        """-> structured array (any, gid, top, cnt, score) per read."""
+        n = off.size - 1
+        any_ = np.zeros(n, dtype=np.uint8)
+        gid, top, cnt = (np.zeros(n, dtype=np.uint32) for _ in range(3))
+        score = np.zeros(n, dtype=np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.L.orc_gene_label(self.h, p(blob), p(off), n, k, p(any_), p(gid), p(top), p(cnt), p(score))
+        return any_, gid, top, cnt, score
+
+    def run(self, list_fn, ofbase, genefile, min_score=0.0, min_kmer=0, min_tax_score=0.0):
+        if self.L.orc_gene_run(self.h, list_fn.encode(), ofbase.encode(), genefile.encode(), min_score, min_kmer, min_tax_score) != 0:
+            raise RuntimeError("gene oracle: run failed")
+
+    def close(self):
+        if self.h:
+            self.L.orc_gene_destroy(self.h)
+            self.h = None
 
 
 class Oracle:

@@ -1,0 +1,110 @@
+"""gene_label (src/gene_label.cpp): the same k-mer lookup against a database of 32-bit gene-id lists, a
+per-read vote instead of the taxonomic call.  CPU: the oracle's database against the REFERENCE's TID_SIZE=32 build
+(tests/golden/gene/ref_lookup_gene.txt).  GPU: the engine's gene database against the same golden, its per-read votes and
+the gene_label-compatible tool against the oracle."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GD = os.path.join(ROOT, "tests", "golden", "gene")
+EXE = os.path.join(ROOT, "lmat_amd", "csrc", "gene_label")
+
+
+def _golden():
+    kms, want = [], []
+    for line in open(os.path.join(GD, "ref_lookup_gene.txt")):
+        f = line.split()
+        kms.append(int(f[0]))
+        want.append([int(x) for x in f[2:]])
+        assert int(f[1]) == len(want[-1])
+    return np.array(kms, dtype=np.uint64), want
+
+
+def _reads():
+    reads = []
+    for fn in ("rl0.out", "rl1.out"):
+        for line in open(os.path.join(GD, fn)):
+            reads.append(line.split("\t")[1])
+    return reads
+
+
+def test_gene_oracle_database_matches_reference_build():
+    import oracle_py
+    o = oracle_py.GeneOracle(os.path.join(GD, "gene.bin"))
+    kms, want = _golden()
+    assert o.k == 20 and len(o) > 20000
+    assert sum(1 for w in want if len(w) > 1) > 2000 and max(max(w) for w in want if w) > 1 << 31
+    for km, w in zip(kms.tolist(), want):
+        assert o.lookup(km) == w
+    o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_gene_database_matches_reference_build():
+    from lmat_amd import Engine, Params
+    eng = Engine(0, Params.run_rl())
+    eng.build_gene_db(os.path.join(GD, "gene.bin"), k=20)
+    kms, want = _golden()
+    counts, tids = eng.lookup(kms, stride=16)
+    for i, w in enumerate(want):
+        assert counts[i] == len(w), int(kms[i])
+        assert tids[i, :len(w)].tolist() == w
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streamed", [False, True])
+def test_gpu_gene_votes_match_oracle(streamed):
+    import oracle_py
+    from lmat_amd import Engine, Params, Stream
+    reads = _reads()
+    # low-complexity and very long reads exercise the repeat path and the larger classes
+    reads += ["ACGT" * 60, "A" * 100, (reads[3] * 12)[:2500], reads[10] + reads[11] + reads[12]]
+    bs = [r.encode() for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    blob = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
+    o = oracle_py.GeneOracle(os.path.join(GD, "gene.bin"))
+    any_, gid, top, cnt, score = o.label(blob, off, 20)
+    o.close()
+    eng = Engine(0, Params.run_rl(prn_all=0))
+    eng.build_gene_db(os.path.join(GD, "gene.bin"), k=20)
+    if streamed:
+        st = Stream(eng, max_reads=len(reads), max_bases=int(off[-1]) + 16, cands_per_read=0, n_slots=2)
+        st.submit(blob, off, tag=1)
+        res = st.next()[0]
+        st.close()
+    else:
+        res, _ = eng.classify(eng.upload_reads((blob, off)), want_cands=False)
+    eng.close()
+    assert any_.sum() > 600 and (top[any_ == 1] > 1).mean() > 0.9
+    for i in range(len(reads)):
+        if any_[i]:
+            assert res["status"][i] == 0 and res["call_tid"][i] == gid[i] and res["n_cand"][i] == top[i] and res["cand_kmer_cnt"][i] == cnt[i], (i, reads[i][:40])
+            assert res["call_score"][i] == score[i]
+        else:
+            assert res["status"][i] != 0, i
+
+
+@pytest.mark.gpu
+def test_gene_label_tool_matches_oracle(tmp_path):
+    """The gene_label-compatible command line (getopt letters of gene_label.cpp:348-449): -l list of read_label outputs,
+    -d gene database, -g annotation table, -o prefix, -x / -q / -b thresholds; per-file .out and both summaries."""
+    import oracle_py
+    lst = tmp_path / "files.lst"
+    lst.write_text(os.path.join(GD, "rl0.out") + "\n" + os.path.join(GD, "rl1.out") + "\n")
+    o = oracle_py.GeneOracle(os.path.join(GD, "gene.bin"))
+    o.run(str(lst), str(tmp_path / "want"), os.path.join(GD, "genes.tbl.gz"), min_score=0.1, min_kmer=40, min_tax_score=0.6)
+    o.close()
+    r = subprocess.run([EXE, "-d", os.path.join(GD, "gene.bin"), "-l", str(lst), "-g", os.path.join(GD, "genes.tbl.gz"), "-o", str(tmp_path / "got"),
+                        "-x", "0.1", "-q", "40", "-b", "0.6"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    names = ["0.out", "1.out", ".0.1.40.genesummary", ".0.1.40.genesummary.min_tax_score.0.6"]
+    for nme in names:
+        w, g = open(str(tmp_path / "want") + nme).read(), open(str(tmp_path / "got") + nme).read()
+        assert w == g, nme
+    assert len(open(str(tmp_path / "got") + "0.out").read()) > 20000 and len(open(str(tmp_path / "got") + names[2]).read()) > 300
