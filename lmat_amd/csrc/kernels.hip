@@ -432,9 +432,19 @@ struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351), 1
     float score;
 };
 static const uint16_t kLinNoGood = 0x8000;
-static const int kK4SmallT = 16;                     // registered taxids of a "small" read
-static const int kK4SmallLin = kK4SmallT + 3;        // its lineage: the candidates plus at most 3 appended ancestors
-static const int kK4SmallStride = 125;               // dwords per lane (odd): 6 x u16[16], u8[16], f32[16], LinEnt[19]; 5 waves per CU
+// K4 in LDS, three table sizes (registered taxids of a read): per-lane block = 6 x u16[T], u8[T], f32[T], LinEnt[LIN], an
+// odd number of dwords apart (conflict-free).  The lineage holds the candidates plus the appended ancestors: a read whose
+// chain is longer is passed on to the scratch kernel.
+static const int kFastE = 320;                       // kept-list elements a read of the fast classes may have (7 B of LDS each)
+static const int kK4SmallT = 16;                     // 64 lanes x 500 B: 5 waves per CU
+static const int kK4MidT = 32;                       // 64 lanes x 1028 B: 2 waves per CU
+template <int TT> struct K4Lds {
+    static constexpr int LIN = TT + (TT <= 16 ? 3 : 8);
+    static constexpr int LANES = TT <= 32 ? 64 : 32;  // the 64-taxid tier runs half waves: 2 per CU as well
+    static constexpr int STRIDE = ((17 * TT + 12 * LIN + 3) / 4) | 1;  // dwords per lane
+    static constexpr int BYTES = STRIDE * 4 * LANES;
+};
+static_assert(K4Lds<16>::STRIDE == 125, "small tier: 31.25 KB per wave");
 
 // U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in registered
 // taxids, E = capacity in kept-list elements summed over the read's distinct payloads.
@@ -458,7 +468,7 @@ struct WL {
     static constexpr int R2_L = INK4 ? 12 * LIN : 0;                   // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
-    static constexpr int R3_E = (INK4 ? 16 : 20) * E;                  // element staging (+ tin/tout when slots map to lanes)
+    static constexpr int R3_E = (INK4 ? 16 : 7) * E;                   // element staging (slots map to lanes: the per-id facts stay in registers)
     static constexpr int R3 = R3_P > R3_E ? R3_P : R3_E;
     static constexpr int OFF_RD = 0;
     static constexpr int OFF_R1 = ((RD_WORDS * 4 + 15) / 16) * 16;
@@ -691,7 +701,7 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
             if (sflags[s] & kFlagHuman) score[s] += (P.hbias * stdev1);
     }
     for (int s = 0; s < nT; ++s) ord[s] = (uint16_t)s;
-    ss_sort(ord, nT, TCmpDev{score, dep});  // :892-893
+    ss_sort<(LIN <= 152 ? 8 : 34)>(ord, nT, TCmpDev{score, dep});  // :892-893
     S.diff_thresh = stdev1 * P.sdiff;       // :895
     // findReadLabelVer2 :287-325
     S.plasmid_slot = -1;
@@ -728,6 +738,7 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
 }
 
 // K4 part 2 (lane 0): lineage sort, competitor scan, call, candidate list.  read_label.cpp:344-419, 898-937.
+template <int LIN>
 __device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_read_result& res, const K4State& S,
                          const float* score, const uint16_t* tin, const uint16_t* tout, const uint16_t* reg,
                          const uint16_t* ord, LinEnt* lin, int nlin, int nT,
@@ -737,7 +748,7 @@ __device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_
     if (!P.prn_all && cand_out) {  // without -p, MultiMatch prints cand_lin in list order (:917-927)
         for (int j = 0; j < nlin; ++j) { cand_out[j].tid = tid32[lin[j].tid]; cand_out[j].score = lin[j].score; }
     }
-    ss_sort(lin, nlin, CmpDepthDev{});  // :344-351
+    ss_sort<(LIN <= 152 ? 8 : 34)>(lin, nlin, CmpDepthDev{});  // :344-351
     bool any_no_good = false;
     for (int i = S.lidx; i >= 0; --i) {  // :355-362, cmpCompLineage :264-282
         const int s = ord[i];
@@ -854,15 +865,18 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     LinEnt* lin = (LinEnt*)(lds + L::OFF_R2);
     // R3: payload per distinct k-mer, then the staged kept-list elements
     uint32_t* upay = (uint32_t*)(lds + (CPT ? L::OFF_UPAY_C : L::OFF_R3));
+    // large classes (16 B per element): poff u32 | t | ta | d | sp | plen u16 | fl u8.
+    // T <= 64 (7 B per element): t | ta (later: slot of ta) | item offset u16 | d u8 -- the facts of an id live in the
+    // registers of the lane that is its registration slot.
+    using eld_t = typename std::conditional<INK4, uint16_t, uint8_t>::type;
     uint32_t* el_poff = (uint32_t*)(lds + L::OFF_R3);
-    uint16_t* el_t = (uint16_t*)(el_poff + E);   // kept id, registration order
+    uint16_t* el_t = INK4 ? (uint16_t*)(el_poff + E) : (uint16_t*)(lds + L::OFF_R3);   // kept id, registration order
     uint16_t* el_ta = el_t + E;                  // kept id, ascending order (closure order)
-    uint16_t* el_d = el_ta + E;                  // owning distinct-payload index
-    uint16_t* el_sp = el_d + E;                  // species_of[ta]
+    eld_t* el_d = (eld_t*)(el_ta + (INK4 ? E : 2 * E));  // owning distinct-payload index
+    uint16_t* el_off = el_ta + E;                // T <= 64: offset of the id's chain in the item list of the closure
+    uint16_t* el_sp = (uint16_t*)el_d + E;       // large classes: species_of[ta]
     uint16_t* el_plen = el_sp + E;               // path_len[ta]
-    uint8_t* el_fl = (uint8_t*)(el_plen + E);    // flags[ta]; bit 7 marks a closure-eligible element (lane-parallel closure)
-    uint16_t* el_tin = (uint16_t*)(lds + L::OFF_R3 + 16 * E);  // Euler interval of ta (lane-parallel closure only)
-    uint16_t* el_tout = el_tin + E;
+    uint8_t* el_fl = (uint8_t*)(el_plen + E);    // flags[ta]
 
     const DeviceTables& tb = A.tb;
     const int k = tb.k;
@@ -1497,7 +1511,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             if (d < ndist) {
                 dstart[d] = (uint16_t)s0;
                 if (s0 + n <= (uint32_t)E)
-                    for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (uint16_t)d;
+                    for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (eld_t)d;
             }
             nel += __shfl(incl, 63);
         }
@@ -1557,7 +1571,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 const uint32_t* c;
                 __device__ bool operator()(uint16_t a, uint16_t b) const { return c[a] > c[b]; }
             };
-            ss_sort(gord, (int)nT, VoteCmp{gcnt});
+            ss_sort<(T <= 128 ? 8 : 34)>(gord, (int)nT, VoteCmp{gcnt});
             lmat_read_result q;
             q.status = LMAT_ST_CALL; q.match_type = LMAT_MT_DIRECT; q.cand_kmer_cnt = (uint16_t)nuniq;
             q.valid_kmers = valid_kmers; q.read_len = (int)len; q.log_avg = 0; q.stdev = 0;
@@ -1603,7 +1617,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             dfl[d] = (uint8_t)fl;
             dstart[d] = (uint16_t)s0;
             if (s0 + n <= (uint32_t)E) {  // owner index of every element; ids of the short lists
-                for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (uint16_t)d;
+                for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (eld_t)d;
                 if (n == 1) { el_t[s0] = (uint16_t)w3; el_ta[s0] = (uint16_t)w4; }
                 else if (n == 2) {
                     el_t[s0] = (uint16_t)w3; el_t[s0 + 1] = (uint16_t)w4;
@@ -1620,6 +1634,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         fnd += fm;
         nel += __shfl(incl, 63);
     }
+    if (A.prm.stop_after == 7) { if (lane == 0) { emit(250, nel > 65535u ? 65535u : nel); } return; }
     bool overflow = nel > (uint32_t)E;
     if (overflow) {
         if (lane == 0) {
@@ -1648,18 +1663,19 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
         WSYNC();
     }
-    for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
-        const uint32_t e = e0 + lane;
-        if (e < nel) {
-            const u32x4 f = g_facts16[el_ta[e]];
-            el_poff[e] = f.x;
-            el_plen[e] = (uint16_t)(f.y & 0xFFFFu);
-            el_sp[e] = (uint16_t)(f.y >> 16);
-            el_fl[e] = (uint8_t)(f.w >> 16);
-            if (!INK4) { el_tin[e] = (uint16_t)(f.z & 0xFFFFu); el_tout[e] = (uint16_t)(f.z >> 16); }
+    if constexpr (INK4) {
+        for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < nel) {
+                const u32x4 f = g_facts16[el_ta[e]];
+                el_poff[e] = f.x;
+                el_plen[e] = (uint16_t)(f.y & 0xFFFFu);
+                el_sp[e] = (uint16_t)(f.y >> 16);
+                el_fl[e] = (uint8_t)(f.w >> 16);
+            }
         }
+        WSYNC();
     }
-    WSYNC();
     RELANE();
     // ---- phase 1 registration (read_label.cpp:1104-1122): first-lookup position order, then the depth-sorted
     //      order inside a k-mer's kept list == element order.  Within a chunk the lowest lane holding a new
@@ -1695,6 +1711,10 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
         return;
     }
+    // T <= 64: the fact record of every kept id, one per lane = registration slot (every kept id is registered by now);
+    // the load is in flight while the counts are made
+    u32x4 fz = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (!INK4) { if ((uint32_t)lane < nT) fz = g_facts16[reg[lane]]; }
     // cnt/leaf are packed u16 pairs updated with dword atomics: clear them for all slots that can be used
     for (uint32_t i = lane; i < (uint32_t)T; i += 64) ((unsigned int*)cnt)[i] = 0;  // covers cnt[T] and leaf[T]
     WSYNC();
@@ -1713,21 +1733,23 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     RELANE();
     // representative strain per species (read_label.cpp:1144-1177): max leaf count, ties -> smallest taxid
     // (-s: the whole post pass :1143-1204 is skipped; the list records already hold the lineages)
-    for (uint32_t e0 = 0; e0 < nel && !PERM; e0 += 64) {
-        const uint32_t e = e0 + lane;
-        if (e < nel && (el_fl[e] & kFlagStrain) && el_sp[e]) {
-            const uint32_t u = el_ta[e];
-            const uint32_t lf = leaf[hent[tid_find(hent, THM, u)] >> 16];
-            const uint32_t h = tid_find_or_claim(hent, THM, el_sp[e]);
-            atomicMax(&best[h], (lf << 16) | (0xFFFFu - u));
+    if constexpr (INK4) {
+        for (uint32_t e0 = 0; e0 < nel && !PERM; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            if (e < nel && (el_fl[e] & kFlagStrain) && el_sp[e]) {
+                const uint32_t u = el_ta[e];
+                const uint32_t lf = leaf[hent[tid_find(hent, THM, u)] >> 16];
+                const uint32_t h = tid_find_or_claim(hent, THM, el_sp[e]);
+                atomicMax(&best[h], (lf << 16) | (0xFFFFu - u));
+            }
         }
+        WSYNC();
     }
-    WSYNC();
     RELANE();
     // ---- phase 2 (read_label.cpp:1178-1203): per position, ancestors of the eligible kept ids, visited in
     //      ascending taxid order; positions ascending == distinct payloads in first-occurrence order.
     //      Everything but the path elements is already in LDS; the next chain is prefetched.
-    auto eligible = [&](uint32_t e) -> bool {
+    auto eligible = [&](uint32_t e) -> bool {  // large classes
         if (PERM) return false;                          // gPERMISSIVE_MATCH: no closure pass
         if (dfl[el_d[e]] & kListNegFirst) return false;  // closure only where first >= 0 (:1179)
         if (!(el_fl[e] & kFlagStrain)) return true;      // rank != "strain" (:1184)
@@ -1801,25 +1823,66 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         static_assert(E % 64 == 0 && T <= 64, "lane-parallel closure: one lane per registration slot");
         uint16_t* s_tin = stamp;  // per-slot Euler interval; the stamps are not used on this path and the leaf
         uint16_t* s_tout = leaf;  // counts are dead after the representative-strain pass
+        // facts of the id registered in this lane's slot
+        const bool sl_p1 = (uint32_t)lane < nT;
+        const uint32_t f_poff = fz.x, f_plen = fz.y & 0xFFFFu, f_sp = fz.y >> 16, f_fl = (fz.w >> 16) & 0xFFu, f_iv = fz.z;
+        const uint32_t my_id = sl_p1 ? (uint32_t)reg[lane] : 0u;
+        // representative strain per species, one vote per kept id
+        if (!PERM && sl_p1 && (f_fl & kFlagStrain) && f_sp) {
+            const uint32_t h = tid_find_or_claim(hent, THM, f_sp);
+            atomicMax(&best[h], ((uint32_t)leaf[lane] << 16) | (0xFFFFu - my_id));
+        }
+        WSYNC();
+        // which kept ids take part in the closure (:1184-1190): everything but strains, and of the strains the representative
+        bool es = false;
+        if (!PERM && sl_p1) {
+            if (!(f_fl & kFlagStrain)) es = true;
+            else if (f_sp) {
+                const int h = tid_find(hent, THM, f_sp);
+                es = h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - my_id);
+            }
+        }
+        const uint64_t ES = __ballot(es);
+        WSYNC();  // leaf and best are dead from here
+        unsigned int* first = best;  // per slot: its first eligible element
+        if (sl_p1) { s_tin[lane] = (uint16_t)(f_iv & 0xFFFFu); s_tout[lane] = (uint16_t)(f_iv >> 16); }
+        first[lane] = 0xFFFFFFFFu;
+        WSYNC();
+        // Per element: the slot of its id and whether it is eligible (closure only where first >= 0, :1179).  Only the
+        // FIRST eligible occurrence of a kept id has to be walked: a later walk of the same chain meets nothing but
+        // registered ids.  (Lists of one genus repeat their ids: without this such a read walked thousands of items,
+        // one round trip to memory per 64.)
         uint32_t W = 0;
+        uint32_t sreg[EC];  // slot | eligible << 8
+#pragma unroll
+        for (int ch = 0; ch < EC; ++ch) {
+            sreg[ch] = 0;
+            if ((uint32_t)ch * 64 < nel) {
+                const uint32_t e = (uint32_t)ch * 64 + lane;
+                if (e < nel) {
+                    const uint32_t sl = hent[tid_find(hent, THM, el_ta[e])] >> 16;
+                    const bool el = !(dfl[el_d[e]] & kListNegFirst) && ((ES >> sl) & 1ull);
+                    sreg[ch] = sl | (el ? 0x100u : 0u);
+                    el_ta[e] = (uint16_t)sl;
+                    if (el) atomicMin(&first[sl], e);
+                }
+            }
+        }
+        WSYNC();
 #pragma unroll
         for (int ch = 0; ch < EC; ++ch) {
             if ((uint32_t)ch * 64 < nel) {
                 const uint32_t e = (uint32_t)ch * 64 + lane;
-                const bool el = e < nel && eligible(e);
-                const uint32_t w = el ? (uint32_t)el_plen[e] : 0u;
+                const uint32_t sl = sreg[ch] & 0xFFu;
+                const uint32_t plen = (uint32_t)__shfl((int)f_plen, (int)sl);
+                const bool walk = e < nel && first[sl] == e;
+                const uint32_t w = walk ? plen : 0u;
                 uint32_t incl = w;
                 for (int o = 1; o < 64; o <<= 1) {
                     const uint32_t v = __shfl_up(incl, o);
                     if (lane >= o) incl += v;
                 }
-                if (e < nel) {
-                    el_sp[e] = (uint16_t)(W + incl - w);  // species_of is dead once eligibility is known: item offset
-                    if (el) el_fl[e] |= 0x80;
-                    const uint32_t s = hent[tid_find(hent, THM, el_ta[e])] >> 16;  // Euler interval of the id's slot
-                    s_tin[s] = el_tin[e];
-                    s_tout[s] = el_tout[e];
-                }
+                if (e < nel) el_off[e] = (uint16_t)(W + incl - w);
                 W += __shfl(incl, 63);
             }
         }
@@ -1830,14 +1893,20 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const bool act = i < W;
             uint32_t a = 0, h = 0;
             uint64_t pe = 0;
+            uint32_t sl_i = 0, rel = 0;
             if (act) {
                 uint32_t lo = 0, hi = nel;  // last element whose offset is <= i (offsets are non-decreasing)
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if ((uint32_t)el_sp[mid] <= i) lo = mid + 1; else hi = mid;
+                    if ((uint32_t)el_off[mid] <= i) lo = mid + 1; else hi = mid;
                 }
                 const uint32_t e = lo - 1;
-                pe = g_paths8[el_poff[e] + (i - (uint32_t)el_sp[e])];  // id | depth | tin | tout of that ancestor
+                sl_i = el_ta[e];
+                rel = i - (uint32_t)el_off[e];
+            }
+            const uint32_t poff_i = (uint32_t)__shfl((int)f_poff, (int)sl_i);  // the chain's start, from the slot's lane
+            if (act) {
+                pe = g_paths8[poff_i + rel];  // id | depth | tin | tout of that ancestor
                 a = (uint32_t)(pe & 0xFFFFu);
                 h = tid_find_or_claim(hent, THM, a);
                 atomicMin(&hent[h], a | ((0x8000u | (uint32_t)lane) << 16));
@@ -1859,7 +1928,6 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
         if (!overflow && W > 0) {
             const bool sl_act = (uint32_t)lane < nT;
-            const uint32_t a_s = sl_act ? (uint32_t)reg[lane] : 0u;
             uint32_t tin_s = 0xFFFF, tout_s = 0;
             if (sl_act) { tin_s = s_tin[lane]; tout_s = s_tout[lane]; }
             uint32_t add = 0, m_cur = 0;
@@ -1869,12 +1937,12 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             for (int ch = 0; ch < EC; ++ch) {
                 if ((uint32_t)ch * 64 < nel) {
                     const uint32_t e = (uint32_t)ch * 64 + lane;
-                    uint32_t p0 = 0, p1 = 0, p2 = 0;
+                    uint32_t p0 = 0, p2 = 0;
+                    const uint32_t p1 = (uint32_t)__shfl((int)f_iv, (int)(sreg[ch] & 0xFFu));  // Euler interval of the element's id
                     if (e < nel) {
                         const uint32_t d = el_d[e];
-                        p0 = (uint32_t)el_ta[e] | (d << 16);
-                        p1 = (uint32_t)el_tin[e] | ((uint32_t)el_tout[e] << 16);
-                        p2 = (uint32_t)(el_fl[e] >> 7) | ((uint32_t)dmult[d] << 1);
+                        p0 = (sreg[ch] & 0xFFu) | (d << 16);
+                        p2 = ((sreg[ch] >> 8) & 1u) | ((uint32_t)dmult[d] << 1);
                     }
                     const int n_here = (int)(nel - (uint32_t)ch * 64 < 64u ? nel - (uint32_t)ch * 64 : 64u);
                     for (int j = 0; j < n_here; ++j) {
@@ -1886,7 +1954,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                             if (hit && !member) add += m_cur;
                             cur_d = d; member = false; hit = false; m_cur = q2 >> 1;
                         }
-                        member |= (q0 & 0xFFFFu) == a_s;
+                        member |= (q0 & 0xFFFFu) == (uint32_t)lane;  // elements carry the slot of their id
                         if (q2 & 1u) hit |= tin_s < (q1 & 0xFFFFu) && (q1 >> 16) <= tout_s;
                     }
                 }
@@ -1945,7 +2013,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane < (int)nT) krec[2 + lane] = (uint32_t)reg[lane] | ((uint32_t)cnt[lane] << 16);
         if (lane == 0) {
             krec[0] = nT | (cand << 16);
-            emit(nT <= (uint32_t)kK4SmallT && !A.nm.active ? 254u : 253u, cand);  // pending K4, small / large tables
+            emit(A.nm.active ? 253u : (nT <= (uint32_t)kK4SmallT ? 254u : (nT <= (uint32_t)kK4MidT ? 252u : 253u)), cand);  // pending K4, by table size
         }
         return;
     }
@@ -2023,7 +2091,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
                 else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
             }
-            k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
+            k4_part2<L::LIN>(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
                      high_tout, cout_, &ncand, &call_idx);
         } else {
             call_idx = A.phix_call_idx;
@@ -2075,23 +2143,36 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
         w[0] = out[0]; w[1] = out[1]; w[2] = out[2]; w[3] = out[3]; w[4] = out[4];
         __builtin_memcpy(&res, w, 40);
     }
-    if (res.status != 254 && res.status != 253) return true;
+    if (res.status != 254 && res.status != 253 && res.status != 252) return true;
     const uint32_t hdr = krec[0];
     const int nT = (int)(hdr & 0xFFFFu);
     const uint32_t cand = hdr >> 16;
     if (nT > TT) return false;
     const int nmt = NM ? nm_table_of(A.nm, cand) : -1;  // NM: compile-time, keeps the plain path free of the track[] scratch
-    for (int s = 0; s < nT; ++s) {
-        const uint32_t w = krec[2 + s];
-        const uint32_t t = w & 0xFFFFu;
-        reg[s] = (uint16_t)t;
-        cnt[s] = (uint16_t)(w >> 16);
-        const u32x4 f = g_facts16[t];  // one record instead of four gathers
-        dep[s] = (uint16_t)(f.w & 0xFFFFu);
-        sflags[s] = (uint8_t)(f.w >> 16);
-        tin[s] = (uint16_t)(f.z & 0xFFFFu);
-        tout[s] = (uint16_t)(f.z >> 16);
-        if (NM && nmt >= 0) {  // null-model probability of this taxid at the read's GC bin (read_label.cpp:768-775)
+    // the (taxid, count) words and the per-taxid facts in batches of eight: 2 round trips to memory per batch, not per id
+    for (int s0 = 0; s0 < nT; s0 += 8) {
+        uint32_t w[8];
+        u32x4 f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = s0 + j < nT ? krec[2 + s0 + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = g_facts16[w[j] & 0xFFFFu];  // one record instead of four gathers
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = s0 + j;
+            if (s < nT) {
+                reg[s] = (uint16_t)(w[j] & 0xFFFFu);
+                cnt[s] = (uint16_t)(w[j] >> 16);
+                dep[s] = (uint16_t)(f[j].w & 0xFFFFu);
+                sflags[s] = (uint8_t)(f[j].w >> 16);
+                tin[s] = (uint16_t)(f[j].z & 0xFFFFu);
+                tout[s] = (uint16_t)(f[j].z >> 16);
+            }
+        }
+    }
+    if (NM && nmt >= 0) {  // null-model probability of every taxid at the read's GC bin (read_label.cpp:768-775)
+        for (int s = 0; s < nT; ++s) {
+            const uint32_t t = reg[s];
             const size_t row = (size_t)nmt * tb.n_ids + t;
             const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
             const int nb = ((const GAS int*)A.nm.nbins)[nmt];
@@ -2117,18 +2198,29 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
             const uint32_t alen = hf.y & 0xFFFFu, aoff = hf.x;
             if (bail_on_long && (uint32_t)nlin + alen > (uint32_t)LIN) return false;
             const float fcand = (float)cand;
-            for (uint32_t j = 0; j < alen; ++j) {
-                if (nlin >= LIN) { G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); break; }
-                const uint64_t pe = g_paths8[aoff + j];
-                const uint32_t a = (uint32_t)(pe & 0xFFFFu);
-                int sl = -1;
-                for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
-                LinEnt en;
-                en.tid = (uint16_t)a;
-                // pre-bias score of a registered ancestor (all_cand_set, :821), -10000 otherwise
-                en.score = sl >= 0 ? (NM ? score0[sl] : (float)cnt[sl] / fcand) : -10000.0f;
-                en.dep = (uint16_t)(pe >> 16); en.tin = (uint16_t)(pe >> 32); en.tout = (uint16_t)(pe >> 48);
-                lin[nlin++] = en;
+            bool trunc = false;
+            for (uint32_t j0 = 0; j0 < alen && !trunc; j0 += 8) {  // the chain in batches of eight loads
+                uint64_t pes[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pes[j] = j0 + j < alen ? g_paths8[aoff + j0 + j] : 0ull;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j0 + j < alen && !trunc) {
+                        if (nlin >= LIN) { G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); trunc = true; }
+                        else {
+                            const uint64_t pe = pes[j];
+                            const uint32_t a = (uint32_t)(pe & 0xFFFFu);
+                            int sl = -1;
+                            for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
+                            LinEnt en;
+                            en.tid = (uint16_t)a;
+                            // pre-bias score of a registered ancestor (all_cand_set, :821), -10000 otherwise
+                            en.score = sl >= 0 ? (NM ? score0[sl] : (float)cnt[sl] / fcand) : -10000.0f;
+                            en.dep = (uint16_t)(pe >> 16); en.tin = (uint16_t)(pe >> 32); en.tout = (uint16_t)(pe >> 48);
+                            lin[nlin++] = en;
+                        }
+                    }
+                }
             }
         }
         GAS lmat_cand* cout_ = nullptr;
@@ -2138,7 +2230,7 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
             if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
             else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
         }
-        k4_part2(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, cout_,
+        k4_part2<LIN>(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, cout_,
                  &ncand, &call_idx);
     }
     res.cand_off = coff;
@@ -2155,7 +2247,8 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
     return true;
 }
 
-// pending reads of the batch -> two index lists by table size (status 254: small, 253: large); counts in cursor[4], cursor[5]
+// pending reads of the batch -> three index lists by table size (status 254: small, 252: mid, 253: large); counts in
+// cursor[4], cursor[8], cursor[5]
 __global__ __launch_bounds__(256) void k4_compact_kernel(ClassifyArgs A) {
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
     const int lane = threadIdx.x & 63;
@@ -2168,16 +2261,16 @@ __global__ __launch_bounds__(256) void k4_compact_kernel(ClassifyArgs A) {
             const uint64_t it = base + (uint64_t)j * 64 + lane;
             st[j] = it < A.count ? (uint32_t)*(const GAS uint8_t*)(A.results + it) : 0u;  // status is the record's first byte
         }
-        for (int cls = 0; cls < 2; ++cls) {
-            const uint32_t want = cls == 0 ? 254u : 253u;
+        for (int cls = 0; cls < 3; ++cls) {
+            const uint32_t want = cls == 0 ? 254u : (cls == 1 ? 252u : 253u);
             uint32_t total = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) total += (uint32_t)popc64(__ballot(st[j] == want));
             if (!total) continue;
             uint32_t pos = 0;
-            if (lane == 0) pos = G_ADD(&g_cursor[4 + cls], total);
+            if (lane == 0) pos = G_ADD(&g_cursor[cls == 0 ? 4 : (cls == 1 ? 8 : 5)], total);
             pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-            GAS uint32_t* list = (GAS uint32_t*)(cls == 0 ? A.k4_small : A.k4_large);
+            GAS uint32_t* list = (GAS uint32_t*)(cls == 0 ? A.k4_small : (cls == 1 ? A.k4_mid : A.k4_large));
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const uint64_t m = __ballot(st[j] == want);
@@ -2188,44 +2281,48 @@ __global__ __launch_bounds__(256) void k4_compact_kernel(ClassifyArgs A) {
     }
 }
 
+template <int TT>
 __global__ __launch_bounds__(64) void k4_lds_kernel(ClassifyArgs A) {
+    using K = K4Lds<TT>;
     extern __shared__ __align__(16) unsigned char smem[];
-    static_assert(kK4SmallStride * 4 >= 12 * kK4SmallT + kK4SmallT + 4 * kK4SmallT + 12 * kK4SmallLin, "per-lane block");
-    unsigned char* blk = smem + (size_t)(threadIdx.x & 63) * kK4SmallStride * 4;
+    const int lane = threadIdx.x & 63;
+    if (lane >= K::LANES) return;
+    unsigned char* blk = smem + (size_t)lane * K::STRIDE * 4;
     uint16_t* reg = (uint16_t*)blk;
-    uint16_t* cnt = reg + kK4SmallT;
-    uint16_t* dep = cnt + kK4SmallT;
-    uint16_t* tin = dep + kK4SmallT;
-    uint16_t* tout = tin + kK4SmallT;
-    uint16_t* ord = tout + kK4SmallT;
-    float* score = (float*)(ord + kK4SmallT);
-    LinEnt* lin = (LinEnt*)(score + kK4SmallT);
-    uint8_t* sflags = (uint8_t*)(lin + kK4SmallLin);
+    uint16_t* cnt = reg + TT;
+    uint16_t* dep = cnt + TT;
+    uint16_t* tin = dep + TT;
+    uint16_t* tout = tin + TT;
+    uint16_t* ord = tout + TT;
+    float* score = (float*)(ord + TT);
+    LinEnt* lin = (LinEnt*)(score + TT);
+    uint8_t* sflags = (uint8_t*)(lin + K::LIN);
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
-    const uint64_t n = *(const GAS uint32_t*)(g_cursor + 4);
-    const uint64_t stride = (uint64_t)gridDim.x * 64;
-    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
-        const uint64_t it = ((const GAS uint32_t*)A.k4_small)[i];
-        if (!k4_read<kK4SmallT, kK4SmallLin, false>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, nullptr, nullptr, nullptr,
-                                                    lin, true))
+    const uint64_t n = *(const GAS uint32_t*)(g_cursor + (TT == kK4SmallT ? 4 : (TT == kK4MidT ? 8 : 5)));
+    const GAS uint32_t* list = (const GAS uint32_t*)(TT == kK4SmallT ? A.k4_small : (TT == kK4MidT ? A.k4_mid : A.k4_large));
+    const uint64_t stride = (uint64_t)gridDim.x * K::LANES;
+    for (uint64_t i = (uint64_t)blockIdx.x * K::LANES + lane; i < n; i += stride) {
+        const uint64_t it = list[i];
+        if (!k4_read<TT, K::LIN, false>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, nullptr, nullptr, nullptr, lin, true))
             ((GAS uint32_t*)A.k4_bail)[G_ADD(&g_cursor[6], 1u)] = (uint32_t)it;  // lineage longer than the LDS block: scratch kernel, last launch
     }
 }
 
-template <bool NM>
+template <bool NM, int TT>
 __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
-    constexpr int LIN = kK4T + 72;
+    constexpr int LIN = TT == kK4T ? kK4T + 72 : TT + 8;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
-    const uint64_t n = *(const GAS uint32_t*)(g_cursor + A.k4_slot);  // 5: the large-table list, 6: reads the LDS kernel passed on
-    const GAS uint32_t* list = (const GAS uint32_t*)(A.k4_slot == 5 ? A.k4_large : A.k4_bail);
+    const uint64_t n = *(const GAS uint32_t*)(g_cursor + A.k4_slot);  // 5: the large-table list, 8: up to 32 taxids, 6: reads an LDS/short kernel passed on
+    const GAS uint32_t* list = (const GAS uint32_t*)(A.k4_slot == 5 ? A.k4_large : (A.k4_slot == 8 ? A.k4_mid : A.k4_bail));
     const uint64_t stride = (uint64_t)gridDim.x * 64;
     for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
         const uint64_t it = list[i];
-        uint16_t reg[kK4T], cnt[kK4T], dep[kK4T], tin[kK4T], tout[kK4T], ord[kK4T];
-        uint8_t sflags[kK4T], nm_cl[NM ? kK4T : 1];
-        float score[kK4T], score0[NM ? kK4T : 1], nm_rp[NM ? kK4T : 1];
+        uint16_t reg[TT], cnt[TT], dep[TT], tin[TT], tout[TT], ord[TT];
+        uint8_t sflags[TT], nm_cl[NM ? TT : 1];
+        float score[TT], score0[NM ? TT : 1], nm_rp[NM ? TT : 1];
         LinEnt lin[LIN];
-        k4_read<kK4T, LIN, NM>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, score0, nm_cl, nm_rp, lin, false);
+        if (!k4_read<TT, LIN, NM>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, score0, nm_cl, nm_rp, lin, TT != kK4T))
+            ((GAS uint32_t*)A.k4_bail)[G_ADD(&g_cursor[6], 1u)] = (uint32_t)it;
     }
 }
 
@@ -2259,7 +2356,7 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
 // resident waves per SIMD each class is compiled for: what its LDS footprint allows (and no more registers than that needs)
-constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > 128 ? (U <= 160 ? 3 : 2) : (U <= 160 ? (CPT ? 7 : 5) : (U <= 256 ? 5 : 3))); }
+constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 7 : 5) : (U <= 256 ? 5 : 3))); }
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
@@ -2363,36 +2460,59 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
     }
 }
 
-// The LDS kernel (5 waves per CU, LDS-bound) and the scratch kernel (64 VGPRs, latency-bound on HBM) fit a CU side by
-// side, so they run concurrently on two streams; `joined` is recorded when both are done.
-void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipEvent_t forked, hipEvent_t joined) {
+// The K4 kernels of a batch, by table size, side by side: up to 16 taxids in LDS on `stream`, 17..32 in scratch memory on
+// `stream2`, 33..64 in LDS (half waves) on `stream3`; the scratch kernel alone when null models are loaded (its extra tables do not fit the LDS
+// blocks), and once more at the end for the few reads a tier passed on (lineage longer than its block).
+template <int TT>
+static void launch_k4_lds(const ClassifyArgs& a, uint64_t max_reads, hipStream_t stream) {
+    using K = K4Lds<TT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k4_lds_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::BYTES);
+        attr_set = true;
+    }
+    const uint64_t per_cu = 160 * 1024 / K::BYTES;
+    uint64_t g = (max_reads + K::LANES - 1) / K::LANES;
+    if (g > 256 * per_cu) g = 256 * per_cu;
+    if (g < 1) g = 1;
+    k4_lds_kernel<TT><<<dim3((unsigned)g), dim3(64), K::BYTES, stream>>>(a);
+}
+void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked, hipEvent_t joined,
+               hipEvent_t joined3) {
     uint64_t blocks = (a.count + 4095) / 4096;  // a wave takes 1024 reads per pass
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
     k4_compact_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>(a);
     hipEventRecord(forked, stream);
     hipStreamWaitEvent(stream2, forked, 0);
-    constexpr int lds_bytes = kK4SmallStride * 4 * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)k4_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
-    uint64_t waves = (a.count + 63) / 64;
-    uint64_t g2 = waves < 256 * 32 ? waves : 256 * 32;
-    if (g2 < 1) g2 = 1;
     ClassifyArgs b = a;
     b.k4_slot = 5;
-    if (a.nm.active) k4_kernel<true><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
-    else k4_kernel<false><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+    const uint64_t waves = (a.count + 63) / 64;
+    uint64_t g2 = waves < 256 * 32 ? waves : 256 * 32;
+    if (g2 < 1) g2 = 1;
+    // tables of 17..32 taxids: one lane per read with the tables in scratch memory; every wave is resident at once, which
+    // the LDS tier of that size (2 waves per CU, a millisecond per pass) cannot offer.  LMAT_K4_MODE=1 runs it anyway.
+    static const int mode = getenv("LMAT_K4_MODE") ? atoi(getenv("LMAT_K4_MODE")) : 0;
+    if (a.nm.active) {
+        k4_kernel<true, kK4T><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+    } else if (mode == 1) {
+        launch_k4_lds<kK4MidT>(a, a.count, stream2);
+    } else {
+        b.k4_slot = 8;
+        k4_kernel<false, kK4MidT><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+    }
     hipEventRecord(joined, stream2);
-    uint64_t g1 = waves < 256 * 5 ? waves : 256 * 5;  // 5 blocks of 31.25 KB fit a CU's LDS
-    if (g1 < 1) g1 = 1;
-    k4_lds_kernel<<<dim3((unsigned)g1), dim3(64), lds_bytes, stream>>>(a);
+    if (!a.nm.active) {  // 33..64 taxids: few reads, but a pass over them is long -- a stream of its own
+        hipStreamWaitEvent(stream3, forked, 0);
+        launch_k4_lds<kK4T>(a, a.count / 8 + 64, stream3);
+        hipEventRecord(joined3, stream3);
+    }
+    launch_k4_lds<kK4SmallT>(a, a.count, stream);
+    if (!a.nm.active) hipStreamWaitEvent(stream, joined3, 0);
     hipStreamWaitEvent(stream, joined, 0);
     b.k4_slot = 6;  // the few reads whose lineage outgrew the LDS block
-    if (a.nm.active) k4_kernel<true><<<dim3(64), dim3(64), 0, stream>>>(b);
-    else k4_kernel<false><<<dim3(64), dim3(64), 0, stream>>>(b);
+    if (a.nm.active) k4_kernel<true, kK4T><<<dim3(64), dim3(64), 0, stream>>>(b);
+    else k4_kernel<false, kK4T><<<dim3(64), dim3(64), 0, stream>>>(b);
 }
 
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
@@ -2430,14 +2550,14 @@ size_t classify_gmem_scratch_bytes() { return (size_t)kGmemGrid * WL<kGmemU, 409
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream) {
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
-    if (tcap_class == 2) {  // reads whose kept lists add up to more than 128 elements (many strains per k-mer): 512 of them
+    if (tcap_class == 2) {  // reads whose kept lists add up to more than kFastE elements (many strains per k-mer): 512 of them
         if (P <= 160) LC(160, 64, 512, false); else LC(512, 64, 512, false);
     } else if (P <= 160 && tcap_class == 0) {
-        LC(160, 64, 128, false);
+        LC(160, 64, kFastE, false);
     } else if (P <= 256) {
-        if (tcap_class == 0) LC(256, 64, 128, false); else LC(256, 1024, 4096, true);
+        if (tcap_class == 0) LC(256, 64, kFastE, false); else LC(256, 1024, 4096, true);
     } else if (P <= 512) {
-        if (tcap_class == 0) LC(512, 64, 128, false); else LC(512, 1024, 4096, true);
+        if (tcap_class == 0) LC(512, 64, kFastE, false); else LC(512, 1024, 4096, true);
     } else if (P <= 2048) {
         LC(2048, 1024, 4096, true);
     } else if (P <= (uint32_t)kGmemU && a.gscratch) {

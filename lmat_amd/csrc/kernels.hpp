@@ -24,6 +24,7 @@ struct ClassifyArgs {
     const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
     uint32_t* k4buf;           // per-read records handed from the fast classify kernel to the K4 kernels
     uint32_t* k4_small;        // read indices awaiting K4, small tables (count in cursor[4])
+    uint32_t* k4_mid;          // read indices awaiting K4, up to 32 taxids (count in cursor[8])
     uint32_t* k4_large;        // read indices awaiting K4, large tables (count in cursor[5])
     uint32_t* k4_bail;         // reads the LDS K4 kernel could not hold after all (count in cursor[6])
     uint32_t k4_slot;          // which of the two lists a k4_kernel launch takes (5 or 6)
@@ -58,7 +59,8 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
                    uint32_t stride, hipStream_t stream);
 // tcap_class: 0 = fast (T=64, E=128), 2 = the same with E=512, 1 = large (T=1024).  Returns false if max_len exceeds every U class.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
-void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipEvent_t forked, hipEvent_t joined);
+void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked, hipEvent_t joined,
+               hipEvent_t joined3);
 int classify_max_read_len();
 size_t classify_gmem_scratch_bytes();
 // issues ~n_probes random bucket reads (rounded up to 144 per wave x 4096 waves)

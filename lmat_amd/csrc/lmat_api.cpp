@@ -122,6 +122,8 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     free_null_models(c);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_join3) hipEventDestroy(c->ev_join3);
+    if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c->ingest;
@@ -894,7 +896,7 @@ static int ensure_scratch(lmat_ctx* c, uint64_t count) {
         if (c->d_k4large) hipFree(c->d_k4large);
         c->d_k4small = c->d_k4large = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_k4small, count * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_k4large, count * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_k4large, 2 * count * sizeof(uint32_t)));  // two lists: large tables | up to 32 taxids
         if (c->d_k4bail) hipFree(c->d_k4bail);
         c->d_k4bail = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_k4bail, count * sizeof(uint32_t)));
@@ -940,6 +942,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     if (c->rand_launch) { a.rand_max = c->d_rand_max; a.rand_cnt = c->d_rand_cnt; a.rand_gc = c->d_rand_gc; a.rand_nb = c->rand_nb; }
     a.k4_small = c->d_k4small;
     a.k4_large = c->d_k4large;
+    a.k4_mid = c->d_k4large + c->ovf_cap;
     a.k4_bail = c->d_k4bail;
     a.k4_slot = 5;
     a.nm = c->nm;
@@ -1058,7 +1061,11 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
-        launch_k4(a, c->stream, c->stream2, c->ev_fork, c->ev_join);
+        if (!c->stream3) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
+        }
+        launch_k4(a, c->stream, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_join3);
     }
     {   // ... to the large LDS class (1024 taxids, reads up to 2067 bp), or directly to the global-memory class when the
         // batch holds reads beyond that

@@ -252,23 +252,47 @@ LM_HD void ss_heapsort(T* a, int first, int last, Cmp& cmp) {
         ss_adjust_heap(a, first, 0, l - first, v, cmp);
     }
 }
-template <class T, class Cmp>
+// CAP = capacity of the stack of pending ranges.  Only ranges of more than 16 elements are kept (smaller ones need no
+// partitioning), they are disjoint, and each carries a smaller depth budget than the one below it: at most
+// min(n / 17, 2 * floor(log2 n) + 1) entries.  CAP <= 8 (n <= 152, the K4 kernels' tables) keeps the stack in registers --
+// an indexed private array lives in scratch memory, which a GPU kernel pays for at every dispatch.
+template <int CAP = 34, class T, class Cmp>
 LM_HD void ss_sort(T* a, int n, Cmp cmp) {
     if (n <= 0) return;
     if (n <= 16) {  // introsort loop is a no-op below the threshold: straight to the final insertion sort
         ss_insertion_sort(a, 0, n, cmp);
         return;
     }
-    // introsort loop, recursion on the right part made explicit with a small stack
-    // pending right-hand ranges: at most one per recursion level, depth <= 2*floor(log2 n) <= 32 for n < 65536
-    int stack_first[34], stack_last[34], stack_depth[34];
+    // introsort loop, recursion on the right part made explicit; entry = first | last << 13 | depth << 26 (n < 8192)
+    uint32_t st[CAP];
     int sp = 0;
+    auto push = [&](uint32_t v) {
+        if (CAP <= 8) {
+#pragma unroll
+            for (int q = 0; q < CAP; ++q) if (q == sp) st[q] = v;
+        } else if (sp < CAP) st[sp] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        --sp;
+        if (CAP <= 8) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int q = 0; q < CAP; ++q) if (q == sp) v = st[q];
+            return v;
+        }
+        return st[sp];
+    };
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) ++lg;
-    stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = 2 * lg; sp = 1;
+    if (CAP <= 8) {
+#pragma unroll
+        for (int q = 0; q < CAP; ++q) st[q] = 0;
+    }
+    push(0u | ((uint32_t)n << 13) | ((uint32_t)(2 * lg) << 26));
     while (sp > 0) {
-        --sp;
-        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+        const uint32_t top = pop();
+        int first = (int)(top & 0x1FFFu), last = (int)((top >> 13) & 0x1FFFu), depth = (int)(top >> 26);
         while (last - first > 16) {
             if (depth == 0) {
                 ss_heapsort(a, first, last, cmp);
@@ -300,16 +324,12 @@ LM_HD void ss_sort(T* a, int n, Cmp cmp) {
             const int cut = lo;
             // reference recurses on [cut,last) first, then loops on [first,cut)
             // (order of processing disjoint ranges does not change the result)
-            if (sp < 34) { stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = depth; ++sp; }
+            if (last - cut > 16) push((uint32_t)cut | ((uint32_t)last << 13) | ((uint32_t)depth << 26));
             last = cut;
         }
     }
-    if (n > 16) {
-        ss_insertion_sort(a, 0, 16, cmp);
-        for (int i = 16; i < n; ++i) ss_unguarded_linear_insert(a, i, cmp);
-    } else {
-        ss_insertion_sort(a, 0, n, cmp);
-    }
+    ss_insertion_sort(a, 0, 16, cmp);
+    for (int i = 16; i < n; ++i) ss_unguarded_linear_insert(a, i, cmp);
 }
 
 }  // namespace lmat

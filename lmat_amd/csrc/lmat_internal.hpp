@@ -160,7 +160,8 @@ struct lmat_ctx {
     uint32_t* d_k4large = nullptr;
     uint32_t* d_k4bail = nullptr;
     hipStream_t stream2 = nullptr;  // the scratch K4 kernel runs beside the LDS one
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream3 = nullptr;  // ... and the LDS kernel of the largest tables beside both
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     lmat::NullModelDev nm;         // device pointers owned by the context
     std::vector<void*> nm_allocs;
     uint64_t ovf_cap = 0;
