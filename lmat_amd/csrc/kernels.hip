@@ -1930,36 +1930,45 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const bool sl_act = (uint32_t)lane < nT;
             uint32_t tin_s = 0xFFFF, tout_s = 0;
             if (sl_act) { tin_s = s_tin[lane]; tout_s = s_tout[lane]; }
-            uint32_t add = 0, m_cur = 0;
-            int cur_d = -1;
-            bool member = false, hit = false;
-#pragma unroll
-            for (int ch = 0; ch < EC; ++ch) {
-                if ((uint32_t)ch * 64 < nel) {
-                    const uint32_t e = (uint32_t)ch * 64 + lane;
-                    uint32_t p0 = 0, p2 = 0;
-                    const uint32_t p1 = (uint32_t)__shfl((int)f_iv, (int)(sreg[ch] & 0xFFu));  // Euler interval of the element's id
-                    if (e < nel) {
-                        const uint32_t d = el_d[e];
-                        p0 = (sreg[ch] & 0xFFu) | (d << 16);
-                        p2 = ((sreg[ch] >> 8) & 1u) | ((uint32_t)dmult[d] << 1);
-                    }
-                    const int n_here = (int)(nel - (uint32_t)ch * 64 < 64u ? nel - (uint32_t)ch * 64 : 64u);
-                    for (int j = 0; j < n_here; ++j) {
-                        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, j);
-                        const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)p1, j);
-                        const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)p2, j);
-                        const int d = (int)(q0 >> 16);
-                        if (d != cur_d) {
-                            if (hit && !member) add += m_cur;
-                            cur_d = d; member = false; hit = false; m_cur = q2 >> 1;
-                        }
-                        member |= (q0 & 0xFFFFu) == (uint32_t)lane;  // elements carry the slot of their id
-                        if (q2 & 1u) hit |= tin_s < (q1 & 0xFFFFu) && (q1 >> 16) <= tout_s;
-                    }
+            // (3a) for every kept id that is eligible somewhere: the set of slots that are proper ancestors of it, as a
+            //      64-bit mask held by the id's own lane
+            uint32_t anc_lo = 0, anc_hi = 0;
+            uint64_t todo = __ballot(first[lane] != 0xFFFFFFFFu);
+            while (todo) {
+                const int sx = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t tin_x = (uint32_t)__builtin_amdgcn_readlane((int)tin_s, sx);
+                const uint32_t tout_x = (uint32_t)__builtin_amdgcn_readlane((int)tout_s, sx);
+                const uint64_t am = __ballot(sl_act && tin_s < tin_x && tout_x <= tout_s);
+                if (lane == sx) { anc_lo = (uint32_t)am; anc_hi = (uint32_t)(am >> 32); }
+            }
+            // (3b) lane d = position set d (at most 64 of them here): the slots it keeps, and the ancestors of its eligible ids
+            const bool d_act = (uint32_t)lane < ndist;
+            const uint32_t dn_ = d_act ? (uint32_t)dn[lane] : 0u, ds_ = d_act ? (uint32_t)dstart[lane] : 0u;
+            const bool d_ok = d_act && !(dfl[lane] & kListNegFirst);
+            uint32_t hit_lo = 0, hit_hi = 0, mem_lo = 0, mem_hi = 0;
+            for (uint32_t j = 0; __ballot(j < dn_) != 0; ++j) {
+                const bool on = j < dn_;
+                const uint32_t sl = on ? (uint32_t)el_ta[ds_ + j] : 0u;  // the slot of the id (stored above)
+                const uint32_t alo = (uint32_t)__shfl((int)anc_lo, (int)sl), ahi = (uint32_t)__shfl((int)anc_hi, (int)sl);
+                if (on) {
+                    const uint32_t bit = 1u << (sl & 31u);
+                    if (sl & 32u) mem_hi |= bit; else mem_lo |= bit;
+                    if (d_ok && ((ES >> sl) & 1ull)) { hit_lo |= alo; hit_hi |= ahi; }
                 }
             }
-            if (hit && !member) add += m_cur;
+            // (3c) count[a] += m_d for every position set d that reaches a without keeping it
+            const uint32_t add_lo = hit_lo & ~mem_lo, add_hi = hit_hi & ~mem_hi;
+            const uint32_t md = d_act ? (uint32_t)dmult[lane] : 0u;
+            const uint32_t my_bit = 1u << (lane & 31);
+            uint32_t add = 0;
+            for (uint32_t d = 0; d < ndist; ++d) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)add_lo, (int)d);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)add_hi, (int)d);
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)md, (int)d);
+                if ((lo | hi) == 0) continue;
+                if ((lane < 32 ? lo : hi) & my_bit) add += m;
+            }
             if (sl_act && add) cnt[lane] = (uint16_t)(cnt[lane] + add);
             WSYNC();
         }
@@ -2477,8 +2486,8 @@ static void launch_k4_lds(const ClassifyArgs& a, uint64_t max_reads, hipStream_t
     if (g < 1) g = 1;
     k4_lds_kernel<TT><<<dim3((unsigned)g), dim3(64), K::BYTES, stream>>>(a);
 }
-void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked, hipEvent_t joined,
-               hipEvent_t joined3) {
+void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked,
+                     hipEvent_t joined) {
     uint64_t blocks = (a.count + 4095) / 4096;  // a wave takes 1024 reads per pass
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
@@ -2502,15 +2511,17 @@ void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, h
         k4_kernel<false, kK4MidT><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
     }
     hipEventRecord(joined, stream2);
-    if (!a.nm.active) {  // 33..64 taxids: few reads, but a pass over them is long -- a stream of its own
-        hipStreamWaitEvent(stream3, forked, 0);
-        launch_k4_lds<kK4T>(a, a.count / 8 + 64, stream3);
-        hipEventRecord(joined3, stream3);
-    }
+    hipStreamWaitEvent(stream3, forked, 0);
+    if (!a.nm.active) launch_k4_lds<kK4T>(a, a.count / 8 + 64, stream3);  // 33..64 taxids: few reads, but a pass over them is long
     launch_k4_lds<kK4SmallT>(a, a.count, stream);
-    if (!a.nm.active) hipStreamWaitEvent(stream, joined3, 0);
+}
+// ... the caller may queue more work on stream3 (the re-run classes, which do their own K4) ...
+void launch_k4_end(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream3, hipEvent_t joined, hipEvent_t joined3) {
+    hipEventRecord(joined3, stream3);
+    hipStreamWaitEvent(stream, joined3, 0);
     hipStreamWaitEvent(stream, joined, 0);
-    b.k4_slot = 6;  // the few reads whose lineage outgrew the LDS block
+    ClassifyArgs b = a;
+    b.k4_slot = 6;  // the few reads whose lineage outgrew a tier's block
     if (a.nm.active) k4_kernel<true, kK4T><<<dim3(64), dim3(64), 0, stream>>>(b);
     else k4_kernel<false, kK4T><<<dim3(64), dim3(64), 0, stream>>>(b);
 }

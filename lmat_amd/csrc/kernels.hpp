@@ -59,8 +59,9 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
                    uint32_t stride, hipStream_t stream);
 // tcap_class: 0 = fast (T=64, E=128), 2 = the same with E=512, 1 = large (T=1024).  Returns false if max_len exceeds every U class.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
-void launch_k4(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked, hipEvent_t joined,
-               hipEvent_t joined3);
+void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked,
+                     hipEvent_t joined);
+void launch_k4_end(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream3, hipEvent_t joined, hipEvent_t joined3);
 int classify_max_read_len();
 size_t classify_gmem_scratch_bytes();
 // issues ~n_probes random bucket reads (rounded up to 144 per wave x 4096 waves)

@@ -1055,7 +1055,8 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         m.p_max = 0xFFFFFFFFu;
         launch_classify(m, 512 + (uint32_t)c->dev.k - 1, 2, c->stream);
     }
-    if (a.prm.stop_after == 0) {  // score + LCA decision, one lane per read
+    const bool k4 = a.prm.stop_after == 0;
+    if (k4) {  // score + LCA decision, one lane per read
         if (!c->stream2) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1065,10 +1066,11 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
         }
-        launch_k4(a, c->stream, c->stream2, c->stream3, c->ev_fork, c->ev_join, c->ev_join3);
+        launch_k4_begin(a, c->stream, c->stream2, c->stream3, c->ev_fork, c->ev_join);
     }
     {   // ... to the large LDS class (1024 taxids, reads up to 2067 bp), or directly to the global-memory class when the
-        // batch holds reads beyond that
+        // batch holds reads beyond that.  These kernels make their own decision step, so they run beside the K4 kernels.
+        hipStream_t rs = k4 ? c->stream3 : c->stream;
         const bool lds_class = reads->max_len <= 2048 + 19;
         ClassifyArgs b = a;
         b.index = c->d_ovf2;
@@ -1077,15 +1079,16 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         b.ovf_slot = 7;
         b.count = 0;
         b.gscratch = c->d_gscratch;
-        launch_classify(b, reads->max_len, 1, c->stream);
+        launch_classify(b, reads->max_len, 1, rs);
         if (lds_class) {  // what even that class cannot hold goes to the global-memory class
             ClassifyArgs g = b;
             g.index = c->d_ovf3;
             g.count_ptr = c->d_cursor + 7;
             g.ovf_list = nullptr;
-            launch_classify(g, 2048 + 20, 1, c->stream);
+            launch_classify(g, 2048 + 20, 1, rs);
         }
     }
+    if (k4) launch_k4_end(a, c->stream, c->stream3, c->ev_join, c->ev_join3);
     if (timed) {
         HIPCHK(c, hipEventRecord(e3, c->stream));
         c->pending_events.push_back(std::make_pair(e0, e1));
