@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--read-len", default="150", help="read length, or a comma list for a mixed-length batch (not the headline workload)")
     ap.add_argument("--cpu-sample", type=int, default=40000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--list-replicas", type=int, default=1, help="copies of every distinct taxid list in the arena, one per 512-base stretch of a genome (5: 4 M lists, 250 MB -- the most 24-bit payloads address)")
+    ap.add_argument("--genus-permille", type=int, default=100, help="share of every genome that is a block shared within its genus (SURVEY 8d: 100)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the boundary-inclusive (pinned host -> H2D -> classify -> D2H) leg")
     args = ap.parse_args()
 
@@ -227,7 +229,7 @@ def main():
     pm = 1.0 - 0.99 ** k
     G = int(0.8 * (table_bytes / 8) / (n_species * (1.0 + S * pm)))
     t0 = time.perf_counter()
-    eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes)
+    eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes, genus_block_permille=args.genus_permille, list_replicas=args.list_replicas)
     t_build = time.perf_counter() - t0
     log(f"db built: {eng.db_size} k-mers in {t_build:.2f}s, table {table_bytes / 2**30:.1f} GiB, G={G}")
     n_steps_total = args.steps + args.warmup
@@ -317,13 +319,13 @@ def main():
                                    f"k-mer hash ({eng.db_size} 20-mers, replicated per GPU), run_rl.sh flags -x 0 -j 30 -l 0 -b 1, calls-only",
                        "reads_per_step_per_gpu": args.batch, "read_len": args.read_len, "db_gib": args.db_gb,
                        "db_kmers": eng.db_size, "k": k, "parallelism": f"reads sharded x{world}, DB replicated",
-                       "db_build_s": round(t_build, 2), "reads_called": called, "nomatch": nomatch},
+                       "db_build_s": round(t_build, 2), "genus_block_permille": args.genus_permille, "list_replicas": args.list_replicas, "distinct_lists": eng.n_lists, "list_arena_mib": round(eng.arena_bytes / 2**20, 1), "reads_called": called, "nomatch": nomatch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                          "frac_measured": frac_measured,
                          "frac_bucket_only": mean_bucket * args.batch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_read_bucket_only": mean_bucket,
-                         "kernel": "classify_kernel<160,64,128,false,false,true>",
+                         "kernel": "classify_kernel<160,64,320,false,false,true>",
                          "kernel_avg_ms": avg_ms, "k4_kernels_avg_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.batch,
                          "random_64B_gather_ceiling_GBs": gather_gbs},
         }

@@ -117,6 +117,8 @@ int lmat_db_save_image(lmat_ctx* ctx, const char* fn);
 int lmat_db_load_image(lmat_ctx* ctx, const char* fn, uint64_t table_bytes);
 int lmat_db_kmer_length(const lmat_ctx* ctx);   /* SortedDb::get_kmer_length (SortedDb.hpp:433) */
 uint64_t lmat_db_size(const lmat_ctx* ctx);      /* SortedDb::size (SortedDb.hpp:438)            */
+uint64_t lmat_db_list_count(const lmat_ctx* ctx); /* distinct taxid-list records of a synthetic database (0: not counted) */
+uint64_t lmat_db_arena_bytes(const lmat_ctx* ctx); /* size of the taxid-list arena on the device */
 uint64_t lmat_db_table_bytes(const lmat_ctx* ctx);
 
 /* TaxNodeStat-style lookup of n k-mers on the GPU: counts[i] = taxidCount (0 = miss),

@@ -82,6 +82,8 @@ def load_library(path: str | None = None):
         "lmat_nullmodel_clear": (i32, [vp]),
         "lmat_db_kmer_length": (i32, [vp]),
         "lmat_db_size": (u64, [vp]),
+        "lmat_db_list_count": (u64, [vp]),
+        "lmat_db_arena_bytes": (u64, [vp]),
         "lmat_db_table_bytes": (u64, [vp]),
         "lmat_db_lookup": (i32, [vp, vp, u64, vp, vp, u32]),
         "lmat_synth_taxonomy": (i32, [vp, vp]),
@@ -126,7 +128,7 @@ def load_library(path: str | None = None):
 
 
 EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_last_error", "lmat_set_params", "lmat_taxonomy_load_files",
-            "lmat_db_begin", "lmat_genedb_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size",
+            "lmat_db_begin", "lmat_genedb_begin", "lmat_db_add_taxhisto", "lmat_db_finalize", "lmat_db_kmer_length", "lmat_db_size", "lmat_db_list_count", "lmat_db_arena_bytes",
             "lmat_db_set_build_options", "lmat_db_save_image", "lmat_db_load_image", "lmat_ingest_create", "lmat_ingest_idmap_from_tree", "lmat_rand_mode", "lmat_rand_reset", "lmat_rand_label", "lmat_rand_get",
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
             "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
@@ -400,6 +402,14 @@ class Engine:
     @property
     def db_size(self):
         return int(self.lib.lmat_db_size(self.ctx))
+
+    @property
+    def n_lists(self):
+        return int(self.lib.lmat_db_list_count(self.ctx))
+
+    @property
+    def arena_bytes(self):
+        return int(self.lib.lmat_db_arena_bytes(self.ctx))
 
     @property
     def table_bytes(self):

@@ -322,7 +322,8 @@ __global__ void synth_db_kernel(DeviceTables tb, SynthGeo g, int k, const uint16
             const uint64_t km = canon_from_fwd(anc, k);
             uint32_t pay = inblk ? list_payload[g_off + ((uint64_t)(sp / g.spg) << (g.spg * g.S)) + mask]
                                  : list_payload[((uint64_t)sp << g.S) + mask];
-            if (rep > 1 && pay >= kListBase) pay += (uint32_t)(mix64(km) % rep) * rep_stride;
+            // replica of the list record: one per 512-base stretch of a genome, so neighbouring k-mers still share their list
+            if (rep > 1 && pay >= kListBase) pay += (uint32_t)(mix64(((uint64_t)sp << 32) | (pos >> 9)) % rep) * rep_stride;
             if (!table_insert(tb, km, pay)) atomicAdd(fail, 1u);
             ++local;
         }
@@ -2317,14 +2318,17 @@ __global__ __launch_bounds__(64) void k4_lds_kernel(ClassifyArgs A) {
     }
 }
 
-template <bool NM, int TT>
+// LANES < 64: fewer reads per wave.  A wave runs as long as its slowest lane at every step of the nested loops, so at larger
+// tables half-filled waves finish sooner (and there are registers and scratch for all of them to be resident at once).
+template <bool NM, int TT, int LANES>
 __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     constexpr int LIN = TT == kK4T ? kK4T + 72 : TT + 8;
+    if ((int)threadIdx.x >= LANES) return;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
     const uint64_t n = *(const GAS uint32_t*)(g_cursor + A.k4_slot);  // 5: the large-table list, 8: up to 32 taxids, 6: reads an LDS/short kernel passed on
     const GAS uint32_t* list = (const GAS uint32_t*)(A.k4_slot == 5 ? A.k4_large : (A.k4_slot == 8 ? A.k4_mid : A.k4_bail));
-    const uint64_t stride = (uint64_t)gridDim.x * 64;
-    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * LANES;
+    for (uint64_t i = (uint64_t)blockIdx.x * LANES + threadIdx.x; i < n; i += stride) {
         const uint64_t it = list[i];
         uint16_t reg[TT], cnt[TT], dep[TT], tin[TT], tout[TT], ord[TT];
         uint8_t sflags[TT], nm_cl[NM ? TT : 1];
@@ -2503,12 +2507,15 @@ void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stre
     // the LDS tier of that size (2 waves per CU, a millisecond per pass) cannot offer.  LMAT_K4_MODE=1 runs it anyway.
     static const int mode = getenv("LMAT_K4_MODE") ? atoi(getenv("LMAT_K4_MODE")) : 0;
     if (a.nm.active) {
-        k4_kernel<true, kK4T><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+        k4_kernel<true, kK4T, 64><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
     } else if (mode == 1) {
         launch_k4_lds<kK4MidT>(a, a.count, stream2);
     } else {
         b.k4_slot = 8;
-        k4_kernel<false, kK4MidT><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+        const uint64_t cap = 256 * 32;
+        if (mode == 2) { const uint64_t w = (a.count + 15) / 16; k4_kernel<false, kK4MidT, 16><<<dim3((unsigned)(w < cap ? w : cap)), dim3(64), 0, stream2>>>(b); }
+        else if (mode == 3) { const uint64_t w = (a.count + 31) / 32; k4_kernel<false, kK4MidT, 32><<<dim3((unsigned)(w < cap ? w : cap)), dim3(64), 0, stream2>>>(b); }
+        else k4_kernel<false, kK4MidT, 64><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
     }
     hipEventRecord(joined, stream2);
     hipStreamWaitEvent(stream3, forked, 0);
@@ -2522,8 +2529,8 @@ void launch_k4_end(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream
     hipStreamWaitEvent(stream, joined, 0);
     ClassifyArgs b = a;
     b.k4_slot = 6;  // the few reads whose lineage outgrew a tier's block
-    if (a.nm.active) k4_kernel<true, kK4T><<<dim3(64), dim3(64), 0, stream>>>(b);
-    else k4_kernel<false, kK4T><<<dim3(64), dim3(64), 0, stream>>>(b);
+    if (a.nm.active) k4_kernel<true, kK4T, 64><<<dim3(64), dim3(64), 0, stream>>>(b);
+    else k4_kernel<false, kK4T, 64><<<dim3(64), dim3(64), 0, stream>>>(b);
 }
 
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>

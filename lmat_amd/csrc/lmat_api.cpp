@@ -540,6 +540,8 @@ int lmat_db_from_ingest(lmat_ctx* c, lmat_ingest* g, uint64_t table_bytes) {
 
 int lmat_db_kmer_length(const lmat_ctx* c) { return c ? c->dev.k : 0; }
 uint64_t lmat_db_size(const lmat_ctx* c) { return c ? c->n_kmers : 0; }
+uint64_t lmat_db_list_count(const lmat_ctx* c) { return c ? c->n_lists : 0; }
+uint64_t lmat_db_arena_bytes(const lmat_ctx* c) { return c ? c->arena_words * 2 : 0; }
 uint64_t lmat_db_table_bytes(const lmat_ctx* c) {
     return c ? ((c->dev.cpt.nb ? c->dev.cpt.nb : (uint64_t)c->dev.nbuckets) + c->dev.ovf_nbuckets) * 64 : 0;
 }
@@ -743,7 +745,7 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
     c->synth_genome_len = G;
     c->synth_seed = seed;
     c->synth_geo = geo;
-    c->n_lists = block_units ? (uint64_t)list_payload.size() : 0;
+    c->n_lists = (uint64_t)list_payload.size() * list_replicas;
     c->db_ready = true;
     return LMAT_OK;
 }

@@ -20,7 +20,7 @@ for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     pmc[ctr] = {k: {"dispatches": len(v), "mean_KiB_per_dispatch": sum(v) / len(v)} for k, v in agg.items()}
 bench = json.loads(open(f"{src}/kt_bench.json").read().strip().splitlines()[-1])
-cls = [k for k in pmc["FETCH_SIZE"] if "classify_kernel" in k][0]
+cls = max((k for k in pmc["FETCH_SIZE"] if "classify_kernel" in k), key=lambda k: pmc["FETCH_SIZE"][k]["mean_KiB_per_dispatch"])  # the fast class
 gat = [k for k in pmc["FETCH_SIZE"] if "gather_bench" in k]
 fetch = pmc["FETCH_SIZE"][cls]["mean_KiB_per_dispatch"] * 1024
 write = pmc["WRITE_SIZE"][cls]["mean_KiB_per_dispatch"] * 1024
