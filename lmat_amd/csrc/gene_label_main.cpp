@@ -6,6 +6,8 @@
 // hits a gene (:299-300), and the two summaries <o>.<x>.<q>.genesummary[.min_tax_score.<b>] joined against the annotation
 // table (:658-703).  The per-read work (retrieve_kmer_labels + the vote, :218-300) runs on the GPU through the C ABI: a
 // context opened with lmat_genedb_begin returns gene_label's vote from lmat_classify.
+// -R <list of gene_label output files, one per input file> replays an earlier run instead: every read's vote is taken from
+// those files (no database, no GPU) and the outputs and summaries are made again, e.g. under other thresholds.
 // -d takes the database in the tax_histo record format with 32-bit gene ids (what make_db_table ingests for a TID_SIZE=32
 // build), or a text file listing several; PERM heap images cannot be opened without perm-je.
 #include <getopt.h>
@@ -36,8 +38,8 @@ int main(int argc, char* argv[]) {
     signed char c;
     int n_threads = 0, k_size = -1, min_kmer = 0;
     float min_score = 0.0f, min_tax_score = 0.0f;
-    std::string genefile, kmer_db_fn, query_fn, query_fn_lst, ofbase;
-    while ((c = getopt(argc, argv, "b:h:n:jye:wmpk:c:v:k:i:d:l:t:s:r o:x:f:g:z:q:aV")) != -1) {
+    std::string genefile, kmer_db_fn, query_fn, query_fn_lst, ofbase, replay_lst;
+    while ((c = getopt(argc, argv, "b:h:n:jye:wmpk:c:v:k:i:d:l:t:s:r o:x:f:g:z:q:aVR:")) != -1) {
         switch (c) {
             case 'b': min_tax_score = atof(optarg); break;
             case 'g': genefile = optarg; break;
@@ -52,23 +54,48 @@ int main(int argc, char* argv[]) {
             case 'k': k_size = atoi(optarg); break;
             case 'i': query_fn = optarg; break;
             case 'd': kmer_db_fn = optarg; break;
+            case 'R': replay_lst = optarg; break;
             case 'o': ofbase = optarg; break;
             case 'V': std::cout << "LMAT version " << LMAT_VERSION << "\n"; exit(0);
             default: std::cout << "Unrecognized option: " << c << ", ignore." << std::endl;
         }
     }
-    if (ofbase == "" || kmer_db_fn == "") {
+    const bool replay = !replay_lst.empty();
+    if (ofbase == "" || (kmer_db_fn == "" && !replay)) {
         std::cout << "essential arguments missing: [" << ofbase << "] [" << n_threads << "] [" << kmer_db_fn << "] [" << query_fn << "] " << std::endl;
         usage(argv[0]);
         return -1;
     }
+    lmat_ctx* ctx = nullptr;
+    auto fail = [&](const char* what) { std::cerr << "ERROR! " << what << ": " << lmat_last_error(ctx) << std::endl; lmat_ctx_destroy(ctx); return -1; };
+    // replay: per input file, header -> (gene, votes, valid k-mers) as an earlier run printed them
+    struct Vote { uint32_t gid, top, cnt; };
+    std::vector<std::map<std::string, Vote>> votes;
+    if (replay) {
+        std::ifstream l(replay_lst.c_str());
+        std::string f, line;
+        while (l >> f) {
+            votes.emplace_back();
+            std::ifstream in(f.c_str());
+            if (!in) { std::cerr << "did not open for reading: [" << f << "]" << std::endl; return -1; }
+            while (std::getline(in, line)) {
+                const size_t p1 = line.find('\t'), p2 = line.find('\t', p1 + 1), p3 = line.find('\t', p2 + 1), p4 = line.find('\t', p3 + 1),
+                             p5 = line.find('\t', p4 + 1);
+                if (p5 == std::string::npos) continue;
+                Vote v = {0, 0, 0};
+                int minus1 = 0;
+                std::istringstream a(line.substr(p4 + 1, p5 - p4 - 1)), b(line.substr(p5 + 1));
+                a >> minus1 >> v.top >> v.cnt;
+                b >> v.gid;
+                votes.back()[line.substr(0, p1)] = v;
+            }
+        }
+    } else {
     std::cout << "Start kmer DB load\n";
     int device = 0;
     if (const char* d = getenv("LMAT_DEVICE")) device = atoi(d);
     lmat_params prm = {1.0f, 0.0f, 0.0f, 0, 0, 0, 0};
-    lmat_ctx* ctx = nullptr;
     if (lmat_ctx_create(device, &prm, &ctx) != LMAT_OK) { std::cerr << "ERROR! no usable HIP device (this build has no CPU path)" << std::endl; return -1; }
-    auto fail = [&](const char* what) { std::cerr << "ERROR! " << what << ": " << lmat_last_error(ctx) << std::endl; lmat_ctx_destroy(ctx); return -1; };
     std::vector<std::string> files;
     {   // a tax_histo-format file starts with its 29-byte header (64 one-bits at offset 12); anything else is a list of such files
         FILE* f = fopen(kmer_db_fn.c_str(), "rb");
@@ -94,6 +121,7 @@ int main(int argc, char* argv[]) {
     if (lmat_db_finalize(ctx) != LMAT_OK) return fail("gene DB");
     if (k_size < 1) k_size = lmat_db_kmer_length(ctx);
     std::cout << "num kmers: " << lmat_db_size(ctx) << " - " << k_size << std::endl;
+    }
     if (query_fn.length() > 0) { std::cout << "Sorry fasta input file not yet supported" << std::endl; exit(0); }
     std::vector<std::string> inputs;
     { std::ifstream ifs(query_fn_lst.c_str()); std::string s; while (ifs >> s) inputs.push_back(s); }
@@ -120,13 +148,27 @@ int main(int argc, char* argv[]) {
         std::vector<uint64_t> off(1, 0);
         auto flush = [&]() -> bool {
             if (recs.empty()) return true;
-            bases.push_back(0);
-            lmat_reads* dr = nullptr;
             std::vector<lmat_read_result> res(recs.size());
-            if (lmat_reads_upload(ctx, bases.data(), off.data(), recs.size(), &dr) != LMAT_OK) return false;
-            const int rc = lmat_classify(ctx, dr, 0, recs.size(), res.data(), nullptr, 0, nullptr);
-            lmat_reads_free(ctx, dr);
-            if (rc != LMAT_OK) return false;
+            if (replay) {
+                for (size_t i = 0; i < recs.size(); ++i) {
+                    res[i].status = LMAT_ST_NODBHITS;
+                    if (th >= votes.size()) continue;
+                    auto it = votes[th].find(recs[i].hdr);
+                    if (it == votes[th].end()) continue;
+                    res[i].status = LMAT_ST_CALL;
+                    res[i].call_tid = it->second.gid;
+                    res[i].n_cand = it->second.top;
+                    res[i].cand_kmer_cnt = (uint16_t)it->second.cnt;
+                    res[i].call_score = (float)it->second.top / (float)it->second.cnt;
+                }
+            } else {
+                bases.push_back(0);
+                lmat_reads* dr = nullptr;
+                if (lmat_reads_upload(ctx, bases.data(), off.data(), recs.size(), &dr) != LMAT_OK) return false;
+                const int rc = lmat_classify(ctx, dr, 0, recs.size(), res.data(), nullptr, 0, nullptr);
+                lmat_reads_free(ctx, dr);
+                if (rc != LMAT_OK) return false;
+            }
             std::string s;
             for (size_t i = 0; i < recs.size(); ++i) {
                 const lmat_read_result& r = res[i];

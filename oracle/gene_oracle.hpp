@@ -105,8 +105,11 @@ inline GeneCall label_read(const GeneDb& db, const char* str, int slen, int klen
 
 // main() of gene_label.cpp (:540-706) for `-l <list of read_label .out files>`: one "thread" per file, <ofbase><i>.out per
 // file, and the two summaries joined against the gene annotation table (-g, gzip).
-inline bool run_files(const GeneDb& db, const std::string& list_fn, const std::string& ofbase, const std::string& genefile,
-                      float min_score, int min_kmer, float min_tax_score, std::string* err) {
+// `label(file index, header, read)` stands for proc_line's lookup + vote (:269-300): the database for a real run, the votes
+// printed in an earlier run's output files for replay_files below.
+template <class Labeler>
+inline bool run_files_with(Labeler label, const std::string& list_fn, const std::string& ofbase, const std::string& genefile,
+                           float min_score, int min_kmer, float min_tax_score, std::string* err) {
     std::vector<std::string> files;
     { std::ifstream l(list_fn.c_str()); std::string f; while (l >> f) files.push_back(f); }
     const size_t nth = files.size();
@@ -141,7 +144,7 @@ inline bool run_files(const GeneDb& db, const std::string& list_fn, const std::s
             istrm >> taxid >> tax_score >> match_type;
             if (match_type[0] == 'N' || match_type[0] == 'R') taxid = 0;
             // proc_line :269-313
-            const GeneCall g = label_read(db, read_buff.c_str(), (int)read_buff.length(), db.k);
+            const GeneCall g = label(th, hdr, read_buff);
             // operator[] on the per-taxid maps happens before proc_line (:600-607): entries exist even when nothing is counted
             std::map<uint32_t, uint32_t>& gtrack = track[th][taxid];
             std::map<uint32_t, uint32_t>& gtrack_tax = track_tax[th][taxid];
@@ -195,6 +198,46 @@ inline bool run_files(const GeneDb& db, const std::string& list_fn, const std::s
     }
     gzclose(gz);
     return true;
+}
+inline bool run_files(const GeneDb& db, const std::string& list_fn, const std::string& ofbase, const std::string& genefile,
+                      float min_score, int min_kmer, float min_tax_score, std::string* err) {
+    return run_files_with([&](size_t, const std::string&, const std::string& read) { return label_read(db, read.c_str(), (int)read.length(), db.k); },
+                          list_fn, ofbase, genefile, min_score, min_kmer, min_tax_score, err);
+}
+// The same run with every read's vote taken from the output files of an earlier gene_label run (`gl_list_fn`: one per input
+// file, same order) instead of a database: the line is "hdr \t read \t tid score \t \t -1 top cnt \t gid gscore GL"
+// (:299-300).  The reference's example run (example/example.tgz) is replayed this way by the tests.
+inline bool replay_files(const std::string& list_fn, const std::string& gl_list_fn, const std::string& ofbase, const std::string& genefile,
+                         float min_score, int min_kmer, float min_tax_score, std::string* err) {
+    std::vector<std::map<std::string, GeneCall>> votes;
+    std::ifstream l(gl_list_fn.c_str());
+    std::string f;
+    while (l >> f) {
+        votes.emplace_back();
+        std::ifstream in(f.c_str());
+        if (!in) { if (err) *err = "did not open for reading: " + f; return false; }
+        std::string line;
+        while (std::getline(in, line)) {
+            const size_t p1 = line.find('\t'), p2 = line.find('\t', p1 + 1), p3 = line.find('\t', p2 + 1), p4 = line.find('\t', p3 + 1),
+                         p5 = line.find('\t', p4 + 1);
+            if (p5 == std::string::npos) continue;
+            GeneCall g;
+            int minus1 = 0;
+            std::istringstream a(line.substr(p4 + 1, p5 - p4 - 1)), b(line.substr(p5 + 1));
+            a >> minus1 >> g.top >> g.cnt;
+            b >> g.gid;
+            g.any = true;
+            g.score = (float)g.top / (float)g.cnt;
+            votes.back()[line.substr(0, p1)] = g;
+        }
+    }
+    return run_files_with([&](size_t th, const std::string& hdr, const std::string&) {
+        GeneCall none;
+        none.any = false;
+        if (th >= votes.size()) return none;
+        auto it = votes[th].find(hdr);
+        return it == votes[th].end() ? none : it->second;
+    }, list_fn, ofbase, genefile, min_score, min_kmer, min_tax_score, err);
 }
 
 }  // namespace gene_oracle

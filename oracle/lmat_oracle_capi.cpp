@@ -323,5 +323,10 @@ int orc_gene_run(void* g, const char* list_fn, const char* ofbase, const char* g
     std::string e;
     return gene_oracle::run_files(*(gene_oracle::GeneDb*)g, list_fn, ofbase, genefile, min_score, min_kmer, min_tax_score, &e) ? 0 : -1;
 }
+int orc_gene_replay(const char* list_fn, const char* gl_list_fn, const char* ofbase, const char* genefile, float min_score, int min_kmer,
+                    float min_tax_score) {
+    std::string e;
+    return gene_oracle::replay_files(list_fn, gl_list_fn, ofbase, genefile, min_score, min_kmer, min_tax_score, &e) ? 0 : -1;
+}
 
 }  // extern "C"

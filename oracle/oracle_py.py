@@ -68,9 +68,16 @@ def _load():
     L.orc_gene_lookup.argtypes = [vp, u64, vp, i32]
     L.orc_gene_label.argtypes = [vp, vp, vp, C.c_long, i32, vp, vp, vp, vp, vp]
     L.orc_gene_run.argtypes = [vp, cp, cp, cp, C.c_float, i32, C.c_float]
+    L.orc_gene_replay.argtypes = [cp, cp, cp, cp, C.c_float, i32, C.c_float]
     L.orc_replay_decision.argtypes = [vp, vp, vp, i32, C.c_float, vp, vp, vp]
     L.orc_run_file.argtypes = [vp, cp, i32, cp, vp, C.c_long, vp, C.c_long]
     return L
+
+
+def gene_replay(list_fn, gl_list_fn, ofbase, genefile, min_score=0.0, min_kmer=0, min_tax_score=0.0):
+    """gene_oracle::replay_files: gene_label's main() with every read's vote taken from an earlier run's output files."""
+    if _load().orc_gene_replay(list_fn.encode(), gl_list_fn.encode(), ofbase.encode(), genefile.encode(), min_score, min_kmer, min_tax_score) != 0:
+        raise RuntimeError("gene oracle: replay failed")
 
 
 class GeneOracle:

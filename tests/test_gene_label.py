@@ -108,3 +108,54 @@ def test_gene_label_tool_matches_oracle(tmp_path):
         w, g = open(str(tmp_path / "want") + nme).read(), open(str(tmp_path / "got") + nme).read()
         assert w == g, nme
     assert len(open(str(tmp_path / "got") + "0.out").read()) > 20000 and len(open(str(tmp_path / "got") + names[2]).read()) > 300
+
+
+# ---- the reference's own example run of gene_label (example/example.tgz), replayed -------------------------------------------
+def _example_gene(tmp_path):
+    import tarfile
+    d = str(tmp_path / "ex")
+    tarfile.open(os.path.join(ROOT, "tests", "golden", "example_gene.tar.gz")).extractall(d)
+    with open(os.path.join(d, "genes.tbl"), "rb") as f, gzip.open(os.path.join(d, "genes.tbl.gz"), "wb") as g:
+        g.write(f.read())
+    for name, pat in (("rl.lst", "rl%d.out"), ("gl.lst", "gl%d.out")):
+        with open(os.path.join(d, name), "w") as f:
+            f.write("".join(os.path.join(d, pat % i) + "\n" for i in range(8)))
+    return d
+
+
+def test_gene_oracle_replays_reference_example(tmp_path):
+    """gene_label's main() -- which read_label records are read and how (taxid, its score, the ReadTooShort / NoDbHits rules),
+    the output line, the thresholds -x 0.1 -q 20 -b 0, the per-file tallies and their merge, the float sums and their printed
+    averages, the join against the annotation table -- restated in oracle/gene_oracle.hpp and run on the eight read_label
+    files of the reference's example with every read's vote (gene, votes, valid k-mers) taken from the example's own output:
+    all eight output files and both summaries come out byte for byte (the first summary after the sort bin/run_gl.sh applies
+    to it).  (The votes themselves need the 10.8 G k-mer gene
+    database of that run.)"""
+    from oracle.oracle_py import gene_replay
+    d = _example_gene(tmp_path)
+    base = os.path.join(d, "replay")
+    gene_replay(os.path.join(d, "rl.lst"), os.path.join(d, "gl.lst"), base, os.path.join(d, "genes.tbl.gz"), 0.1, 20, 0.0)
+    for i in range(8):
+        assert open(base + "%d.out" % i, "rb").read() == open(os.path.join(d, "gl%d.out" % i), "rb").read(), i
+    assert open(base + ".0.1.20.genesummary.min_tax_score.0", "rb").read() == open(os.path.join(d, "genesummary_tax"), "rb").read()
+    # bin/run_gl.sh:160-161 sorts the first summary afterwards; the example holds it sorted
+    srt = subprocess.run(["sort", "-k1gr,1gr", base + ".0.1.20.genesummary"], env=dict(os.environ, LC_ALL="C"), stdout=subprocess.PIPE, check=True).stdout
+    assert srt == open(os.path.join(d, "genesummary"), "rb").read()
+
+
+def test_gene_label_tool_replays_reference_example(tmp_path):
+    """The gene_label-compatible tool in replay mode (-R: votes from an earlier run's output files; no database, no GPU):
+    its own reader, writer, tallies and summaries reproduce the reference's example run byte for byte."""
+    if not os.path.exists(EXE):
+        pytest.skip("gene_label tool not built")
+    d = _example_gene(tmp_path)
+    base = os.path.join(d, "tool")
+    r = subprocess.run([EXE, "-R", os.path.join(d, "gl.lst"), "-l", os.path.join(d, "rl.lst"), "-g", os.path.join(d, "genes.tbl.gz"),
+                        "-o", base, "-x", "0.1", "-q", "20", "-b", "0", "-p"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "set threads=8" in r.stdout and "query time:" in r.stdout  # the log lines of the example's .log
+    for i in range(8):
+        assert open(base + "%d.out" % i, "rb").read() == open(os.path.join(d, "gl%d.out" % i), "rb").read(), i
+    assert open(base + ".0.1.20.genesummary.min_tax_score.0", "rb").read() == open(os.path.join(d, "genesummary_tax"), "rb").read()
+    srt = subprocess.run(["sort", "-k1gr,1gr", base + ".0.1.20.genesummary"], env=dict(os.environ, LC_ALL="C"), stdout=subprocess.PIPE, check=True).stdout
+    assert srt == open(os.path.join(d, "genesummary"), "rb").read()
