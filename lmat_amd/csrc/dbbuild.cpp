@@ -54,10 +54,83 @@ bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string&
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
     if (ids.size() > 65534) {
-        err = "the taxonomy has " + std::to_string(ids.size()) + " nodes; without a 32->16 map (-f) the engine takes at most 65534";
+        err = "the taxonomy has " + std::to_string(ids.size()) + " nodes; without a 32->16 map (-f) the engine takes at most 65534 (make_db_image -t <tree> -M <map> makes one from the database itself)";
         return false;
     }
     return true;
+}
+
+bool idmap_from_database(const std::vector<std::string>& files, const char* tree_fn, uint32_t adaptor_tid,
+                         std::vector<std::pair<uint32_t, uint16_t>>& out, std::string& err) {
+    std::unordered_map<uint32_t, uint32_t> parent;
+    {   // "id nchild child.. parent" / name line pairs after three header lines (TaxTree.hpp:24-57)
+        FILE* f = fopen(tree_fn, "r");
+        if (!f) { err = std::string("failed to open ") + tree_fn + " for reading"; return false; }
+        char* line = nullptr;
+        size_t cap = 0;
+        for (int i = 0; i < 3; ++i) if (getline(&line, &cap, f) < 0) break;
+        while (getline(&line, &cap, f) >= 0) {
+            uint32_t first = 0, last = 0;
+            int n = 0;
+            for (char* p = line;;) {
+                char* e = nullptr;
+                const unsigned long long v = strtoull(p, &e, 10);
+                if (e == p) break;
+                if (!n++) first = (uint32_t)v;
+                last = (uint32_t)v;
+                p = e;
+            }
+            if (n >= 3) parent[first] = last;
+            if (getline(&line, &cap, f) < 0) break;  // name
+        }
+        free(line);
+        fclose(f);
+    }
+    std::unordered_set<uint32_t> used;
+    for (uint32_t special : {1u, 9606u, adaptor_tid ? adaptor_tid : 32630u})
+        if (parent.count(special)) used.insert(special);
+    std::vector<uint32_t> tids;
+    for (auto& fn : files) {
+        FILE* in = fopen(fn.c_str(), "rb");
+        if (!in) { err = "Error: unable to open kmer db [" + fn + "]"; return false; }
+        uint32_t data_start, version, klen;
+        uint64_t kmer_count, test;
+        char loc;
+        bool ok = fread(&data_start, 4, 1, in) == 1 && fread(&kmer_count, 8, 1, in) == 1 && fread(&test, 8, 1, in) == 1 &&
+                  fread(&version, 4, 1, in) == 1 && fread(&loc, 1, 1, in) == 1 && fread(&klen, 4, 1, in) == 1;
+        if (!ok || test != ~0ull || version != 999 || loc != 'N') { fclose(in); err = "not a tax_histo file: " + fn; return false; }
+        for (uint64_t i = 0; i < kmer_count; ++i) {
+            uint64_t kmer;
+            uint16_t n;
+            if (fread(&kmer, 8, 1, in) != 1) break;  // a short file ends the scan as it ends the ingest
+            if (fread(&n, 2, 1, in) != 1) { fclose(in); err = "truncated tax_histo record"; return false; }
+            tids.resize(n);
+            if (n && fread(tids.data(), 4, n, in) != n) { fclose(in); err = "truncated taxid list"; return false; }
+            for (uint32_t t : tids) used.insert(t);
+            if ((i + 1) % 1500 == 0 && (fread(&test, 8, 1, in) != 1 || test != ~0ull)) { fclose(in); err = "tax_histo sanity word missing"; return false; }
+        }
+        fclose(in);
+    }
+    std::vector<uint32_t> all(used.begin(), used.end());
+    for (size_t i = 0; i < all.size(); ++i) {  // ancestors; a node that is its own parent ends the walk (TaxTree.hpp:60-91)
+        auto it = parent.find(all[i]);
+        if (it != parent.end() && it->second != all[i] && used.insert(it->second).second) all.push_back(it->second);
+    }
+    if (all.size() > 65534) {
+        err = "the database's taxids and their ancestors are " + std::to_string(all.size()) + " ids; the engine's ids are 16 bits wide (at most 65534)";
+        return false;
+    }
+    std::sort(all.begin(), all.end());
+    out.clear();
+    for (size_t i = 0; i < all.size(); ++i) out.push_back(std::make_pair(all[i], (uint16_t)(i + 1)));
+    return true;
+}
+
+bool save_idmap(const std::vector<std::pair<uint32_t, uint16_t>>& map, const char* fn) {
+    FILE* f = fopen(fn, "w");
+    if (!f) return false;
+    for (auto& m : map) fprintf(f, "%u %u\n", m.first, (unsigned)m.second);  // "src dest" pairs, make_db_table.cpp:259-273
+    return fclose(f) == 0;
 }
 
 bool Ingest::idmap_from_tree(const char* tree_fn) {

@@ -23,6 +23,14 @@ namespace lmat {
 // canonical payload: 1..65535 = the 16-bit DB taxid of a one-element list; 65536 + i = lists[i]
 bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string& err);  // sorted, unique, <= 65534
 
+// The 32->16 map of a database made from its own content, for taxonomies of more than 65534 nodes (a TID_SIZE=32 build of the
+// reference needs no map; this engine's ids are 16 bits wide): every taxid the tax_histo files hold, 1 / 9606 / the adaptor
+// id where the tree has them (what the ingest options add), and all their ancestors in the tree, numbered from 1 in
+// ascending order.  Fails when that closure has more than 65534 ids.  save_idmap writes the reference's -f file format.
+bool idmap_from_database(const std::vector<std::string>& taxhisto_files, const char* tree_fn, uint32_t adaptor_tid,
+                         std::vector<std::pair<uint32_t, uint16_t>>& out, std::string& err);
+bool save_idmap(const std::vector<std::pair<uint32_t, uint16_t>>& map, const char* fn);
+
 struct Ingest {
     int k = 0;
     bool raw32 = false;  // gene databases (gene_label): 32-bit ids stored as they come, two u16 (low, high) per id, no options

@@ -1494,7 +1494,6 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         uint32_t* gval = (uint32_t*)best;     // registration slot of that gene; 0x80000000 | lane while a chunk decides; 0xFFFFFFFF = none yet
         uint32_t* greg = (uint32_t*)reg;      // [T] gene id per slot (reg + stamp)
         uint32_t* gcnt = (uint32_t*)cnt;      // [T] votes per slot (cnt + leaf)
-        uint32_t* el_gid = el_poff;           // [E]
         uint16_t* gord = (uint16_t*)(lds + L::OFF_R2 + ((11 * L::D + 1) & ~1));  // [T] sort order, behind the d-arrays
         const GAS uint16_t* arena = g_arena;
         uint32_t nel = 0;

@@ -129,3 +129,41 @@ def test_runtime_pruning_matches_reference_taxnodestat(tag, ranks):
         pruned += want != plain[km]
     assert pruned > 3000
     o.close()
+
+
+def _big_tree(tmp_path, extra=70000):
+    """The fixture taxonomy with `extra` unrelated nodes under the root: more nodes than 16-bit ids can number."""
+    src = open(os.path.join(DS, "tax.dat")).read().split("\n")
+    head, body = src[:3], [l for l in src[3:]]
+    big = str(tmp_path / "tax_big.dat")
+    with open(big, "w") as f:
+        f.write("\n".join(head) + "\n")
+        f.write("\n".join(l for l in body if l != "") + "\n")
+        for i in range(extra):
+            f.write("%d 0 1\nfiller node %d\n" % (900000000 + i, i))
+    return big
+
+
+def test_map_from_database_for_a_taxonomy_above_16_bits(tmp_path):
+    """A database of 32-bit taxids under a taxonomy of more than 65534 nodes (the reference's TID_SIZE=32 build): numbering the
+    tree's nodes cannot work, so make_db_image -M makes the 32->16 map from the database's own taxids and their ancestors.
+    Decoded through that map, the stored lists are the ones the reference's add_data stores."""
+    exe = os.path.join(ROOT, "lmat_amd", "csrc", "make_db_image")
+    big = _big_tree(tmp_path)
+    img, mp = str(tmp_path / "t.img"), str(tmp_path / "derived_map.txt")
+    base = [exe, "-i", os.path.join(DS, "th.bin"), "-o", img, "-k", "20", "-t", big]
+    r = subprocess.run(base, capture_output=True, text=True)
+    assert r.returncode != 0 and "65534" in r.stderr  # the tree alone is too large to number
+    r = subprocess.run(base + ["-M", mp, "-g", "2", "-m", OPTS["rank_map"], "-j", OPTS["human_kmers"], "-u", OPTS["adaptor_kmers"]],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    conv = {}
+    for line in open(mp):
+        a, b = line.split()
+        conv[int(b)] = int(a)
+    assert 0 < len(conv) < 65535 and not any(t >= 900000000 for t in conv.values())  # only ids the database can reach
+    from lmat_amd import Ingest
+    back = Ingest(image=img)
+    for km, want in _golden("ref_lookup_opts.txt")[::7]:
+        assert [conv[t] for t in back.lookup(km)] == want
+    back.close()

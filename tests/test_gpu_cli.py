@@ -215,3 +215,24 @@ def test_cli_accepts_the_argv_run_rl_sh_builds(tmp_path, case):
     assert open(sbase + ".fastsummary").read() == fs
     assert open(sbase + ".nomatchsum").read() == nm
     assert len(want) > 50000
+
+
+def test_cli_with_a_taxonomy_above_16_bits(small_dataset, tmp_path):
+    """A taxonomy of more than 65534 nodes (70 000 unrelated nodes added under the root) with the 32->16 map that
+    make_db_image -M derives from the database's own taxids: read_label writes the files of the run on the plain taxonomy."""
+    ds = small_dataset
+    _run_cli(ds, str(tmp_path / "a"), ds["fasta"], 1)
+    big = str(tmp_path / "tax_big.dat")
+    lines = [l for l in open(ds["tree"]).read().split("\n")]
+    with open(big, "w") as f:
+        f.write("\n".join(lines[:3]) + "\n" + "\n".join(l for l in lines[3:] if l != "") + "\n")
+        for i in range(70000):
+            f.write("%d 0 1\nfiller node %d\n" % (900000000 + i, i))
+    mp, img = str(tmp_path / "derived_map.txt"), str(tmp_path / "db.img")
+    r = subprocess.run([os.path.join(ROOT, "lmat_amd", "csrc", "make_db_image"), "-i", ds["db"], "-o", img, "-k", "20", "-t", big, "-M", mp],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    big_ds = dict(ds, tree=big, idmap=mp, db=img)
+    _run_cli(big_ds, str(tmp_path / "b"), ds["fasta"], 1)
+    for suffix in ("0.out", ".0.30.fastsummary", ".0.30.nomatchsum"):
+        assert open(str(tmp_path / "a") + suffix).read() == open(str(tmp_path / "b") + suffix).read(), suffix
