@@ -2,6 +2,7 @@
 // reference uses decides the order of equal-rank taxids during pruning.
 #include "dbbuild.hpp"
 #include <algorithm>
+#include <new>
 #include <cstring>
 #include <queue>
 
@@ -355,60 +356,96 @@ bool Ingest::save_image(const char* fn) const {
     return fclose(f) == 0 && ok;
 }
 
+// An image comes from a file the user names: sizes are checked against the file before anything is allocated, and every
+// k-mer / payload against what the engine assumes (keys of 2k bits, ascending; payloads that are a taxid or an existing list).
+namespace {
+bool image_header(FILE* f, uint32_t& kk, uint64_t& n, uint64_t& nl, std::string& err) {
+    char magic[8];
+    if (!(fread(magic, 8, 1, f) == 1 && memcmp(magic, "LMATIMG1", 8) == 0 && fread(&kk, 4, 1, f) == 1 && fread(&n, 8, 1, f) == 1 &&
+          fread(&nl, 8, 1, f) == 1)) { err = "malformed database image"; return false; }
+    fseek(f, 0, SEEK_END);
+    const uint64_t fsz = (uint64_t)ftell(f);
+    fseek(f, 28, SEEK_SET);
+    if (kk < 1 || kk > 32 || n > fsz / 12 || nl > fsz / 4 || 28 + 12 * n + 4 * nl > fsz) { err = "malformed database image (sizes exceed the file)"; return false; }
+    return true;
+}
+bool read_lists(FILE* f, uint64_t nl, std::vector<std::vector<uint16_t>>& lists, uint64_t fsz_left) {
+    lists.resize(nl);
+    for (uint64_t i = 0; i < nl; ++i) {
+        uint32_t m;
+        if (fread(&m, 4, 1, f) != 1 || (uint64_t)m * 2 > fsz_left) return false;
+        lists[i].resize(m);
+        if (m && fread(lists[i].data(), 2, m, f) != m) return false;
+        fsz_left -= (uint64_t)m * 2;
+    }
+    return true;
+}
+bool check_chunk(const std::vector<uint64_t>& km, const std::vector<uint32_t>& pay, int k, uint64_t nl, uint64_t& last) {
+    for (size_t i = 0; i < km.size(); ++i) {
+        if ((k < 32 && (km[i] >> (2 * k))) || (last != ~0ull && km[i] <= last)) return false;
+        if (pay[i] >= 65536u && pay[i] - 65536u >= nl) return false;
+        last = km[i];
+    }
+    return true;
+}
+}  // namespace
+
 bool Ingest::load_image(const char* fn) {
     FILE* f = fopen(fn, "rb");
     if (!f) { err = std::string("cannot open image ") + fn; return false; }
-    char magic[8];
-    uint32_t kk;
-    uint64_t n, nl;
-    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "LMATIMG1", 8) == 0 && fread(&kk, 4, 1, f) == 1 &&
-              fread(&n, 8, 1, f) == 1 && fread(&nl, 8, 1, f) == 1;
-    if (ok) {
-        k = (int)kk;
-        kmers.resize(n);
-        payload.resize(n);
-        if (n) ok = fread(kmers.data(), 8, n, f) == n && fread(payload.data(), 4, n, f) == n;
-        lists.resize(nl);
-        for (uint64_t i = 0; i < nl && ok; ++i) {
-            uint32_t m;
-            ok = fread(&m, 4, 1, f) == 1;
-            if (ok) { lists[i].resize(m); ok = m == 0 || fread(lists[i].data(), 2, m, f) == m; }
+    uint32_t kk = 0;
+    uint64_t n = 0, nl = 0;
+    bool ok = image_header(f, kk, n, nl, err);
+    try {
+        if (ok) {
+            k = (int)kk;
+            kmers.resize(n);
+            payload.resize(n);
+            if (n) ok = fread(kmers.data(), 8, n, f) == n && fread(payload.data(), 4, n, f) == n;
+            const long here = ftell(f);
+            fseek(f, 0, SEEK_END);
+            const uint64_t left = (uint64_t)(ftell(f) - here);
+            fseek(f, here, SEEK_SET);
+            ok = ok && read_lists(f, nl, lists, left);
+            uint64_t last = ~0ull;
+            ok = ok && check_chunk(kmers, payload, k, nl, last);
         }
-    }
+    } catch (const std::bad_alloc&) { ok = false; }
     fclose(f);
-    if (!ok) err = "malformed database image";
-    else if (n) last_kmer = kmers.back();
+    if (!ok && err.empty()) err = "malformed database image";
+    else if (ok && n) last_kmer = kmers.back();
     return ok;
 }
 
 bool Ingest::load_image_streaming(const char* fn, uint64_t* n_kmers) {
     FILE* f = fopen(fn, "rb");
     if (!f) { err = std::string("cannot open image ") + fn; return false; }
-    char magic[8];
-    uint32_t kk;
+    uint32_t kk = 0;
     uint64_t n = 0, nl = 0;
-    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, "LMATIMG1", 8) == 0 && fread(&kk, 4, 1, f) == 1 &&
-              fread(&n, 8, 1, f) == 1 && fread(&nl, 8, 1, f) == 1;
+    bool ok = image_header(f, kk, n, nl, err);
     const long base = 28;
-    if (ok) {
-        k = (int)kk;
-        ok = fseek(f, base + (long)(12 * n), SEEK_SET) == 0;  // the lists sit behind the two arrays
-        lists.resize(nl);
-        for (uint64_t i = 0; i < nl && ok; ++i) {
-            uint32_t m;
-            ok = fread(&m, 4, 1, f) == 1;
-            if (ok) { lists[i].resize(m); ok = m == 0 || fread(lists[i].data(), 2, m, f) == m; }
+    try {
+        if (ok) {
+            k = (int)kk;
+            ok = fseek(f, base + (long)(12 * n), SEEK_SET) == 0;  // the lists sit behind the two arrays
+            const long here = ftell(f);
+            fseek(f, 0, SEEK_END);
+            const uint64_t left = (uint64_t)(ftell(f) - here);
+            fseek(f, here, SEEK_SET);
+            ok = ok && read_lists(f, nl, lists, left);
         }
-    }
-    const uint64_t chunk = flush_every ? flush_every : (1ull << 24);
-    for (uint64_t s = 0; s < n && ok; s += chunk) {
-        const uint64_t m = std::min(chunk, n - s);
-        kmers.resize(m);
-        payload.resize(m);
-        ok = fseek(f, base + (long)(8 * s), SEEK_SET) == 0 && fread(kmers.data(), 8, m, f) == m &&
-             fseek(f, base + (long)(8 * n + 4 * s), SEEK_SET) == 0 && fread(payload.data(), 4, m, f) == m;
-        if (ok && flush) ok = flush(*this);
-    }
+        const uint64_t chunk = flush_every ? flush_every : (1ull << 24);
+        uint64_t last = ~0ull;
+        for (uint64_t s = 0; s < n && ok; s += chunk) {
+            const uint64_t m = std::min(chunk, n - s);
+            kmers.resize(m);
+            payload.resize(m);
+            ok = fseek(f, base + (long)(8 * s), SEEK_SET) == 0 && fread(kmers.data(), 8, m, f) == m &&
+                 fseek(f, base + (long)(8 * n + 4 * s), SEEK_SET) == 0 && fread(payload.data(), 4, m, f) == m &&
+                 check_chunk(kmers, payload, k, nl, last);
+            if (ok && flush) ok = flush(*this);
+        }
+    } catch (const std::bad_alloc&) { ok = false; }
     fclose(f);
     if (!ok && err.empty()) err = "malformed database image";
     if (n_kmers) *n_kmers = n;

@@ -167,3 +167,38 @@ def test_map_from_database_for_a_taxonomy_above_16_bits(tmp_path):
     for km, want in _golden("ref_lookup_opts.txt")[::7]:
         assert [conv[t] for t in back.lookup(km)] == want
     back.close()
+
+
+def test_corrupt_images_are_refused(tmp_path):
+    """A database image is a file the user names: header sizes beyond the file, a payload that points past the lists, k-mers
+    out of order or wider than 2k bits end in an error from the loader, not in an out-of-bounds access or an uncaught
+    allocation failure."""
+    import struct
+    from lmat_amd import Ingest
+    ing = Ingest(20, os.path.join(DS, "map32to16.txt"))
+    ing.add_taxhisto(os.path.join(DS, "th.bin"))
+    img = str(tmp_path / "ok.img")
+    ing.save_image(img)
+    n = len(ing)
+    ing.close()
+    raw = bytearray(open(img, "rb").read())
+    magic, k, nk, nl = raw[:8], *struct.unpack_from("<IQQ", raw, 8)
+    assert magic == b"LMATIMG1" and k == 20 and nk == n
+
+    def refused(mut):
+        bad = bytearray(raw)
+        mut(bad)
+        fn = str(tmp_path / "bad.img")
+        open(fn, "wb").write(bad)
+        with pytest.raises(Exception):
+            Ingest(image=fn)
+
+    refused(lambda b: struct.pack_into("<Q", b, 12, 1 << 60))                        # k-mer count beyond the file
+    refused(lambda b: struct.pack_into("<Q", b, 20, 1 << 60))                        # list count beyond the file
+    refused(lambda b: struct.pack_into("<I", b, 28 + 8 * nk, 65536 + nl + 5))        # payload past the lists
+    refused(lambda b: struct.pack_into("<Q", b, 28 + 8, struct.unpack_from("<Q", b, 28)[0]))  # k-mers not ascending
+    refused(lambda b: struct.pack_into("<Q", b, 28 + 8 * (nk - 1), 1 << 50))         # key wider than 2k bits
+    refused(lambda b: b.__delitem__(slice(len(b) - 100, len(b))))                    # truncated
+    back = Ingest(image=img)  # the untouched image still loads
+    assert len(back) == n
+    back.close()
