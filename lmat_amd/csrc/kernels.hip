@@ -894,6 +894,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     const GAS uint64_t* g_paths8 = (const GAS uint64_t*)tb.paths8;
     const GAS u32x4* g_facts16 = (const GAS u32x4*)tb.facts16;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    GAS uint32_t* g_err = (GAS uint32_t*)A.err;  // sticky error flags, shared by all launches
     // record words were prefetched by the caller: lane l holds word l + 64*j in wcur[j] (word 0 = length)
     const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)wcur[0]);
     // The result record is assembled from wave-uniform scalars at each exit: a struct kept live from here on
@@ -923,7 +924,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane == 0) {
             emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by a larger class
-            else G_OR(&g_cursor[1], (uint32_t)kErrReadTooLong);
+            else G_OR(g_err, (uint32_t)kErrReadTooLong);
         }
         return;
     }
@@ -1438,7 +1439,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane == 0) {
             emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;
-            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+            else G_OR(g_err, (uint32_t)kErrTidOverflow);
         }
         return;
     }
@@ -1561,7 +1562,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             if (lane == 0) {
                 emit(255, 0);
                 if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;
-                else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+                else G_OR(g_err, (uint32_t)kErrTidOverflow);
             }
             return;
         }
@@ -1640,7 +1641,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane == 0) {
             emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
-            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+            else G_OR(g_err, (uint32_t)kErrTidOverflow);
         }
         return;
     }
@@ -1707,7 +1708,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane == 0) {
             emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
-            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+            else G_OR(g_err, (uint32_t)kErrTidOverflow);
         }
         return;
     }
@@ -1977,7 +1978,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (lane == 0) {
             emit(255, 0);
             if (A.ovf_list) ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;  // re-run by the large-capacity kernel
-            else G_OR(&g_cursor[1], (uint32_t)kErrTidOverflow);
+            else G_OR(g_err, (uint32_t)kErrTidOverflow);
         }
         return;
     }
@@ -2043,7 +2044,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
             const int nb = ((const GAS int*)A.nm.nbins)[nmt];
             const int bin = res.bin_sel < nb ? res.bin_sel : nb - 1;
-            if (cl == 0xFF) G_OR(&g_cursor[1], (uint32_t)kErrNoNullModel);
+            if (cl == 0xFF) G_OR(g_err, (uint32_t)kErrNoNullModel);
             nm_cl[s] = cl == 0xFF ? 0 : cl;
             nm_rp[s] = (float)((double)((const GAS float*)A.nm.val)[row * A.nm.nb_max + bin] + 0.0001);
         }
@@ -2072,7 +2073,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             high_tout = tout[highest];
             const uint32_t alen = g_path_len[high_tid], aoff = g_path_off[high_tid];
             uint32_t room = (uint32_t)L::LIN - (uint32_t)nlin;
-            if (alen > room) { if (lane == 0) G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); }
+            if (alen > room) { if (lane == 0) G_OR(g_err, (uint32_t)kErrLineageTrunc); }
             const uint32_t take = alen < room ? alen : room;
             for (uint32_t j0 = 0; j0 < take; j0 += 64) {
                 const uint32_t j = j0 + lane;
@@ -2098,7 +2099,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 const uint32_t reserve = A.prm.prn_all ? nT : (uint32_t)nlin;  // -p: the candidates; else the lineage as built (:917-927)
                 coff = G_ADD(&g_cursor[0], reserve);
                 if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
-                else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
+                else G_OR(g_err, (uint32_t)kErrCandOverflow);
             }
             k4_part2<L::LIN>(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
                      high_tout, cout_, &ncand, &call_idx);
@@ -2141,6 +2142,7 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
     const GAS uint64_t* g_paths8 = (const GAS uint64_t*)tb.paths8;
     const GAS u32x4* g_facts16 = (const GAS u32x4*)tb.facts16;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    GAS uint32_t* g_err = (GAS uint32_t*)A.err;  // sticky error flags, shared by all launches
     GAS unsigned long long* tally_count = (GAS unsigned long long*)A.counts;
     GAS double* tally_score = (GAS double*)(tally_count + tb.n_ids);
     GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + tb.n_ids);
@@ -2186,7 +2188,7 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
             const uint8_t cl = ((const GAS uint8_t*)A.nm.cls)[row];
             const int nb = ((const GAS int*)A.nm.nbins)[nmt];
             const int bin = res.bin_sel < nb ? res.bin_sel : nb - 1;
-            if (cl == 0xFF) G_OR(&g_cursor[1], (uint32_t)kErrNoNullModel);
+            if (cl == 0xFF) G_OR(g_err, (uint32_t)kErrNoNullModel);
             nm_cl[s] = cl == 0xFF ? 0 : cl;
             nm_rp[s] = (float)((double)((const GAS float*)A.nm.val)[row * A.nm.nb_max + bin] + 0.0001);
         }
@@ -2215,7 +2217,7 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j0 + j < alen && !trunc) {
-                        if (nlin >= LIN) { G_OR(&g_cursor[1], (uint32_t)kErrLineageTrunc); trunc = true; }
+                        if (nlin >= LIN) { G_OR(g_err, (uint32_t)kErrLineageTrunc); trunc = true; }
                         else {
                             const uint64_t pe = pes[j];
                             const uint32_t a = (uint32_t)(pe & 0xFFFFu);
@@ -2237,7 +2239,7 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
             const uint32_t reserve = A.prm.prn_all ? (uint32_t)nT : (uint32_t)nlin;  // -p: the candidates; else the lineage as built
             coff = G_ADD(&g_cursor[0], reserve);
             if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
-            else G_OR(&g_cursor[1], (uint32_t)kErrCandOverflow);
+            else G_OR(g_err, (uint32_t)kErrCandOverflow);
         }
         k4_part2<LIN>(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, cout_,
                  &ncand, &call_idx);
@@ -2486,11 +2488,13 @@ static void launch_k4_lds(const ClassifyArgs& a, uint64_t max_reads, hipStream_t
     const uint64_t per_cu = 160 * 1024 / K::BYTES;
     uint64_t g = (max_reads + K::LANES - 1) / K::LANES;
     if (g > 256 * per_cu) g = 256 * per_cu;
+    static const int gcap = getenv("LMAT_K4_SMALL_GRID") ? atoi(getenv("LMAT_K4_SMALL_GRID")) : 0;  // experiments
+    if (TT == kK4SmallT && gcap > 0 && g > (uint64_t)gcap) g = gcap;
     if (g < 1) g = 1;
     k4_lds_kernel<TT><<<dim3((unsigned)g), dim3(64), K::BYTES, stream>>>(a);
 }
-void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked,
-                     hipEvent_t joined) {
+void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipStream_t small_stream,
+                     hipEvent_t forked) {
     uint64_t blocks = (a.count + 4095) / 4096;  // a wave takes 1024 reads per pass
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
@@ -2502,6 +2506,9 @@ void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stre
     const uint64_t waves = (a.count + 63) / 64;
     uint64_t g2 = waves < 256 * 32 ? waves : 256 * 32;
     if (g2 < 1) g2 = 1;
+    static const int g2cap = getenv("LMAT_K4_MID_GRID") ? atoi(getenv("LMAT_K4_MID_GRID")) : 0;  // experiments
+    if (g2cap > 0 && g2 > (uint64_t)g2cap) g2 = g2cap;
+    else if (small_stream == stream3 && g2 > 1024) g2 = 1024;  // beside the next batch's classify kernel (LMAT_PIPELINE): take fewer wave slots
     // tables of 17..32 taxids: one lane per read with the tables in scratch memory; every wave is resident at once, which
     // the LDS tier of that size (2 waves per CU, a millisecond per pass) cannot offer.  LMAT_K4_MODE=1 runs it anyway.
     static const int mode = getenv("LMAT_K4_MODE") ? atoi(getenv("LMAT_K4_MODE")) : 0;
@@ -2511,25 +2518,29 @@ void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stre
         launch_k4_lds<kK4MidT>(a, a.count, stream2);
     } else {
         b.k4_slot = 8;
-        const uint64_t cap = 256 * 32;
-        if (mode == 2) { const uint64_t w = (a.count + 15) / 16; k4_kernel<false, kK4MidT, 16><<<dim3((unsigned)(w < cap ? w : cap)), dim3(64), 0, stream2>>>(b); }
-        else if (mode == 3) { const uint64_t w = (a.count + 31) / 32; k4_kernel<false, kK4MidT, 32><<<dim3((unsigned)(w < cap ? w : cap)), dim3(64), 0, stream2>>>(b); }
-        else k4_kernel<false, kK4MidT, 64><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
+        k4_kernel<false, kK4MidT, 64><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
     }
-    hipEventRecord(joined, stream2);
     hipStreamWaitEvent(stream3, forked, 0);
     if (!a.nm.active) launch_k4_lds<kK4T>(a, a.count / 8 + 64, stream3);  // 33..64 taxids: few reads, but a pass over them is long
-    launch_k4_lds<kK4SmallT>(a, a.count, stream);
+    if (small_stream != stream && small_stream != stream3) hipStreamWaitEvent(small_stream, forked, 0);
+    launch_k4_lds<kK4SmallT>(a, a.count, small_stream);
 }
 // ... the caller may queue more work on stream3 (the re-run classes, which do their own K4) ...
-void launch_k4_end(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream3, hipEvent_t joined, hipEvent_t joined3) {
-    hipEventRecord(joined3, stream3);
-    hipStreamWaitEvent(stream, joined3, 0);
-    hipStreamWaitEvent(stream, joined, 0);
+// The tiers join on `join_stream` (one of the four), which then takes the few reads a tier passed on; `done` is recorded
+// behind that.
+void launch_k4_end(const ClassifyArgs& a, hipStream_t join_stream, hipStream_t stream2, hipStream_t stream3, hipStream_t small_stream,
+                   hipEvent_t joined2, hipEvent_t joined3, hipEvent_t joined_small, hipEvent_t done) {
+    if (stream2 != join_stream) { hipEventRecord(joined2, stream2); hipStreamWaitEvent(join_stream, joined2, 0); }
+    if (stream3 != join_stream) { hipEventRecord(joined3, stream3); hipStreamWaitEvent(join_stream, joined3, 0); }
+    if (small_stream != join_stream && small_stream != stream3 && small_stream != stream2) {
+        hipEventRecord(joined_small, small_stream);
+        hipStreamWaitEvent(join_stream, joined_small, 0);
+    }
     ClassifyArgs b = a;
     b.k4_slot = 6;  // the few reads whose lineage outgrew a tier's block
-    if (a.nm.active) k4_kernel<true, kK4T, 64><<<dim3(64), dim3(64), 0, stream>>>(b);
-    else k4_kernel<false, kK4T, 64><<<dim3(64), dim3(64), 0, stream>>>(b);
+    if (a.nm.active) k4_kernel<true, kK4T, 64><<<dim3(64), dim3(64), 0, join_stream>>>(b);
+    else k4_kernel<false, kK4T, 64><<<dim3(64), dim3(64), 0, join_stream>>>(b);
+    hipEventRecord(done, join_stream);
 }
 
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>

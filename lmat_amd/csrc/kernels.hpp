@@ -16,7 +16,8 @@ struct ClassifyArgs {
     lmat_read_result* results;
     lmat_cand* cands;          // may be null (calls-only)
     uint64_t cand_cap;
-    uint32_t* cursor;          // [0] candidate bump cursor, [1] error flags
+    uint32_t* cursor;          // per-batch counters: [0] candidate bump cursor, [2..] list lengths
+    uint32_t* err;             // sticky error flags: launches only OR into the word
     void* counts;              // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint32_t phix_call_idx;    // internal index of 32630
     uint32_t* ovf_list;        // reads that exceed this launch's capacities are appended here (count in cursor[ovf_slot])
@@ -59,9 +60,10 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
                    uint32_t stride, hipStream_t stream);
 // tcap_class: 0 = fast (T=64, E=128), 2 = the same with E=512, 1 = large (T=1024).  Returns false if max_len exceeds every U class.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
-void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipEvent_t forked,
-                     hipEvent_t joined);
-void launch_k4_end(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream3, hipEvent_t joined, hipEvent_t joined3);
+void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipStream_t small_stream,
+                     hipEvent_t forked);
+void launch_k4_end(const ClassifyArgs& a, hipStream_t join_stream, hipStream_t stream2, hipStream_t stream3, hipStream_t small_stream,
+                   hipEvent_t joined2, hipEvent_t joined3, hipEvent_t joined_small, hipEvent_t done);
 int classify_max_read_len();
 size_t classify_gmem_scratch_bytes();
 // issues ~n_probes random bucket reads (rounded up to 144 per wave x 4096 waves)

@@ -101,8 +101,11 @@ int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out) {
     lmat_params def = {1.0f, 3.0f, 0.0f, 35, 1, 0, 1};
     c->params = params ? *params : def;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
-    if (hipMalloc((void**)&c->d_cursor, 64) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
+    if (hipMalloc((void**)&c->d_cursor, 64) != hipSuccess || hipMalloc((void**)&c->parked.d_cursor, 64) != hipSuccess ||
+        hipMalloc((void**)&c->d_err, 64) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
     hipMemset(c->d_cursor, 0, 64);
+    hipMemset(c->parked.d_cursor, 0, 64);
+    hipMemset(c->d_err, 0, 64);
     *out = c;
     return LMAT_OK;
 }
@@ -115,7 +118,9 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc};
+                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc,
+                    c->d_err, c->parked.d_results, c->parked.d_cands, c->parked.d_cursor, c->parked.d_ovf, c->parked.d_ovf2, c->parked.d_ovf3, c->parked.d_k4buf, c->parked.d_k4small,
+                    c->parked.d_k4large, c->parked.d_k4bail};
     for (void* p : ptrs)
         if (p) hipFree(p);
     sb_free(c);
@@ -123,6 +128,9 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_join3) hipEventDestroy(c->ev_join3);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->ev_join_small) hipEventDestroy(c->ev_join_small);
+    if (c->parked.done) hipEventDestroy(c->parked.done);
     if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -929,6 +937,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.cands = want_cands ? (c->out_cands ? c->out_cands : c->d_cands) : nullptr;
     a.cand_cap = cand_cap;
     a.cursor = c->d_cursor;
+    a.err = c->d_err;
     a.counts = c->out_counts ? c->out_counts : c->d_counts;
     auto it = c->tax.index_of.find(32630);
     a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
@@ -953,12 +962,37 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     return a;
 }
 
+// the set of per-batch buffers in use <-> the parked one
+static void swap_sets(lmat_ctx* c) {
+    auto& p = c->parked;
+    std::swap(c->d_results, p.d_results); std::swap(c->results_cap, p.results_cap);
+    std::swap(c->d_cands, p.d_cands); std::swap(c->cands_cap, p.cands_cap);
+    std::swap(c->d_cursor, p.d_cursor); std::swap(c->d_ovf, p.d_ovf); std::swap(c->d_ovf2, p.d_ovf2); std::swap(c->d_ovf3, p.d_ovf3);
+    std::swap(c->d_k4buf, p.d_k4buf); std::swap(c->d_k4small, p.d_k4small); std::swap(c->d_k4large, p.d_k4large);
+    std::swap(c->d_k4bail, p.d_k4bail); std::swap(c->ovf_cap, p.ovf_cap);
+    std::swap(c->ev_done, p.done); std::swap(c->set_in_flight, p.in_flight);
+}
+
+// Measured (64 GiB table, 2 M reads of 150 bp per batch): with the decision kernels of batch i beside the classify kernel of
+// batch i + 1 a step takes 10.4 ms instead of 10.7 -- the classify kernel is bound by vector issue with every register and
+// LDS byte of a CU in use, so whatever runs beside it takes its share (an LDS decision wave displaces five classify waves).
+// The classify kernel alone then reads 9.3 ms instead of 8.2.  Off unless LMAT_PIPELINE=1.
+static bool pipeline_on() {
+    static const bool on = getenv("LMAT_PIPELINE") && atoi(getenv("LMAT_PIPELINE")) != 0;
+    return on;
+}
+// pipelined: the launch takes the other set of per-batch buffers and returns with its decision kernels still running on the
+// side streams (beside whatever the caller queues next on the context's stream); the set's `done` event marks their end.
+// Otherwise the context's stream waits for them, as every caller that reads results right away needs.
 static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, bool want_cands,
-                        uint64_t cand_cap, bool timed) {
+                        uint64_t cand_cap, bool timed, bool pipelined = false) {
     if (!c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
     if (first + count > reads->n) return set_err(c, LMAT_E_ARG, "read range out of bounds");
     if (count > 0xFFFFFFFFull) return set_err(c, LMAT_E_ARG, "batch above 2^32 reads");
     hipSetDevice(c->device);
+    if (pipelined) swap_sets(c);
+    if (!c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    if (c->set_in_flight) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));  // the set's previous batch has to be through
     int rc = ensure_results(c, c->out_results ? 0 : count, want_cands && !c->out_cands ? cand_cap : 0);
     if (!rc) rc = ensure_scratch(c, count);
     if (rc) return rc;
@@ -967,10 +1001,9 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
     if (!c->d_gscratch)  // per-read tables of the global-memory class (very long reads, very large taxid tables)
         HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
-    // per-launch counters: the candidate cursor [0] and the list lengths [2..]; the error word [1] is sticky -- launches
+    // per-launch counters: the candidate cursor [0] and the list lengths [2..]; the error word (d_err) is sticky -- launches
     // only OR into it and whoever reports it (lmat_sync, lmat_classify, lmat_rand_label) clears it
-    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_cursor + 2, 0, 56, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 64, c->stream));
     ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
     struct Ev {  // timing events of this launch: handed to the context on success, destroyed on any early return
         hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1068,7 +1101,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
         }
-        launch_k4_begin(a, c->stream, c->stream2, c->stream3, c->ev_fork, c->ev_join);
+        launch_k4_begin(a, c->stream, c->stream2, c->stream3, pipelined ? c->stream3 : c->stream, c->ev_fork);
     }
     {   // ... to the large LDS class (1024 taxids, reads up to 2067 bp), or directly to the global-memory class when the
         // batch holds reads beyond that.  These kernels make their own decision step, so they run beside the K4 kernels.
@@ -1090,9 +1123,15 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
             launch_classify(g, 2048 + 20, 1, rs);
         }
     }
-    if (k4) launch_k4_end(a, c->stream, c->stream3, c->ev_join, c->ev_join3);
+    // the tiers join on the context's stream, or, when the next batch is to run beside them, on the second stream
+    hipStream_t js = k4 && pipelined ? c->stream2 : c->stream;
+    if (k4) {
+        if (!c->ev_join_small) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join_small, hipEventDisableTiming));
+        launch_k4_end(a, js, c->stream2, c->stream3, pipelined ? c->stream3 : c->stream, c->ev_join, c->ev_join3, c->ev_join_small, c->ev_done);
+    } else HIPCHK(c, hipEventRecord(c->ev_done, c->stream));
+    c->set_in_flight = true;
     if (timed) {
-        HIPCHK(c, hipEventRecord(e3, c->stream));
+        HIPCHK(c, hipEventRecord(e3, js));
         c->pending_events.push_back(std::make_pair(e0, e1));
         c->pending_events2.push_back(std::make_pair(e2, e3));
         e0 = e1 = e2 = e3 = nullptr;
@@ -1104,10 +1143,11 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
 // Reads and clears the sticky error word; maps it to the API's codes (the most specific message wins).
 static int report_device_errors(lmat_ctx* c, uint32_t* cand_cursor) {
     uint32_t cur[2];
-    HIPCHK(c, hipMemcpy(cur, c->d_cursor, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&cur[0], c->d_cursor, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&cur[1], c->d_err, 4, hipMemcpyDeviceToHost));
     if (cand_cursor) *cand_cursor = cur[0];
     if (!cur[1]) return LMAT_OK;
-    HIPCHK(c, hipMemset(c->d_cursor + 1, 0, 4));
+    HIPCHK(c, hipMemset(c->d_err, 0, 4));
     if (cur[1] & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
     if (cur[1] & kErrLineageTrunc) return set_err(c, LMAT_E_CAPACITY, "taxonomy deeper than the lineage scratch (72 levels)");
     if (cur[1] & kErrNoNullModel) return set_err(c, LMAT_E_TAXONOMY, "ERROR, ALL TAXIDS MUST HAVE NULL MODELS");
@@ -1148,13 +1188,16 @@ int lmat_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t
 int lmat_classify_async(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count) {
     if (!c || !reads) return LMAT_E_ARG;
     if (!count) return LMAT_OK;
-    return run_classify(c, reads, first, count, false, 0, true);
+    return run_classify(c, reads, first, count, false, 0, true, pipeline_on());
 }
 
 int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     if (!c) return LMAT_E_ARG;
     hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->set_in_flight) { HIPCHK(c, hipEventSynchronize(c->ev_done)); c->set_in_flight = false; }  // decision kernels on the side streams
+    if (c->parked.in_flight) { HIPCHK(c, hipEventSynchronize(c->parked.done)); c->parked.in_flight = false; }
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));  // the timing events behind them
     for (auto& e : c->pending_events) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { c->kernel_ms_total += ms; c->kernel_launches++; }
@@ -1180,6 +1223,7 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     if (getenv("LMAT_DEBUG")) {
         uint32_t cur[6];
         HIPCHK(c, hipMemcpy(cur, c->d_cursor, 24, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&cur[1], c->d_err, 4, hipMemcpyDeviceToHost));
         fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags (all launches since the last report) %u, reads re-run by the large class %u, "
                         "by the global-memory class %u; K4 with small tables %u, with large tables %u\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
     }
@@ -1487,15 +1531,17 @@ static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch
     c->out_results = sl.d_results;
     c->out_cands = sl.d_cands;
     c->out_counts = to_scratch_counts ? st->d_scratch_counts : nullptr;
-    const int rc = run_classify(c, &sl.reads, 0, sl.n, sl.cand_cap != 0, sl.cand_cap, false);
+    const int rc = run_classify(c, &sl.reads, 0, sl.n, sl.cand_cap != 0, sl.cand_cap, false, pipeline_on());
     c->out_results = nullptr; c->out_cands = nullptr; c->out_counts = nullptr;
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(sl.h_cursor, c->d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(sl.ev_done, c->stream));
-    // The copy back rides the context's second stream (idle once the K4 kernels have joined).  A stream of its own
-    // would be the fifth of the process: the runtime multiplexes streams onto 4 hardware queues, and a copy that shares
-    // its queue with the compute stream holds up the next batch's kernels behind it.
-    HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_done, 0));
+    // The batch's decision kernels join on the context's second stream, and the copies back ride it behind them while the
+    // context's own stream goes on with the next batch.  (A stream of its own for the copies would be the fifth of the
+    // process: the runtime multiplexes streams onto 4 hardware queues, and a copy that shares its queue with the compute
+    // stream holds up the next batch's kernels behind it.)
+    HIPCHK(c, hipStreamWaitEvent(st->s_d2h, c->ev_done, 0));
+    HIPCHK(c, hipMemcpyAsync(sl.h_cursor, c->d_cursor, 4, hipMemcpyDeviceToHost, st->s_d2h));
+    HIPCHK(c, hipMemcpyAsync(sl.h_cursor + 1, c->d_err, 4, hipMemcpyDeviceToHost, st->s_d2h));
+    HIPCHK(c, hipEventRecord(sl.ev_done, st->s_d2h));
     HIPCHK(c, hipMemcpyAsync(sl.h_results, sl.d_results, sl.n * sizeof(lmat_read_result), hipMemcpyDeviceToHost, st->s_d2h));
     HIPCHK(c, hipEventRecord(sl.ev_out, st->s_d2h));
     return LMAT_OK;
@@ -1636,7 +1682,7 @@ int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lm
             // the batch printed more candidates than the slot holds: wait for the batches queued behind it, grow this slot
             // fourfold and run it again (packed reads are still resident; its tallies were already counted)
             HIPCHK(c, hipDeviceSynchronize());
-            HIPCHK(c, hipMemset(c->d_cursor + 1, 0, 4));
+            HIPCHK(c, hipMemset(c->d_err, 0, 4));
             for (auto& o : st->slots)  // flags of the batches behind it were in the word just cleared
                 if (&o != &sl && o.state == 2) st->reported &= ~(o.h_cursor[1] & ~(uint32_t)kErrCandOverflow);
             hipFree(sl.d_cands); hipHostFree(sl.h_cands);

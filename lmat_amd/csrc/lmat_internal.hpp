@@ -161,7 +161,22 @@ struct lmat_ctx {
     uint32_t* d_k4bail = nullptr;
     hipStream_t stream2 = nullptr;  // the scratch K4 kernel runs beside the LDS one
     hipStream_t stream3 = nullptr;  // ... and the LDS kernel of the largest tables beside both
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join_small = nullptr;
+    uint32_t* d_err = nullptr;      // sticky error flags of every launch since the last report
+    // Two sets of everything a batch's kernels write besides the tallies (result records, candidates, hand-off records,
+    // lists, counters): the decision kernels of one batch run beside the classify kernel of the next.  The members above
+    // (d_results ... d_k4bail, d_cursor) are the set in use; the other one is parked here.
+    struct BatchSet {
+        lmat_read_result* d_results = nullptr; uint64_t results_cap = 0;
+        lmat_cand* d_cands = nullptr; uint64_t cands_cap = 0;
+        uint32_t *d_cursor = nullptr, *d_ovf = nullptr, *d_ovf2 = nullptr, *d_ovf3 = nullptr, *d_k4buf = nullptr, *d_k4small = nullptr,
+                 *d_k4large = nullptr, *d_k4bail = nullptr;
+        uint64_t ovf_cap = 0;
+        hipEvent_t done = nullptr;   // recorded behind the last kernel that touches the set
+        bool in_flight = false;
+    } parked;
+    hipEvent_t ev_done = nullptr;    // `done` of the set in use
+    bool set_in_flight = false;
     lmat::NullModelDev nm;         // device pointers owned by the context
     std::vector<void*> nm_allocs;
     uint64_t ovf_cap = 0;
