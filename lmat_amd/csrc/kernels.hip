@@ -444,6 +444,7 @@ template <int TT> struct K4Lds {
     static constexpr int LANES = TT <= 32 ? 64 : 32;  // the 64-taxid tier runs half waves: 2 per CU as well
     static constexpr int STRIDE = ((17 * TT + 12 * LIN + 3) / 4) | 1;  // dwords per lane
     static constexpr int BYTES = STRIDE * 4 * LANES;
+    static_assert(8 * TT <= 12 * LIN, "sort keys over the lineage entries");
 };
 static_assert(K4Lds<16>::STRIDE == 125, "small tier: 31.25 KB per wave");
 
@@ -552,6 +553,7 @@ __device__ __forceinline__ bool anc_iv(uint32_t tin_a, uint32_t tout_a, uint32_t
     return tin_a < tin_b && tout_b <= tout_a;
 }
 
+struct K4Key { uint32_t lo, hi; };  // sort key of a candidate: hi = score bits, lo = depth << 16 | slot
 struct TCmpDev {  // TCmp, read_label.cpp:475-485
     const float* score;
     const uint16_t* dep;
@@ -633,7 +635,7 @@ template <int LIN>
 __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& S, const uint16_t* cnt, float* score, float* score0,
                          const uint16_t* dep, const uint8_t* sflags, const uint16_t* tin, const uint16_t* tout,
                          const uint16_t* reg, uint16_t* ord, LinEnt* lin, int nT, uint32_t cand, bool use_nm,
-                         const float* nm_rp, const uint8_t* nm_cl, const NullModelDev& ND) {
+                         const float* nm_rp, const uint8_t* nm_cl, const NullModelDev& ND, K4Key* keys = nullptr) {
     bool fnd_phix = false, has_human = false;
     float log_sum = 0.0f, pos_log_sum = 0.0f, top_score = 0.0f, phix_score = 0.0f;
     unsigned sig_hits = 0, pos_sig_hits = 0;
@@ -701,9 +703,27 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
         for (int s = 0; s < nT; ++s)
             if (sflags[s] & kFlagHuman) score[s] += (P.hbias * stdev1);
     }
-    for (int s = 0; s < nT; ++s) ord[s] = (uint16_t)s;
-    ss_sort<(LIN <= 152 ? 8 : 34)>(ord, nT, TCmpDev{score, dep});  // :892-893
+    if (P.stop_after == 14) { S.done = true; return; }  // timing experiments: scores and statistics only
+    if (keys) {
+        // the same sort on packed (score | depth, slot) pairs: a comparison reads two of them instead of two slots, two
+        // scores and two depths -- three dependent loads per step of the insertion loops become one
+        for (int s = 0; s < nT; ++s) { K4Key kk; kk.hi = __float_as_uint(score[s]); kk.lo = ((uint32_t)dep[s] << 16) | (uint32_t)s; keys[s] = kk; }
+        struct TCmpKey {  // TCmp, read_label.cpp:475-485
+            __device__ bool operator()(const K4Key& a, const K4Key& b) const {
+                const float sa = __uint_as_float(a.hi), sb = __uint_as_float(b.hi);
+                const float d = sa - sb;
+                if ((double)fabsf(d) < 0.001) return (int)(a.lo >> 16) < (int)(b.lo >> 16);
+                return sa < sb;
+            }
+        };
+        ss_sort<(LIN <= 152 ? 8 : 34)>(keys, nT, TCmpKey{});
+        for (int s = 0; s < nT; ++s) ord[s] = (uint16_t)keys[s].lo;
+    } else {
+        for (int s = 0; s < nT; ++s) ord[s] = (uint16_t)s;
+        ss_sort<(LIN <= 152 ? 8 : 34)>(ord, nT, TCmpDev{score, dep});  // :892-893
+    }
     S.diff_thresh = stdev1 * P.sdiff;       // :895
+    if (P.stop_after == 13) { S.done = true; return; }  // ... + the sort
     // findReadLabelVer2 :287-325
     S.plasmid_slot = -1;
     unsigned lowest_depth = 0, highest_depth = 0;
@@ -2136,7 +2156,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 template <int TT, int LIN, bool NM>
 __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint16_t* reg, uint16_t* cnt, uint16_t* dep,
                                         uint16_t* tin, uint16_t* tout, uint16_t* ord, uint8_t* sflags, float* score,
-                                        float* score0, uint8_t* nm_cl, float* nm_rp, LinEnt* lin, bool bail_on_long) {
+                                        float* score0, uint8_t* nm_cl, float* nm_rp, LinEnt* lin, bool bail_on_long, K4Key* keys = nullptr) {
     const DeviceTables& tb = A.tb;
     const GAS uint32_t* g_tid32 = (const GAS uint32_t*)tb.tid32;
     const GAS uint64_t* g_paths8 = (const GAS uint64_t*)tb.paths8;
@@ -2193,9 +2213,11 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
             nm_rp[s] = (float)((double)((const GAS float*)A.nm.val)[row * A.nm.nb_max + bin] + 0.0001);
         }
     }
+    if (A.prm.stop_after == 10) { res.status = LMAT_ST_SILENT; store_result(out, res); return true; }  // timing experiments: staging only
     K4State S;
     k4_part1<LIN>(A.prm, res, S, cnt, score, NM ? score0 : nullptr, dep, sflags, tin, tout, reg, ord, lin, nT, cand, NM && nmt >= 0,
-                  nm_rp, nm_cl, A.nm);
+                  nm_rp, nm_cl, A.nm, keys);
+    if (A.prm.stop_after == 11) { res.status = LMAT_ST_SILENT; store_result(out, res); return true; }  // ... + scores, sort, lineage
     uint32_t call_idx = A.phix_call_idx, ncand = 0, coff = 0;
     if (!S.done) {
         int nlin = S.nlin;
@@ -2234,6 +2256,7 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
                 }
             }
         }
+        if (A.prm.stop_after == 12) { res.status = LMAT_ST_SILENT; store_result(out, res); return true; }  // ... + appended ancestors
         GAS lmat_cand* cout_ = nullptr;
         if (A.cands) {
             const uint32_t reserve = A.prm.prn_all ? (uint32_t)nT : (uint32_t)nlin;  // -p: the candidates; else the lineage as built
@@ -2314,7 +2337,8 @@ __global__ __launch_bounds__(64) void k4_lds_kernel(ClassifyArgs A) {
     const uint64_t stride = (uint64_t)gridDim.x * K::LANES;
     for (uint64_t i = (uint64_t)blockIdx.x * K::LANES + lane; i < n; i += stride) {
         const uint64_t it = list[i];
-        if (!k4_read<TT, K::LIN, false>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, nullptr, nullptr, nullptr, lin, true))
+        // the sort keys lie over the lineage entries, which are written only after the sort
+        if (!k4_read<TT, K::LIN, false>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, nullptr, nullptr, nullptr, lin, true, (K4Key*)lin))
             ((GAS uint32_t*)A.k4_bail)[G_ADD(&g_cursor[6], 1u)] = (uint32_t)it;  // lineage longer than the LDS block: scratch kernel, last launch
     }
 }
@@ -2335,7 +2359,8 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
         uint8_t sflags[TT], nm_cl[NM ? TT : 1];
         float score[TT], score0[NM ? TT : 1], nm_rp[NM ? TT : 1];
         LinEnt lin[LIN];
-        if (!k4_read<TT, LIN, NM>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, score0, nm_cl, nm_rp, lin, TT != kK4T))
+        K4Key keys[TT];
+        if (!k4_read<TT, LIN, NM>(A, it, reg, cnt, dep, tin, tout, ord, sflags, score, score0, nm_cl, nm_rp, lin, TT != kK4T, keys))
             ((GAS uint32_t*)A.k4_bail)[G_ADD(&g_cursor[6], 1u)] = (uint32_t)it;
     }
 }

@@ -1090,7 +1090,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         m.p_max = 0xFFFFFFFFu;
         launch_classify(m, 512 + (uint32_t)c->dev.k - 1, 2, c->stream);
     }
-    const bool k4 = a.prm.stop_after == 0;
+    const bool k4 = a.prm.stop_after == 0 || a.prm.stop_after >= 10;  // 10..12: partial decision steps (timing experiments)
     if (k4) {  // score + LCA decision, one lane per read
         if (!c->stream2) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));

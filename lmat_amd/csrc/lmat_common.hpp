@@ -178,10 +178,18 @@ LM_HD uint64_t splitmix(uint64_t x) {
 // heapsort when the depth limit 2*floor(log2 n) is exhausted.  Works on any
 // random-access array T with cmp(a,b).  Unguarded scans are clamped to the array:
 // the reference would run out of bounds there (undefined behaviour).
+// (LM_NOUNROLL: on the GPU these loops run in lanes that each follow their own path; unrolled and peeled they made the decision
+// kernels 45-90 KB of code, more than the instruction cache holds.)
+#if defined(__clang__)
+#define LM_NOUNROLL _Pragma("nounroll")
+#else
+#define LM_NOUNROLL
+#endif
 template <class T, class Cmp>
 LM_HD void ss_unguarded_linear_insert(T* first, int last, Cmp& cmp) {
     T val = first[last];
     int next = last - 1;
+    LM_NOUNROLL
     while (next >= 0 && cmp(val, first[next])) {
         first[last] = first[next];
         last = next;
@@ -189,25 +197,23 @@ LM_HD void ss_unguarded_linear_insert(T* first, int last, Cmp& cmp) {
     }
     first[last] = val;
 }
+// Written as ONE loop per element with the two cases of libstdc++'s __insertion_sort (new minimum: shift the whole prefix;
+// otherwise: unguarded scan) folded into its condition: on the GPU every lane sorts its own read's table, and lanes that sit
+// in different loops of a nest run one after the other.
 template <class T, class Cmp>
 LM_HD void ss_insertion_sort(T* a, int first, int last, Cmp& cmp) {
     if (first == last) return;
+    LM_NOUNROLL
     for (int i = first + 1; i != last; ++i) {
-        if (cmp(a[i], a[first])) {
-            T val = a[i];
-            for (int j = i; j > first; --j) a[j] = a[j - 1];
-            a[first] = val;
-        } else {
-            // unguarded within [first, i]: a[first] stops the scan in the reference
-            T val = a[i];
-            int lastp = i, next = i - 1;
-            while (next >= first && cmp(val, a[next])) {
-                a[lastp] = a[next];
-                lastp = next;
-                --next;
-            }
-            a[lastp] = val;
+        const T val = a[i];
+        const bool to_front = cmp(val, a[first]);
+        int j = i;
+        LM_NOUNROLL
+        while (j > first && (to_front || cmp(val, a[j - 1]))) {  // a[first] stops the unguarded scan in the reference
+            a[j] = a[j - 1];
+            --j;
         }
+        a[j] = val;
     }
 }
 template <class T, class Cmp>
@@ -263,7 +269,9 @@ LM_HD void ss_sort(T* a, int n, Cmp cmp) {
         ss_insertion_sort(a, 0, n, cmp);
         return;
     }
-    // introsort loop, recursion on the right part made explicit; entry = first | last << 13 | depth << 26 (n < 8192)
+    // introsort loop, recursion on the right part made explicit; entry = first | last << 13 | depth << 26 (n < 8192).
+    // One flat loop: each turn a lane either takes one partitioning step of its current range or fetches the next pending
+    // range; the partition itself is one loop that makes one comparison per turn (scan up / scan down as a state).
     uint32_t st[CAP];
     int sp = 0;
     auto push = [&](uint32_t v) {
@@ -289,37 +297,38 @@ LM_HD void ss_sort(T* a, int n, Cmp cmp) {
 #pragma unroll
         for (int q = 0; q < CAP; ++q) st[q] = 0;
     }
-    push(0u | ((uint32_t)n << 13) | ((uint32_t)(2 * lg) << 26));
-    while (sp > 0) {
-        const uint32_t top = pop();
-        int first = (int)(top & 0x1FFFu), last = (int)((top >> 13) & 0x1FFFu), depth = (int)(top >> 26);
-        while (last - first > 16) {
-            if (depth == 0) {
-                ss_heapsort(a, first, last, cmp);
-                break;
-            }
+    int first = 0, last = n, depth = 2 * lg;
+    bool busy = true;
+    LM_NOUNROLL
+    while (busy) {
+        if (last - first <= 16) {  // done with this range: the next pending one, if any
+            if (sp > 0) {
+                const uint32_t top = pop();
+                first = (int)(top & 0x1FFFu); last = (int)((top >> 13) & 0x1FFFu); depth = (int)(top >> 26);
+            } else busy = false;
+        } else if (depth == 0) {
+            ss_heapsort(a, first, last, cmp);
+            last = first;
+        } else {
             --depth;
-            // median of (first+1, mid, last-1) moved to first
-            int mid = first + (last - first) / 2;
-            int ia = first + 1, ib = mid, ic = last - 1, r = first;
-            int pick;
-            if (cmp(a[ia], a[ib])) {
-                if (cmp(a[ib], a[ic])) pick = ib;
-                else if (cmp(a[ia], a[ic])) pick = ic;
-                else pick = ia;
-            } else if (cmp(a[ia], a[ic])) pick = ia;
-            else if (cmp(a[ib], a[ic])) pick = ic;
-            else pick = ib;
-            { T t = a[r]; a[r] = a[pick]; a[pick] = t; }
+            // median of (first+1, mid, last-1) moved to first (__move_median_to_first: all three comparisons made up front)
+            const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+            const bool ab = cmp(a[ia], a[ib]), bc = cmp(a[ib], a[ic]), ac = cmp(a[ia], a[ic]);
+            const int pick = ab ? (bc ? ib : (ac ? ic : ia)) : (ac ? ia : (bc ? ic : ib));
+            { T t = a[first]; a[first] = a[pick]; a[pick] = t; }
             // unguarded partition of [first+1, last) around a[first]
-            int lo = first + 1, hi = last;
-            while (true) {
-                while (lo < last && cmp(a[lo], a[first])) ++lo;
-                --hi;
-                while (hi > first && cmp(a[first], a[hi])) --hi;
-                if (!(lo < hi)) break;
-                T t = a[lo]; a[lo] = a[hi]; a[hi] = t;
-                ++lo;
+            const T pivot = a[first];
+            int lo = first + 1, hi = last - 1;
+            bool up = true, more = true;  // up: scanning lo upwards; else hi downwards (hi was decremented on entering)
+            LM_NOUNROLL
+            while (more) {
+                const T x = up ? a[lo] : a[hi];
+                const bool in = up ? lo < last : hi > first;
+                const bool step = in && (up ? cmp(x, pivot) : cmp(pivot, x));
+                if (step) { if (up) ++lo; else --hi; }
+                else if (up) up = false;
+                else if (lo < hi) { const T t = a[lo]; a[lo] = x; a[hi] = t; ++lo; --hi; up = true; }
+                else more = false;
             }
             const int cut = lo;
             // reference recurses on [cut,last) first, then loops on [first,cut)
@@ -329,6 +338,7 @@ LM_HD void ss_sort(T* a, int n, Cmp cmp) {
         }
     }
     ss_insertion_sort(a, 0, 16, cmp);
+    LM_NOUNROLL
     for (int i = 16; i < n; ++i) ss_unguarded_linear_insert(a, i, cmp);
 }
 
