@@ -822,3 +822,19 @@ def test_counts_allreduce_across_contexts(small_dataset):
         assert abs(ca[0][t][1] - s) < 1e-6 and abs(cb[0][t][1] - s) < 1e-6
     for e in (a, b, whole):
         e.close()
+
+
+def test_batches_run_beside_each_other_give_the_same_answers():
+    """LMAT_PIPELINE=1: queued launches and the streamed boundary take the two sets of per-batch buffers in turn and the decision
+    kernels of a batch run beside the classify kernel of the next one.  The switch is read once per process, so the tests
+    that queue batches (async launches, sticky errors, the streamed boundary, the CLI) run again in a child process with it on."""
+    import subprocess
+    import sys
+    if os.environ.get("LMAT_PIPELINE"):
+        pytest.skip("already the child run")
+    env = dict(os.environ, LMAT_PIPELINE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_cli.py"),
+                        "-m", "gpu", "-x", "-q", "-k", "async or sync or stream or tallies or cli_matches or several_contexts"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
