@@ -53,6 +53,12 @@ __device__ __forceinline__ void store_result(GAS uint64_t* dst, const lmat_read_
 
 __device__ __forceinline__ uint64_t lt_mask(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+// number of set bits of a wave-uniform mask below this lane (v_mbcnt: two instructions)
+__device__ __forceinline__ uint32_t prefix_count(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// bit `lane` of a wave-uniform mask as this lane's predicate: the mask itself, no instruction
+__device__ __forceinline__ bool lane_bit(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 __device__ __forceinline__ uint32_t hash32(uint64_t x) {
     x *= 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> 40);
@@ -1038,7 +1044,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 const uint32_t code = (codes[p >> 4] >> (2 * (p & 15))) & 3u;
                 isgc = code == 1 || code == 2;
             }
-            const bool covered = (hi >> lane) & 1ull;
+            const bool covered = lane_bit(hi);
             gc += popc64(__ballot(covered && isgc));
             tot += popc64(hi);
             prevV = V;
@@ -1061,7 +1067,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint32_t u2h = (uint32_t)__builtin_amdgcn_update_dpp(n1h, (int)u1h, 0x130, 0xf, 0xf, false);
         const uint32_t u3l = (uint32_t)__builtin_amdgcn_update_dpp(n2l, (int)u2l, 0x130, 0xf, 0xf, false);
         const uint32_t u3h = (uint32_t)__builtin_amdgcn_update_dpp(n2h, (int)u2h, 0x130, 0xf, 0xf, false);
-        const bool fc = (fcmask >> lane) & 1ull;
+        const bool fc = lane_bit(fcmask);
         const uint64_t a0 = ((uint64_t)uhi << 32) | (ulo | (fc ? 0u : 12u)), a1 = ((uint64_t)u1h << 32) | (u1l | (fc ? 4u : 8u));
         const uint64_t a2 = ((uint64_t)u2h << 32) | (u2l | (fc ? 8u : 4u)), a3 = ((uint64_t)u3h << 32) | (u3l | (fc ? 12u : 0u));
         const uint64_t m01 = a0 < a1 ? a0 : a1, m23 = a2 < a3 ? a2 : a3;
@@ -1115,7 +1121,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const bool first = ok && (uint32_t)(hv[h] & 0xFFFF) == p;
         const uint64_t bm = __ballot(first);
         if (first) {
-            const uint32_t rk = nuniq + popc64(bm & lt_mask(lane));
+            const uint32_t rk = nuniq + prefix_count(bm);
             ukmer[rk] = (km << kPayloadBits) + 1;  // pre-shifted for the probe's slot compare
             ubucket[rk] = bucket_of(km, tb.nbuckets);
             upay[rk] = 0;
@@ -1126,7 +1132,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= P) break;
-            pass2_chunk((uint32_t)c * 64, kreg[c], hreg[c], (okm[c] >> lane) & 1ull);
+            pass2_chunk((uint32_t)c * 64, kreg[c], hreg[c], lane_bit(okm[c]));
         }
     } else {
         for (uint32_t p0 = 0; p0 < P; p0 += 64) {
@@ -1197,7 +1203,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                         uint32_t b = ubucket[idx] + NB;
                         if (b >= tb.nbuckets) b -= tb.nbuckets;
                         ubucket[idx] = b;
-                        pnext[npend + (uint32_t)popc64(pm & lt_mask(lane))] = (uint16_t)idx;
+                        pnext[npend + prefix_count(pm)] = (uint16_t)idx;
                     }
                     npend += (uint32_t)popc64(pm);
                 }
@@ -1250,7 +1256,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             if ((uint32_t)c * 64 >= P) break;
             const uint64_t V = okm[c];
             const uint64_t V1 = (V << 1) | (Vp >> 63), V2 = (V << 2) | (Vp >> 62), V3 = (V << 3) | (Vp >> 61);  // lane - d is valid
-            const bool ok = (V >> lane) & 1ull;
+            const bool ok = lane_bit(V);
             const uint32_t b = hreg[c];
             const uint32_t sig = (uint32_t)(kreg[c] ^ (kreg[c] >> 17));
             const uint32_t q = (uint32_t)c * 64 + lane + (treg[c] >> 30);  // where the k-mer's minimizer starts in the read
@@ -1259,8 +1265,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps1, (int)sig, 0x138, 0xf, 0xf, false);
             const uint32_t s2 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps2, (int)s1, 0x138, 0xf, 0xf, false);
             const uint32_t s3 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps3, (int)s2, 0x138, 0xf, 0xf, false);
-            bool hit = ok && ((((V1 >> lane) & 1ull) && sig == s1) || (((V2 >> lane) & 1ull) && sig == s2) || (((V3 >> lane) & 1ull) && sig == s3));
-            if (ok && !(((V1 >> lane) & 1ull) && b == bprev && q == qprev)) {  // opens a group
+            bool hit = ok && ((lane_bit(V1) && sig == s1) || (lane_bit(V2) && sig == s2) || (lane_bit(V3) && sig == s3));
+            if (ok && !(lane_bit(V1) && b == bprev && q == qprev)) {  // opens a group
                 const uint32_t h1 = b & 2047u, h2 = (b >> 11) & 2047u;
                 const unsigned int oa = __hip_atomic_fetch_or(&bloomA[h1 >> 5], 1u << (h1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const unsigned int ob = __hip_atomic_fetch_or(&bloomB[h2 >> 5], 1u << (h2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1283,7 +1289,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if ((uint32_t)c * 64 >= P) break;
-                const bool ok = (okm[c] >> lane) & 1ull;
+                const bool ok = lane_bit(okm[c]);
                 uint32_t h = 0;
                 if (ok) h = lds_min_insert(hv, L::H - 1, kreg[c], (uint32_t)c * 64 + lane);
                 treg[c] = (treg[c] & 0xC000FFFFu) | (h << 16);  // the tag is 16 bits wide; the hash slot rides above it
@@ -1292,7 +1298,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if ((uint32_t)c * 64 >= P) break;
-                const bool ok = (okm[c] >> lane) & 1ull;
+                const bool ok = lane_bit(okm[c]);
                 firstm[c] = __ballot(ok && (uint32_t)(hv[(treg[c] >> 16) & 0x3FFFu] & 0xFFFF) == (uint32_t)c * 64 + lane);
                 nuniq += popc64(firstm[c]);
             }
@@ -1344,10 +1350,10 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint32_t p = p0 + lane;
         const uint64_t V1 = __ballot(ok) << 1;  // lane - 1 holds a valid k-mer (lane 0 always opens a group)
         const uint32_t bprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, false);  // wave_shr:1
-        const bool leader = ok && !(((V1 >> lane) & 1ull) && b == bprev);
+        const bool leader = ok && !(lane_bit(V1) && b == bprev);
         const uint64_t lm = __ballot(leader);
         const uint32_t ng = (uint32_t)popc64(lm);
-        const uint32_t gidx = (uint32_t)popc64(lm & ((lt_mask(lane) << 1) | 1ull)) - 1u;  // group of this lane (ok lanes)
+        const uint32_t gidx = prefix_count(lm) + (leader ? 1u : 0u) - 1u;  // group of this lane (ok lanes): leaders at or below it, minus one
         if (leader) gbkt[gidx] = b;
         WSYNC();
 #pragma unroll
@@ -1390,7 +1396,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint64_t pm = __ballot(pend);
         if (pm) {
             if (nov + (uint32_t)popc64(pm) > 64u) { WSYNC(); ovf_pass(); WSYNC(); }  // the list holds 64 entries: one chunk's worth
-            if (pend) olist[nov + (uint32_t)popc64(pm & lt_mask(lane))] = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, tag | (p << 16)};
+            if (pend) olist[nov + prefix_count(pm)] = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, tag | (p << 16)};
             nov += (uint32_t)popc64(pm);
         }
         WSYNC();
@@ -1399,7 +1405,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= P) break;
-            probe_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c] & 0xFFFFu, (okm[c] >> lane) & 1ull, (firstm[c] >> lane) & 1ull);
+            probe_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c] & 0xFFFFu, lane_bit(okm[c]), lane_bit(firstm[c]));
         }
     } else {
         for (uint32_t p0 = 0; p0 < P; p0 += 64) {
@@ -1485,7 +1491,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const uint64_t bm = __ballot(owner);
             WSYNC();
             if (owner) {
-                const uint32_t rk = ndist + popc64(bm & lt_mask(lane));
+                const uint32_t rk = ndist + prefix_count(bm);
                 dpay[rk] = pay;
                 hv[h] = ((unsigned long long)pay << 16) | (0x8000u | rk);  // first index -> rank (bit 15 marks it)
             }
@@ -1568,7 +1574,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const uint32_t newcnt = popc64(nm_);
             if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
             if (isnew) {
-                const uint32_t sl = nT + popc64(nm_ & lt_mask(lane));
+                const uint32_t sl = nT + prefix_count(nm_);
                 gval[h] = sl;
                 greg[sl] = gid;
                 gcnt[sl] = 0;
@@ -1717,7 +1723,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint32_t newcnt = popc64(nm_);
         if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
         if (isnew) {
-            const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+            const uint32_t s = nT + prefix_count(nm_);
             hent[h] = t | (s << 16);
             reg[s] = (uint16_t)t; stamp[s] = 0xFFFF;
         }
@@ -1818,7 +1824,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                     const uint32_t newcnt = popc64(nm_);
                     if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
                     if (unreg) {
-                        const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+                        const uint32_t s = nT + prefix_count(nm_);
                         hent[h] = a | (s << 16);
                         reg[s] = (uint16_t)a; stamp[s] = 0xFFFF;
                     }
@@ -1938,7 +1944,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const uint32_t newcnt = popc64(nm_);
             if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
             if (isnew) {
-                const uint32_t s = nT + popc64(nm_ & lt_mask(lane));
+                const uint32_t s = nT + prefix_count(nm_);
                 hent[h] = a | (s << 16);
                 reg[s] = (uint16_t)a;
                 s_tin[s] = (uint16_t)(pe >> 32);
@@ -2308,7 +2314,7 @@ __global__ __launch_bounds__(256) void k4_compact_kernel(ClassifyArgs A) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const uint64_t m = __ballot(st[j] == want);
-                if (st[j] == want) list[pos + popc64(m & lt_mask(lane))] = (uint32_t)(base + (uint64_t)j * 64 + lane);
+                if (st[j] == want) list[pos + prefix_count(m)] = (uint32_t)(base + (uint64_t)j * 64 + lane);
                 pos += (uint32_t)popc64(m);
             }
         }
