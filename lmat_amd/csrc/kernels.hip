@@ -53,6 +53,18 @@ __device__ __forceinline__ void store_result(GAS uint64_t* dst, const lmat_read_
 
 __device__ __forceinline__ uint64_t lt_mask(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+// inclusive prefix sum over the 64 lanes in six DPP adds (shifts inside the rows of 16, then the row totals broadcast
+// onward); all lanes must be active.  No LDS crossbar as with __shfl_up, no lane arithmetic.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(x), 63); }
 // number of set bits of a wave-uniform mask below this lane (v_mbcnt: two instructions)
 __device__ __forceinline__ uint32_t prefix_count(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1633,11 +1645,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             }
         }
         // inclusive scan of n over the wave
-        uint32_t incl = n;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
+        const uint32_t incl = wave_scan_incl(n);
         if (d < ndist) {
             const uint32_t s0 = nel + incl - n;
             dn[d] = (uint16_t)n;
@@ -1655,11 +1663,10 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         any_long |= __ballot(n > 2) != 0;
         // label_vec.first < 0 positions leave the candidate count (quirk Q4); positions with a
         // non-empty set count as found (construct_labels :722-725)
-        uint32_t negm = (fl & kListNegFirst) ? m : 0, fm = n ? m : 0;
-        for (int o = 32; o > 0; o >>= 1) { negm += __shfl_xor(negm, o); fm += __shfl_xor(fm, o); }
-        cand -= negm;
-        fnd += fm;
-        nel += __shfl(incl, 63);
+        const uint32_t both = wave_sum(((fl & kListNegFirst) ? m : 0u) | ((n ? m : 0u) << 16));  // each sum is at most the k-mer capacity
+        cand -= both & 0xFFFFu;
+        fnd += both >> 16;
+        nel += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     if (A.prm.stop_after == 7) { if (lane == 0) { emit(250, nel > 65535u ? 65535u : nel); } return; }
     bool overflow = nel > (uint32_t)E;
@@ -1904,13 +1911,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 const uint32_t plen = (uint32_t)__shfl((int)f_plen, (int)sl);
                 const bool walk = e < nel && first[sl] == e;
                 const uint32_t w = walk ? plen : 0u;
-                uint32_t incl = w;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t v = __shfl_up(incl, o);
-                    if (lane >= o) incl += v;
-                }
+                const uint32_t incl = wave_scan_incl(w);
                 if (e < nel) el_off[e] = (uint16_t)(W + incl - w);
-                W += __shfl(incl, 63);
+                W += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
         WSYNC();

@@ -1125,6 +1125,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     }
     // the tiers join on the context's stream, or, when the next batch is to run beside them, on the second stream
     hipStream_t js = k4 && pipelined ? c->stream2 : c->stream;
+    c->join_stream = js;
     if (k4) {
         if (!c->ev_join_small) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join_small, hipEventDisableTiming));
         launch_k4_end(a, js, c->stream2, c->stream3, pipelined ? c->stream3 : c->stream, c->ev_join, c->ev_join3, c->ev_join_small, c->ev_done);
@@ -1534,14 +1535,18 @@ static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch
     const int rc = run_classify(c, &sl.reads, 0, sl.n, sl.cand_cap != 0, sl.cand_cap, false, pipeline_on());
     c->out_results = nullptr; c->out_cands = nullptr; c->out_counts = nullptr;
     if (rc) return rc;
-    // The batch's decision kernels join on the context's second stream, and the copies back ride it behind them while the
-    // context's own stream goes on with the next batch.  (A stream of its own for the copies would be the fifth of the
-    // process: the runtime multiplexes streams onto 4 hardware queues, and a copy that shares its queue with the compute
-    // stream holds up the next batch's kernels behind it.)
-    HIPCHK(c, hipStreamWaitEvent(st->s_d2h, c->ev_done, 0));
-    HIPCHK(c, hipMemcpyAsync(sl.h_cursor, c->d_cursor, 4, hipMemcpyDeviceToHost, st->s_d2h));
-    HIPCHK(c, hipMemcpyAsync(sl.h_cursor + 1, c->d_err, 4, hipMemcpyDeviceToHost, st->s_d2h));
-    HIPCHK(c, hipEventRecord(sl.ev_done, st->s_d2h));
+    // The counters are copied out on the stream the batch's kernels joined on, and the set's `done` event is recorded again
+    // behind that copy: the next launch that takes this set of buffers clears the counters, and must not overtake it.
+    // The results ride the context's second stream (idle once the decision kernels have joined; with LMAT_PIPELINE it is
+    // the joining stream itself).  A stream of its own for them would be the fifth of the process: the runtime multiplexes
+    // streams onto 4 hardware queues, and a copy that shares its queue with the compute stream holds up the next batch's
+    // kernels behind it.
+    hipStream_t js = c->join_stream;
+    HIPCHK(c, hipMemcpyAsync(sl.h_cursor, c->d_cursor, 4, hipMemcpyDeviceToHost, js));
+    HIPCHK(c, hipMemcpyAsync(sl.h_cursor + 1, c->d_err, 4, hipMemcpyDeviceToHost, js));
+    HIPCHK(c, hipEventRecord(c->ev_done, js));
+    HIPCHK(c, hipEventRecord(sl.ev_done, js));
+    if (st->s_d2h != js) HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_done, 0));
     HIPCHK(c, hipMemcpyAsync(sl.h_results, sl.d_results, sl.n * sizeof(lmat_read_result), hipMemcpyDeviceToHost, st->s_d2h));
     HIPCHK(c, hipEventRecord(sl.ev_out, st->s_d2h));
     return LMAT_OK;

@@ -176,6 +176,7 @@ struct lmat_ctx {
         bool in_flight = false;
     } parked;
     hipEvent_t ev_done = nullptr;    // `done` of the set in use
+    hipStream_t join_stream = nullptr;  // where the last launch's kernels joined (its `done` was recorded there)
     bool set_in_flight = false;
     lmat::NullModelDev nm;         // device pointers owned by the context
     std::vector<void*> nm_allocs;
