@@ -533,7 +533,8 @@ __device__ __forceinline__ uint32_t lds_find(const unsigned long long* hv, int h
 
 // taxid hash entry: low 16 bits = taxid index (0 = empty); high 16 bits = registration slot (< 0x8000),
 // 0x8000|lane while a chunk decides who registers it, 0xFFFF = known key, not registered
-__device__ __forceinline__ uint32_t tid_hash(uint32_t t, int thmask) { return ((t * 0x9E3779B1u) >> 12) & thmask; }
+// taxids are 16 bits wide here: a 24-bit multiply (full rate) mixes them as well as a 32-bit one (quarter rate)
+__device__ __forceinline__ uint32_t tid_hash(uint32_t t, int thmask) { return (__umul24(t, 0x9E3779u) >> 10) & thmask; }
 __device__ __forceinline__ uint32_t tid_find_or_claim(unsigned int* hent, int thmask, uint32_t t) {
     uint32_t h = tid_hash(t, thmask);
     while (true) {
@@ -1387,7 +1388,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const LAS uint32_t* bk = stage + gidx * 16;
             const u32x4 t0 = *(const LAS u32x4*)bk;
             const uint32_t t4 = bk[4], t5 = bk[5];
-            const uint32_t key2 = tag * 0x10001u;
+            const uint32_t key2 = tag | (tag << 16);
             // z(x): each 16-bit half is 0 where the slot's tag equals the k-mer's, else 1 (tags are never 0, empty slots are)
             auto z = [&](uint32_t x) -> uint32_t {
                 const u16x2 d = __builtin_bit_cast(u16x2, x ^ key2), one = {1, 1};
