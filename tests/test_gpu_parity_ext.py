@@ -838,3 +838,18 @@ def test_batches_run_beside_each_other_give_the_same_answers():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_wide_table_format_gives_the_same_answers():
+    """LMAT_TABLE_FORMAT=wide keeps round 1's 8-byte-slot table (the non-compact kernel variants share every step after the
+    probe with the default ones).  Read once per process, so the text-parity tests run again in a child process with it set."""
+    import subprocess
+    import sys
+    if os.environ.get("LMAT_TABLE_FORMAT"):
+        pytest.skip("already the child run")
+    env = dict(os.environ, LMAT_TABLE_FORMAT="wide")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
+                        "-k", "config1_text_parity or parameter_variants or overflow_rerun or many_distinct or degenerate or long_reads or sorteddb"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
