@@ -1105,7 +1105,8 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     }
     {   // ... to the large LDS class (1024 taxids, reads up to 2067 bp), or directly to the global-memory class when the
         // batch holds reads beyond that.  These kernels make their own decision step, so they run beside the K4 kernels.
-        hipStream_t rs = k4 ? c->stream3 : c->stream;
+        static const bool rerun_side = getenv("LMAT_RERUN_SIDE") && atoi(getenv("LMAT_RERUN_SIDE")) != 0;  // experiments
+        hipStream_t rs = k4 && (pipelined || rerun_side) ? c->stream3 : c->stream;
         const bool lds_class = reads->max_len <= 2048 + 19;
         ClassifyArgs b = a;
         b.index = c->d_ovf2;
