@@ -224,7 +224,7 @@ def test_full_size_sample_parity(tmp_path, gb, n_reads, lens):
     single-GPU shard of [4]: a 200 GB-class DB (20 G 20-mers, near HBM capacity) with reads of 75-300 bp.  The whole
     batch runs on the GPU; a 20 k-read sample is re-derived by the CPU oracle from the GPU table's own lookups and
     must match byte for byte; size-independent properties are checked on all reads.  (LMAT_TEST_DB_GB /
-    LMAT_TEST_READS override the first case.)"""
+    LMAT_TEST_READS override the first case, LMAT_TEST_SAMPLE the sample size.)"""
     from lmat_amd import Engine, Params, synth
     import oracle_py
     if gb == 8:
@@ -252,7 +252,7 @@ def test_full_size_sample_parity(tmp_path, gb, n_reads, lens):
     called = res[res["status"] == 0]
     assert (called["call_score"] > 0).all() and (called["call_score"] <= 1.0).all()
     # sample parity through the oracle
-    ns = 20000
+    ns = min(n_reads, int(os.environ.get("LMAT_TEST_SAMPLE", "20000")))  # soak: LMAT_TEST_SAMPLE=200000
     tax = synth.make_taxonomy(br, specials=False)
     p = synth.write_aux_files(str(tmp_path), tax)
     orc = oracle_py.Oracle(p["tree"], p["depth"], p["rank"], p["idmap"])
