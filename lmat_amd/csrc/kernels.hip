@@ -454,7 +454,7 @@ static const uint16_t kLinNoGood = 0x8000;
 // K4 in LDS, three table sizes (registered taxids of a read): per-lane block = 6 x u16[T], u8[T], f32[T], LinEnt[LIN], an
 // odd number of dwords apart (conflict-free).  The lineage holds the candidates plus the appended ancestors: a read whose
 // chain is longer is passed on to the scratch kernel.
-static const int kFastE = 320;                       // kept-list elements a read of the fast classes may have (7 B of LDS each)
+static const int kFastE = 256;                       // kept-list elements a read of the fast classes may have (7 B of LDS each)
 static const int kK4SmallT = 16;                     // 64 lanes x 500 B: 5 waves per CU
 static const int kK4MidT = 32;                       // 64 lanes x 1028 B: 2 waves per CU
 template <int TT> struct K4Lds {
@@ -484,21 +484,26 @@ struct WL {
     static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T + 4 * T + 4 * T + T : 0);
     static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
     static constexpr int R2_K = CPT ? 0 : 8 * U + 4 * U;               // ukmer, ubucket (wide layout only)
-    static constexpr int R2_D = 4 * D + 2 * D + 2 * D + 2 * D + D + 2 * T + 2;  // dpay, dmult, dn, dstart, dfl (+ gene mode: sort order of the registered genes)
+    static constexpr int R2_D = 4 * D + 2 * D + 2 * D + 2 * D + D;     // dpay, dmult, dn, dstart, dfl
     static constexpr int R2_L = INK4 ? 12 * LIN : 0;                   // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
     static constexpr int R3_E = (INK4 ? 16 : 7) * E;                   // element staging (slots map to lanes: the per-id facts stay in registers)
     static constexpr int R3 = R3_P > R3_E ? R3_P : R3_E;
     static constexpr int OFF_RD = 0;
-    static constexpr int OFF_R1 = ((RD_WORDS * 4 + 15) / 16) * 16;
+    // The packed record is read by K1 only.  Where a class keeps the k-mers of a read in registers (U <= 512) and addresses
+    // the compact table, nothing else is written below OFF_R1 + 2048 before K1 is through, and the tables start at 0.
+    static constexpr int OFF_R1 = CPT && U <= 512 ? 0 : ((RD_WORDS * 4 + 15) / 16) * 16;
     static constexpr int OFF_R2 = OFF_R1 + ((R1 + 15) / 16) * 16;
     static constexpr int OFF_R3 = OFF_R2 + ((R2 + 15) / 16) * 16;
     static constexpr int BYTES_BASE = OFF_R3 + ((R3 + 15) / 16) * 16;
-    // compact-layout probe: a block of real LDS [bucket stage 4096 | repeat filter 512 | overflow-probe list 1024].
-    // Classes that keep a read's k-mers in registers (U <= 512) overlay it on R1..R3, which are idle until the probe is
-    // done; the others get it behind their tables (the global-memory class keeps nothing else in LDS).
-    static constexpr int XL_BYTES = 5632;
+    // compact-layout probe: a block of real LDS [bucket stage 2048: 32 buckets per round of loads | bucket of each group 256 |
+    // repeat filter 512 | overflow-probe list 1024].  Classes that keep a read's k-mers in registers (U <= 512) overlay it
+    // on R1..R3, which are idle until the probe is done; the others get it behind their tables (the global-memory class
+    // keeps nothing else in LDS).
+    static constexpr int XL_STAGE = 2048, XL_GBKT = XL_STAGE, XL_BLOOM = XL_GBKT + 256, XL_OLIST = XL_BLOOM + 512;
+    static constexpr int XL_BYTES = XL_OLIST + 1024;
+    static_assert(!(CPT && U <= 512) || RD_WORDS * 4 <= XL_STAGE, "the record lies under the stage, which K1 does not touch");
     static constexpr bool XL_OVERLAY = U <= 512;
     static constexpr int OFF_XL = XL_OVERLAY ? OFF_R1 : BYTES_BASE;
     // payload per k-mer position (compact) / per distinct k-mer (wide): at R3, or behind the block where that overlaps R3
@@ -975,7 +980,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         if (w >= 1 && w - 1 < (uint32_t)L::RD_WORDS) rd[w - 1] = (w - 1 < nb + nm) ? wcur[j] : 0u;
     }
     if (!CPT) { for (int i = lane; i < L::H; i += 64) hv[i] = kEmpty64; }
-    else { *(LAS u32x2*)(xl + 4096 + 8 * lane) = u32x2{0u, 0u}; }  // the repeat filter of the compact path
+    else { *(LAS u32x2*)(xl + L::XL_BLOOM + 8 * lane) = u32x2{0u, 0u}; }  // the repeat filter of the compact path
     WSYNC();
     const uint32_t* codes = rd;
     const uint32_t* vmask = rd + nb;
@@ -1247,11 +1252,10 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     // batched pass at the end.  upay[] gets one entry per k-mer POSITION (0 for repeats, misses and invalid
     // windows): K3 only needs the payloads in first-occurrence order, which position order is.
     LAS uint32_t* stage = (LAS uint32_t*)xl;
-    LAS uint32_t* gbkt = (LAS uint32_t*)(xl + 4096 - 256);  // bucket of group g while the loads are being issued: the tail of
-                                                            // the stage, which only the last wave-load of a full chunk overwrites
-    LAS unsigned int* bloomA = (LAS unsigned int*)(xl + 4096);
-    LAS unsigned int* bloomB = (LAS unsigned int*)(xl + 4096 + 256);
-    LAS u32x4* olist = (LAS u32x4*)(xl + 4608);     // k-mers to look up in the overflow table: k-mer, bucket, tag | position << 16
+    LAS uint32_t* gbkt = (LAS uint32_t*)(xl + L::XL_GBKT);  // bucket of group g of the chunk
+    LAS unsigned int* bloomA = (LAS unsigned int*)(xl + L::XL_BLOOM);
+    LAS unsigned int* bloomB = (LAS unsigned int*)(xl + L::XL_BLOOM + 256);
+    LAS u32x4* olist = (LAS u32x4*)(xl + L::XL_OLIST);  // k-mers to look up in the overflow table: k-mer, bucket, tag | position << 16
     const GAS u32x4* quarters = (const GAS u32x4*)g_slots;
     uint64_t firstm[KC];
     // ---- repeats.  A k-mer seen twice in a read is looked up once (read_label.cpp:985,1010,1017).  Exact detection
@@ -1369,40 +1373,44 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         const uint32_t gidx = prefix_count(lm) + (leader ? 1u : 0u) - 1u;  // group of this lane (ok lanes): leaders at or below it, minus one
         if (leader) gbkt[gidx] = b;
         WSYNC();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if ((uint32_t)s * 16 < ng) {
-                const uint32_t g = (uint32_t)s * 16 + ((uint32_t)lane >> 2);
-                if (g < ng) {
-                    const uint32_t gb = gbkt[g];
-                    __builtin_amdgcn_global_load_lds((const GAS void*)(quarters + (uint64_t)gb * 4 + (lane & 3)),
-                                                     (LAS void*)(xl + s * 1024), 16, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        WSYNC();
         uint32_t pay = 0;
         bool spill = false;
-        if (ok) {
-            const LAS uint32_t* bk = stage + gidx * 16;
-            const u32x4 t0 = *(const LAS u32x4*)bk;
-            const uint32_t t4 = bk[4], t5 = bk[5];
-            const uint32_t key2 = tag | (tag << 16);
-            // z(x): each 16-bit half is 0 where the slot's tag equals the k-mer's, else 1 (tags are never 0, empty slots are)
-            auto z = [&](uint32_t x) -> uint32_t {
-                const u16x2 d = __builtin_bit_cast(u16x2, x ^ key2), one = {1, 1};
-                return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, one));
-            };
-            const uint32_t miss = z(t0.x) | (z(t0.y) << 1) | (z(t0.z) << 2) | (z(t0.w) << 3) | (z(t4) << 4) | (z(t5) << 5);
-            const uint32_t acc = ~miss & 0x003F003Fu;  // bit i: slot 2i matches, bit 16 + i: slot 2i + 1
-            if (acc) {
-                const uint32_t bit = (uint32_t)__builtin_ctz(acc);
-                const uint32_t slot = 2 * (bit & 15u) + (bit >> 4);
-                pay = (uint32_t)((const LAS uint16_t*)bk)[12 + slot] | ((uint32_t)((const LAS uint8_t*)bk)[48 + slot] << 16);
-            } else {
-                spill = (bk[15] & kCptOvfFlag) != 0;
+        // the groups' buckets, 32 per round of loads (a chunk of a genome read has ~26 groups: one round)
+        for (uint32_t g0 = 0; g0 < ng; g0 += 32) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (g0 + (uint32_t)s * 16 < ng) {
+                    const uint32_t g = g0 + (uint32_t)s * 16 + ((uint32_t)lane >> 2);
+                    if (g < ng) {
+                        const uint32_t gb = gbkt[g];
+                        __builtin_amdgcn_global_load_lds((const GAS void*)(quarters + (uint64_t)gb * 4 + (lane & 3)),
+                                                         (LAS void*)(xl + s * 1024), 16, 0, 0);
+                    }
+                }
             }
+            __builtin_amdgcn_s_waitcnt(0);
+            WSYNC();
+            if (ok && gidx - g0 < 32u) {
+                const LAS uint32_t* bk = stage + (gidx - g0) * 16;
+                const u32x4 t0 = *(const LAS u32x4*)bk;
+                const uint32_t t4 = bk[4], t5 = bk[5];
+                const uint32_t key2 = tag | (tag << 16);
+                // z(x): each 16-bit half is 0 where the slot's tag equals the k-mer's, else 1 (tags are never 0, empty slots are)
+                auto z = [&](uint32_t x) -> uint32_t {
+                    const u16x2 d = __builtin_bit_cast(u16x2, x ^ key2), one = {1, 1};
+                    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, one));
+                };
+                const uint32_t miss = z(t0.x) | (z(t0.y) << 1) | (z(t0.z) << 2) | (z(t0.w) << 3) | (z(t4) << 4) | (z(t5) << 5);
+                const uint32_t acc = ~miss & 0x003F003Fu;  // bit i: slot 2i matches, bit 16 + i: slot 2i + 1
+                if (acc) {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(acc);
+                    const uint32_t slot = 2 * (bit & 15u) + (bit >> 4);
+                    pay = (uint32_t)((const LAS uint16_t*)bk)[12 + slot] | ((uint32_t)((const LAS uint8_t*)bk)[48 + slot] << 16);
+                } else {
+                    spill = (bk[15] & kCptOvfFlag) != 0;
+                }
+            }
+            if (g0 + 32 < ng) WSYNC();  // the next round overwrites the stage
         }
         if (p < P) upay[p] = first ? pay : 0u;
         const bool pend = first && spill;
@@ -1534,7 +1542,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         uint32_t* gval = (uint32_t*)best;     // registration slot of that gene; 0x80000000 | lane while a chunk decides; 0xFFFFFFFF = none yet
         uint32_t* greg = (uint32_t*)reg;      // [T] gene id per slot (reg + stamp)
         uint32_t* gcnt = (uint32_t*)cnt;      // [T] votes per slot (cnt + leaf)
-        uint16_t* gord = (uint16_t*)(lds + L::OFF_R2 + ((11 * L::D + 1) & ~1));  // [T] sort order, behind the d-arrays
+        uint16_t* gord = (uint16_t*)(lds + L::OFF_R3);  // [T] sort order: the head of the element area, which this mode leaves unused
         const GAS uint16_t* arena = g_arena;
         uint32_t nel = 0;
         bool overflow = false;
@@ -2405,7 +2413,7 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
 // resident waves per SIMD each class is compiled for: what its LDS footprint allows (and no more registers than that needs)
-constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 7 : 5) : (U <= 256 ? 5 : 3))); }
+constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 8 : 5) : (U <= 256 ? 5 : 3))); }
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
