@@ -2604,7 +2604,11 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     }
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
     const int per_cu = 160 * 1024 / lds_bytes;
-    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * 2;
+    // Reads differ in cost (one over genus-shared k-mers takes 3-4 times the usual), and a block keeps its share of the batch:
+    // with two blocks per wave slot the last ones ran alone for a fifth of the kernel.  32 per slot (8 reads each at 2 M reads):
+    // 6.66 -> 5.80 ms; beyond that the per-block start-up shows (LMAT_GRID_MULT to try).
+    static const int gmult = getenv("LMAT_GRID_MULT") ? atoi(getenv("LMAT_GRID_MULT")) : 32;
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * (gmult > 0 ? gmult : 32);
     if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)a.count;
     if (a.count_ptr && INK4 && grid > 512) grid = 512;  // the lists of the large classes are short; the E = 512 class may get a tenth of a batch
     if (grid < 1) grid = 1;
