@@ -325,7 +325,7 @@ def main():
                          "frac_measured": frac_measured,
                          "frac_bucket_only": mean_bucket * args.batch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_read_bucket_only": mean_bucket,
-                         "kernel": "classify_kernel<160,64,320,false,false,true>",
+                         "kernel": "classify_kernel<160,64,256,false,false,true>",
                          "kernel_avg_ms": avg_ms, "k4_kernels_avg_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.batch,
                          "random_64B_gather_ceiling_GBs": gather_gbs},
         }

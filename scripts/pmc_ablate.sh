@@ -9,7 +9,7 @@ for s in ${STOPS:-1 2 3 4 5 6 0}; do
 import csv, collections
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open("$OUT/p_counter_collection.csv")):
-    if "classify_kernel<160, 64, 320" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "classify_kernel<160, 64, 256" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("stop=$s", " ".join("%s=%.0f"%(k.replace("SQ_INSTS_","").replace("SQ_",""), sum(v)/len(v)/1e6) for k,v in sorted(agg.items())), "(per read, 1M reads)")
 PY
 done
