@@ -1723,6 +1723,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     // ---- phase 1 registration (read_label.cpp:1104-1122): first-lookup position order, then the depth-sorted
     //      order inside a k-mer's kept list == element order.  Within a chunk the lowest lane holding a new
     //      taxid registers it (atomicMin on the entry), so order is kept with several lists per chunk.
+    //      The same pass makes leaf_track (:1112-1116) and the kept ids' own position counts (:701-721): the hash entry of
+    //      an element's id is at hand.  cnt/leaf are packed u16 pairs updated with dword atomics, cleared for all slots.
+    for (uint32_t i = lane; i < (uint32_t)T; i += 64) ((unsigned int*)cnt)[i] = 0;  // covers cnt[T] and leaf[T]
     uint32_t nT = 0;
     for (uint32_t e0 = 0; e0 < nel && !overflow; e0 += 64) {
         const uint32_t e = e0 + lane;
@@ -1745,6 +1748,12 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
         }
         nT += newcnt;
         WSYNC();
+        if (act) {
+            const uint32_t s = hent[h] >> 16;
+            const uint32_t m = dmult[el_d[e]];
+            add_u16(leaf, s, m);
+            add_u16(cnt, s, m);
+        }
     }
     if (overflow) {
         if (lane == 0) {
@@ -1758,19 +1767,6 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     // the load is in flight while the counts are made
     u32x4 fz = u32x4{0u, 0u, 0u, 0u};
     if constexpr (!INK4) { if ((uint32_t)lane < nT) fz = g_facts16[reg[lane]]; }
-    // cnt/leaf are packed u16 pairs updated with dword atomics: clear them for all slots that can be used
-    for (uint32_t i = lane; i < (uint32_t)T; i += 64) ((unsigned int*)cnt)[i] = 0;  // covers cnt[T] and leaf[T]
-    WSYNC();
-    // leaf_track (:1112-1116) and the kept ids' own position counts (:701-721), all elements at once
-    for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
-        const uint32_t e = e0 + lane;
-        if (e < nel) {
-            const uint32_t s = hent[tid_find(hent, THM, el_t[e])] >> 16;
-            const uint32_t m = dmult[el_d[e]];
-            add_u16(leaf, s, m);
-            add_u16(cnt, s, m);
-        }
-    }
     WSYNC();
     if (A.prm.stop_after == 5) { if (lane == 0) { emit(250, nT); } return; }
     RELANE();
