@@ -870,14 +870,22 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
 #pragma push_macro("WSYNC")
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
+// The launch arguments are read where they are used, from the kernel-argument segment (scalar loads from constant memory),
+// through a pointer the compiler is made to forget at every phase boundary (REARGS): kept in scalar registers for the whole
+// kernel they did not fit (85 spilled into vector-register lanes, and every spill and refill is a vector instruction).
+typedef const ClassifyArgs __attribute__((address_space(4))) CArgs;
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
-__device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, unsigned char* lds, LAS unsigned char* xl, int lane,
+__device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned char* lds, LAS unsigned char* xl, int lane,
                                              const uint32_t* wcur, uint32_t (&nmacc)[2]) {
     using L = WL<U, T, E, INK4, CPT>;
     constexpr int THM = L::TH - 1;
     // RELANE: values derived from the lane id (LDS addresses, masks) are cheap; re-deriving them per phase keeps the
     // register allocator from carrying (and spilling) them across the probe phase, where 34 VGPRs hold loads in flight
-#define RELANE() asm volatile("" : "+v"(lane))
+#define RELANE() do { asm volatile("" : "+v"(lane)); asm volatile("" : "+s"(Ap)); } while (0)
+#pragma push_macro("A")
+#pragma push_macro("tb")
+#define A (*Ap)
+#define tb (Ap->tb)
     RELANE();
     uint32_t* rd = (uint32_t*)(lds + L::OFF_RD);
     // R1, hash phases
@@ -923,7 +931,6 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     uint16_t* el_plen = el_sp + E;               // path_len[ta]
     uint8_t* el_fl = (uint8_t*)(el_plen + E);    // flags[ta]
 
-    const DeviceTables& tb = A.tb;
     const int k = tb.k;
     const GAS uint64_t* g_slots = (const GAS uint64_t*)tb.slots;
     const GAS uint16_t* g_arena = (const GAS uint16_t*)tb.arena;
@@ -1437,7 +1444,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
             const bool ok = p < P && window(p, km, kr, fc);
             bool first = false;
             if (ok) {
-                cpt_address(tb.cpt, km, kr, b, t);
+                cpt_address(*(const CptGeom*)&tb.cpt, km, kr, b, t);
                 first = (uint32_t)(hv[lds_find(hv, L::H - 1, km)] & 0xFFFF) == p;
             }
             nuniq += (uint32_t)popc64(__ballot(first));
@@ -2066,7 +2073,9 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     res.status = LMAT_ST_NODBHITS; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = valid_kmers;
     res.read_len = (int)len; res.log_avg = 0; res.stdev = 0; res.call_tid = 0; res.call_score = 0;
     res.cand_off = 0; res.n_cand = 0; res.bin_sel = bin_sel;
-    const int nmt = nm_table_of(A.nm, cand);
+    const NullModelDev& nm_g = *(const NullModelDev*)&A.nm;  // the large classes' own decision step takes generic references
+    const KernelParams& prm_g = *(const KernelParams*)&A.prm;
+    const int nmt = nm_table_of(nm_g, cand);
     for (uint32_t s = lane; s < nT; s += 64) {
         const uint32_t t = reg[s];
         dep[s] = g_fdepth[t];
@@ -2088,7 +2097,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     K4State S;
     S.done = false; S.nlin = 0; S.highest = -1; S.highest_depth = 0; S.lidx = -1; S.lowest = -1; S.plasmid_slot = -1;
     S.top_score = 0; S.diff_thresh = 0;
-    if (lane == 0) k4_part1<L::LIN>(A.prm, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, (int)nT, cand, nmt >= 0, nm_rp, nm_cl, A.nm);
+    if (lane == 0) k4_part1<L::LIN>(prm_g, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, (int)nT, cand, nmt >= 0, nm_rp, nm_cl, nm_g);
     const int done = __builtin_amdgcn_readfirstlane((int)S.done);
     int nlin = __builtin_amdgcn_readfirstlane(S.nlin);
     const int highest = __builtin_amdgcn_readfirstlane(S.highest);
@@ -2135,7 +2144,7 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
                 if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
                 else G_OR(g_err, (uint32_t)kErrCandOverflow);
             }
-            k4_part2<L::LIN>(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
+            k4_part2<L::LIN>(prm_g, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
                      high_tout, cout_, &ncand, &call_idx);
         } else {
             call_idx = A.phix_call_idx;
@@ -2155,6 +2164,8 @@ __device__ __forceinline__ void classify_one(const ClassifyArgs& A, uint64_t r, 
     }
 }
 
+#pragma pop_macro("tb")
+#pragma pop_macro("A")
 #pragma pop_macro("WSYNC")
 
 // ------------------------------------------------------------------------------------------
@@ -2439,7 +2450,7 @@ __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_
         const uint64_t off2 = it + 2 * G < count ? rec_off[r_of(it + 2 * G)] : 0;
 #pragma unroll
         for (int j = 0; j < NW; ++j) wnext[j] = it + G < count ? words[off1 + lane + 64 * j] : 0u;
-        classify_one<U, T, E, INK4, PERM, CPT>(A, r_of(it), smem, xl, lane, wcur, nmacc);
+        classify_one<U, T, E, INK4, PERM, CPT>((CArgs*)__builtin_amdgcn_kernarg_segment_ptr(), r_of(it), smem, xl, lane, wcur, nmacc);
         WSYNC();
 #pragma unroll
         for (int j = 0; j < NW; ++j) wcur[j] = wnext[j];
