@@ -482,7 +482,10 @@ struct WL {
     // reg, stamp, cnt, leaf (u16) | hent, best (u32) | in-kernel K4: dep, ord, tin, tout (u16), score (f32), sflags (u8),
     // score0, nm_rp (f32), nm_cl (u8)
     static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T + 4 * T + 4 * T + T : 0);
-    static constexpr int R1 = R1_HASH > R1_TID ? R1_HASH : R1_TID;
+    // The k-mer hash of the compact path (reads whose repeat filter fires) is through before the probe writes anything: in the
+    // classes that overlay the probe's block on their tables it may run on over R2 / R3 and the payload array behind R1.
+    static constexpr bool HASH_OVER = CPT && U <= 512 && !INK4;
+    static constexpr int R1 = HASH_OVER ? R1_TID : (R1_HASH > R1_TID ? R1_HASH : R1_TID);
     static constexpr int R2_K = CPT ? 0 : 8 * U + 4 * U;               // ukmer, ubucket (wide layout only)
     static constexpr int R2_D = 4 * D + 2 * D + 2 * D + 2 * D + D;     // dpay, dmult, dn, dstart, dfl
     static constexpr int R2_L = INK4 ? 12 * LIN : 0;                   // lineage (K4, after the d-arrays die)
@@ -510,7 +513,8 @@ struct WL {
     static constexpr int OFF_UPAY_C = XL_OVERLAY && OFF_R1 + XL_BYTES > OFF_R3 ? OFF_R1 + XL_BYTES : OFF_R3;
     static constexpr int BYTES_C = XL_OVERLAY ? (OFF_UPAY_C + 4 * U > BYTES_BASE ? ((OFF_UPAY_C + 4 * U + 15) / 16) * 16 : BYTES_BASE)
                                               : BYTES_BASE + XL_BYTES;
-    static constexpr int BYTES = CPT ? BYTES_C : BYTES_BASE;
+    static constexpr int BYTES_H = HASH_OVER && OFF_R1 + R1_HASH > BYTES_C ? OFF_R1 + R1_HASH : BYTES_C;
+    static constexpr int BYTES = CPT ? BYTES_H : BYTES_BASE;
 };
 
 static const uint64_t kEmpty64 = ~0ull;
@@ -2420,7 +2424,7 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
 // resident waves per SIMD each class is compiled for: what its LDS footprint allows (and no more registers than that needs)
-constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 8 : 5) : (U <= 256 ? 5 : 3))); }
+constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 8 : 5) : (U <= 256 ? (CPT ? 6 : 5) : (CPT ? 4 : 3)))); }
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
