@@ -2424,7 +2424,7 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
 // resident waves per SIMD each class is compiled for: what its LDS footprint allows (and no more registers than that needs)
-constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 8 : 5) : (U <= 256 ? (CPT ? 6 : 5) : (CPT ? 4 : 3)))); }
+constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 8 : 5) : (U <= 256 ? (CPT ? 8 : 5) : (CPT ? 4 : 3)))); }
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
