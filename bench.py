@@ -181,25 +181,62 @@ def e2e_stream(eng, reads, batch, steps, warmup, log):
                     "copy in / kernels / copy out overlapped (lmat_stream_*); calls only"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes, one per GPU, started by THIS process, which
+    never imports torch or touches HIP itself (a parent that had could not safely start GPU children).  Each child gets the
+    environment a launcher would set; rank 0's stdout (the JSON line) is this process's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--db-gb", type=float, default=64.0, help="hash table size in GiB (BASELINE metric: 64)")
-    ap.add_argument("--batch", type=int, default=2_000_000, help="reads per step per GPU")
+    ap.add_argument("--batch", type=int, default=8_000_000, help="reads per step per GPU (rounded up to whole launches)")
+    ap.add_argument("--launch-reads", type=int, default=2_000_000, help="reads per classify launch: a step is batch / launch-reads launches")
     ap.add_argument("--read-len", default="150", help="read length, or a comma list for a mixed-length batch (not the headline workload)")
     ap.add_argument("--cpu-sample", type=int, default=40000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--list-replicas", type=int, default=1, help="copies of every distinct taxid list in the arena, one per 512-base stretch of a genome (5: 4 M lists, 250 MB -- the most 24-bit payloads address)")
     ap.add_argument("--genus-permille", type=int, default=100, help="share of every genome that is a block shared within its genus (SURVEY 8d: 100)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the boundary-inclusive (pinned host -> H2D -> classify -> D2H) leg")
+    ap.add_argument("--windows", type=int, default=5, help="the timed window of --steps steps is `value`; this many further windows of the same steps give value_median_of_windows (0: none)")
+    ap.add_argument("--as-ranks", type=int, default=1, help="tests: ONE rank classifies the read sets of this many ranks one after the other (what an N-rank run must add up to)")
+    ap.add_argument("--tally-out", default=None, help="tests: rank 0 writes the merged per-taxid tallies to this JSON file")
+    ap.add_argument("--spawn-check", action="store_true", help="tests: every rank prints the environment it was started with and exits before touching a GPU")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     T0 = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.spawn_check:
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR"),
+                          "torch_loaded_in_parent": "torch" in sys.modules}), file=sys.stderr if rank else sys.stdout)
+        return
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     import torch
     # LMAT_BENCH_REHEARSE=1: N ranks on ONE GPU over gloo, to rehearse the multi-rank control flow on a 1-GPU box
     rehearse = os.environ.get("LMAT_BENCH_REHEARSE") == "1"
@@ -232,12 +269,28 @@ def main():
     eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes, genus_block_permille=args.genus_permille, list_replicas=args.list_replicas)
     t_build = time.perf_counter() - t0
     log(f"db built: {eng.db_size} k-mers in {t_build:.2f}s, table {table_bytes / 2**30:.1f} GiB, G={G}")
+    # a step = one pass of the path over one batch of --batch reads, classified as launches of --launch-reads reads each
+    args.launch_reads = max(1, min(args.launch_reads, args.batch))
+    lps = (args.batch + args.launch_reads - 1) // args.launch_reads  # launches per step
+    args.batch = lps * args.launch_reads
     n_steps_total = args.steps + args.warmup
     n_reads = args.batch * n_steps_total
     read_lens = tuple(int(x) for x in str(args.read_len).split(","))
     args.read_len = read_lens[0] if len(read_lens) == 1 else "/".join(str(x) for x in read_lens)
-    reads = eng.synth_reads(n_reads, read_lens, seed=3003 + 7919 * rank)
+    # rank r's reads come from seed 3003 + 7919 r; --as-ranks R (tests): this one rank takes the sets of ranks 0..R-1 in turn
+    read_sets = [eng.synth_reads(n_reads, read_lens, seed=3003 + 7919 * (rank + j)) for j in range(args.as_ranks)]
+    reads = read_sets[0]
     log(f"{n_reads} reads generated ({reads.device_bytes / 2**20:.0f} MiB packed)")
+    # the tally merge across ranks is the engine's own RCCL all-reduce (lmat_comm_*, collective.cpp): rank 0 makes the
+    # communicator id, the launcher's channel (here: torch.distributed's broadcast) hands it round.  The rehearsal mode
+    # (N ranks on ONE GPU) cannot form an RCCL communicator -- two ranks on one device -- and sums over gloo instead.
+    if dist is not None and not rehearse:
+        uid = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        eng.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+        log(f"RCCL communicator of {world} ranks inside the engine")
 
     def barrier():
         torch.cuda.synchronize()
@@ -257,15 +310,27 @@ def main():
     t_sc = torch.as_tensor(_Buf(base + 8 * n_ids, n_ids, "<f8"), device=f"cuda:{local_rank}")
     t_nm = torch.as_tensor(_Buf(base + 16 * n_ids, 3, "<i8"), device=f"cuda:{local_rank}")
 
+    def run_step(rs, step):
+        for l_ in range(lps):
+            eng.classify_async(rs, (step * lps + l_) * args.launch_reads, args.launch_reads)
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     for w in range(args.warmup):
-        eng.classify_async(reads, w * args.batch, args.batch)
+        run_step(reads, w)
     wms, wl = eng.sync()
     log(f"warmup done: {wl} launches, {wms:.1f} ms kernel time")
     eng.counts_reset()
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        eng.classify_async(reads, (args.warmup + s) * args.batch, args.batch)
+    for rs in read_sets:
+        for s in range(args.steps):
+            run_step(rs, args.warmup + s)
     kernel_ms, launches = eng.sync()
     classify_ms, decide_ms, _ = eng.last_timing()
     from lmat_amd.shard import allreduce_tallies
@@ -274,25 +339,37 @@ def main():
         allreduce_tallies(host[0], host[1], host[2], dist)
         for d_, h_ in zip((t_cnt, t_sc, t_nm), host):
             d_.copy_(h_)
-    else:
-        allreduce_tallies(t_cnt, t_sc, t_nm, dist)  # merge step of read_label.cpp:1760-1800
+    elif dist is not None:
+        eng.comm_allreduce_counts()  # merge step of read_label.cpp:1760-1800: ncclAllReduce on the tally buffers in HBM
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = reduce_max(time.perf_counter() - t0)
 
     log(f"timed region {dt:.3f}s, kernels {kernel_ms:.1f} ms over {launches} launches (classify {classify_ms:.1f} + decide {decide_ms:.1f})")
-    total_reads = args.batch * args.steps * world
+    total_reads = args.batch * args.steps * world * args.as_ranks
     value = total_reads / dt
+    merged = eng.counts() if rank == 0 else None   # the job's tallies, before the extra windows add to them
+    # further windows of the same K steps (same barriers, max over ranks): their median says how far one slow launch moved `value`
+    win = []
+    for _ in range(max(args.windows, 0)):
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            run_step(reads, args.warmup + s)
+        eng.sync()
+        barrier()
+        win.append(args.batch * args.steps * world / reduce_max(time.perf_counter() - t0))
     if rank == 0:
-        counts, nomatch = eng.counts()
+        counts, nomatch = merged
         called = sum(c for c, _ in counts.values())
+        if args.tally_out:
+            with open(args.tally_out, "w") as f:
+                json.dump({"n_gpus": world, "counts": {str(t): c for t, (c, _) in sorted(counts.items())},
+                           "scores": {str(t): sc for t, (_, sc) in sorted(counts.items())}, "nomatch": nomatch}, f)
         mean_b, mean_bucket = sample_algorithmic_bytes(eng, reads, 2000, k)
         log(f"algorithmic bytes/read = {mean_b:.0f} (reads + one 64-B bucket per distinct k-mer + result: {mean_bucket:.0f})")
         avg_ms = classify_ms / max(launches, 1)  # dominant kernel only: classify_kernel (HBM-bound probe inside)
-        achieved = mean_b * args.batch / (avg_ms * 1e-3) / 1e9
+        achieved = mean_b * args.launch_reads / (avg_ms * 1e-3) / 1e9
+        step_ms = (classify_ms + decide_ms) / max(launches, 1)  # every kernel of a launch: classify + decision tiers + re-runs
         # HBM bytes per launch come from PMC counters, which only a rocprofv3 run of this command can collect
         # (scripts/profile_gpu.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, condensed into profiles/): the number
         # is carried over from that committed file and labelled as such, never presented as measured in this run
@@ -301,7 +378,7 @@ def main():
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                same = tj.get("reads_per_launch") == args.batch and tj.get("db_gib") == args.db_gb and tj.get("read_len") == args.read_len
+                same = tj.get("reads_per_launch") == args.launch_reads and tj.get("db_gib") == args.db_gb and tj.get("read_len") == args.read_len
                 if same:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_from = f"{tj.get('from')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on another run (kernel {tj.get('kernel_avg_ms'):.2f} ms there)"
@@ -313,29 +390,32 @@ def main():
         log(f"random 64-B gather ceiling on this table: {gather_gbs:.0f} GB/s")
         out = {
             "metric": "reads/s (150 bp) vs 64 GB k-mer DB", "value": value, "unit": "reads/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / (args.steps * args.as_ranks) * 1e3,
+            "value_median_of_windows": float(np.median(win)) if win else None, "windows": [round(x) for x in win],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.batch * args.steps} x {args.read_len} bp reads/GPU vs {args.db_gb:g} GiB "
                                    f"k-mer hash ({eng.db_size} 20-mers, replicated per GPU), run_rl.sh flags -x 0 -j 30 -l 0 -b 1, calls-only",
-                       "reads_per_step_per_gpu": args.batch, "read_len": args.read_len, "db_gib": args.db_gb,
+                       "reads_per_step_per_gpu": args.batch, "launches_per_step": lps, "reads_per_launch": args.launch_reads, "read_len": args.read_len, "db_gib": args.db_gb,
                        "db_kmers": eng.db_size, "k": k, "parallelism": f"reads sharded x{world}, DB replicated",
                        "db_build_s": round(t_build, 2), "genus_block_permille": args.genus_permille, "list_replicas": args.list_replicas, "distinct_lists": eng.n_lists, "list_arena_mib": round(eng.arena_bytes / 2**20, 1), "reads_called": called, "nomatch": nomatch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                          "frac_measured": frac_measured,
-                         "frac_bucket_only": mean_bucket * args.batch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_step": mean_b * args.launch_reads / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_bucket_only": mean_bucket * args.launch_reads / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_read_bucket_only": mean_bucket,
                          "kernel": "classify_kernel<160,64,256,false,false,true>",
-                         "kernel_avg_ms": avg_ms, "k4_kernels_avg_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.batch,
+                         "kernel_avg_ms": avg_ms, "k4_kernels_avg_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.launch_reads,
                          "random_64B_gather_ceiling_GBs": gather_gbs},
         }
         if world == 1 and not args.no_e2e and len(read_lens) == 1:
-            out["e2e_stream"] = e2e_stream(eng, reads, args.batch, args.steps, args.warmup, log)
+            out["e2e_stream"] = e2e_stream(eng, reads, args.launch_reads, args.steps * lps, args.warmup * lps, log)
         if world == 1 and not args.no_cpu:
             with tempfile.TemporaryDirectory() as td:
                 out["cpu_baseline"] = cpu_baseline(eng, reads, args.cpu_sample, k, td)
         print(json.dumps(out))
-    reads.free()
+    for rs in read_sets:
+        rs.free()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

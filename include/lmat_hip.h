@@ -115,6 +115,10 @@ int lmat_db_set_build_options(lmat_ctx* ctx, int tid_cutoff, const char* rank_ma
  * src/make_db_table.cpp:330-343,429): save between begin and finalize; load + finalize to use it. */
 int lmat_db_save_image(lmat_ctx* ctx, const char* fn);
 int lmat_db_load_image(lmat_ctx* ctx, const char* fn, uint64_t table_bytes);
+/* A replica of src's finalized database in dst (another GPU of the node, or the same one): the k-mer table, its
+ * overflow table and the list arena are copied device to device (hipMemcpyPeer: over xGMI between GPUs), instead of
+ * every GPU parsing the files again.  dst must hold the same taxonomy and label modes as src and no database yet. */
+int lmat_db_clone(lmat_ctx* dst, lmat_ctx* src);
 int lmat_db_kmer_length(const lmat_ctx* ctx);   /* SortedDb::get_kmer_length (SortedDb.hpp:433) */
 uint64_t lmat_db_size(const lmat_ctx* ctx);      /* SortedDb::size (SortedDb.hpp:438)            */
 uint64_t lmat_db_list_count(const lmat_ctx* ctx); /* distinct taxid-list records of a synthetic database (0: not counted) */
@@ -236,9 +240,23 @@ int lmat_counts_layout(const lmat_ctx* ctx, uint32_t* n_ids, uint64_t* bytes);
 void* lmat_counts_device_ptr(lmat_ctx* ctx);
 int lmat_counts_get(lmat_ctx* ctx, uint32_t* tid32, uint64_t* count, double* score, uint32_t cap, uint32_t* n_nonzero,
                     uint64_t nomatch3[3]);
-/* The same merge across the contexts of one process (one per GPU, read_label -t N on an N-GPU node): afterwards every
- * context holds the sum of all.  Host-side sum of the ~50 KB arrays. */
+/* The same merge across the contexts of ONE process (one per GPU, read_label -t N on an N-GPU node): afterwards every
+ * context holds the sum of all.  Contexts on distinct devices: RCCL over xGMI (ncclCommInitAll over their devices, kept
+ * for the next call, + one grouped ncclAllReduce per array on each context's stream).  Contexts that share a device
+ * cannot be ranks of one communicator: those are summed through the host. */
 int lmat_counts_allreduce(lmat_ctx** ctxs, int n_ctx);
+
+/* ... and across PROCESSES, one context (= one GPU) per rank, whatever launched them: rank 0 makes an id
+ * (ncclGetUniqueId), the launcher's own channel hands its LMAT_COMM_ID_BYTES bytes to the other ranks, every rank calls
+ * lmat_comm_init (ncclCommInitRank; collective), then lmat_comm_allreduce_counts sums the tallies in place on all ranks
+ * (ncclAllReduce on the context's stream, u64 counts / f64 score sums / u64 nomatch; returns when it is complete).
+ * librccl is opened on first use of these entry points, never by a one-GPU run. */
+#define LMAT_COMM_ID_BYTES 128
+int lmat_comm_unique_id(uint8_t* id /* [LMAT_COMM_ID_BYTES] */);
+int lmat_comm_init(lmat_ctx* ctx, const uint8_t* id, int n_ranks, int rank);
+int lmat_comm_allreduce_counts(lmat_ctx* ctx);
+int lmat_comm_size(const lmat_ctx* ctx);   /* ranks of the communicator, 0 = none */
+void lmat_comm_destroy(lmat_ctx* ctx);
 
 /* ---- rand_read_label: the null-model generator (src/rand_read_label.cpp) on the same kernels -----------
  * Replaces its proc_line/construct_labels (:185-213, :372-398) over src/rkmer.hpp's retrieve_kmer_labels, which is

@@ -115,6 +115,12 @@ def load_library(path: str | None = None):
         "lmat_stream_release": (i32, [vp]),
         "lmat_stream_destroy": (None, [vp]),
         "lmat_counts_allreduce": (i32, [P(vp), i32]),
+        "lmat_comm_unique_id": (i32, [vp]),
+        "lmat_comm_init": (i32, [vp, vp, i32, i32]),
+        "lmat_comm_allreduce_counts": (i32, [vp]),
+        "lmat_comm_size": (i32, [vp]),
+        "lmat_comm_destroy": (None, [vp]),
+        "lmat_db_clone": (i32, [vp, vp]),
         "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
     }
@@ -138,7 +144,8 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
-            "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce"]
+            "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
+            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone"]
 
 
 def _ptr(a):
@@ -504,6 +511,27 @@ class Engine:
 
     def counts_device_ptr(self):
         return int(self.lib.lmat_counts_device_ptr(self.ctx) or 0)
+
+    # tallies across ranks: RCCL inside the engine (collective.cpp) ---------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: 128 bytes made by one rank and handed to the others by the launcher's own channel."""
+        buf = C.create_string_buffer(128)
+        rc = load_library().lmat_comm_unique_id(buf)
+        if rc != 0:
+            raise LmatError(rc, "cannot open librccl / make a communicator id")
+        return buf.raw
+
+    def comm_init(self, uid: bytes, n_ranks: int, rank: int):
+        assert len(uid) == 128
+        self._chk(self.lib.lmat_comm_init(self.ctx, C.c_char_p(uid), n_ranks, rank))
+
+    def comm_allreduce_counts(self):
+        """The merge of read_label.cpp:1760-1800 across ranks: every rank's tallies become the sum of all."""
+        self._chk(self.lib.lmat_comm_allreduce_counts(self.ctx))
+
+    def clone_db_from(self, src: "Engine"):
+        self._chk(self.lib.lmat_db_clone(self.ctx, src.ctx))
 
     def counts(self):
         n, _ = self.counts_layout()

@@ -11,6 +11,7 @@
 //   K3 registration/closure/count src/read_label.cpp:1104-1204, 692-764
 //   K4 score + decision           src/read_label.cpp:803-941, 284-419, 225-282
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <type_traits>
 #include "kernels.hpp"
 
@@ -2473,6 +2474,18 @@ __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// hipFuncSetAttribute applies to the CURRENT device's copy of a kernel: one process drives one context per GPU, each from its
+// own thread, so "already raised" is kept per device (an atomic flag per device; setting it twice is harmless).
+struct PerDeviceOnce {
+    std::atomic<unsigned char> done[64];
+    PerDeviceOnce() { for (auto& d : done) d.store(0); }
+    template <class F> void operator()(F&& f) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { f(); return; }
+        if (!done[dev].load(std::memory_order_acquire)) { f(); done[dev].store(1, std::memory_order_release); }
+    }
+};
+
 static int grid_for(uint64_t n, int per_block, int cap) {
     uint64_t b = (n + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -2534,11 +2547,8 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
 template <int TT>
 static void launch_k4_lds(const ClassifyArgs& a, uint64_t max_reads, hipStream_t stream) {
     using K = K4Lds<TT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)k4_lds_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::BYTES);
-        attr_set = true;
-    }
+    static PerDeviceOnce attr_once;
+    attr_once([] { hipFuncSetAttribute((const void*)k4_lds_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, K::BYTES); });
     const uint64_t per_cu = 160 * 1024 / K::BYTES;
     uint64_t g = (max_reads + K::LANES - 1) / K::LANES;
     if (g > 256 * per_cu) g = 256 * per_cu;
@@ -2608,11 +2618,8 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     }
     static const int lds_pad = getenv("LMAT_LDS_PAD") ? atoi(getenv("LMAT_LDS_PAD")) : 0;  // experiments: fewer resident waves
     const int lds_bytes = L::BYTES + lds_pad;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
+    static PerDeviceOnce attr_once;
+    attr_once([lds_bytes] { hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
     const int per_cu = 160 * 1024 / lds_bytes;
     // Reads differ in cost (one over genus-shared k-mers takes 3-4 times the usual), and a block keeps its share of the batch:

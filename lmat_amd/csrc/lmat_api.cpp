@@ -125,6 +125,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
         if (p) hipFree(p);
     sb_free(c);
     free_null_models(c);
+    comm_free(c);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_join3) hipEventDestroy(c->ev_join3);
@@ -544,6 +545,49 @@ int lmat_db_from_ingest(lmat_ctx* c, lmat_ingest* g, uint64_t table_bytes) {
     if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
     c->db_ready = false;
     return build_device_db(c, g->ing, table_bytes);
+}
+
+// A replica of a finalized database on another context: table, overflow table and arena copied device to device.
+int lmat_db_clone(lmat_ctx* d, lmat_ctx* s) {
+    if (!d || !s || d == s) return LMAT_E_ARG;
+    if (!s->db_ready) return set_err(d, LMAT_E_ARG, "the source context holds no finalized database");
+    if (d->db_ready || d->ingest) return set_err(d, LMAT_E_ARG, "the destination already holds a database");
+    if (s->gene_mode != d->gene_mode || (!s->gene_mode && (!d->tax.loaded || d->tax.n != s->tax.n || d->tax.tid32 != s->tax.tid32)))
+        return set_err(d, LMAT_E_TAXONOMY, "load the same taxonomy into the destination first");
+    if (d->permissive != s->permissive || d->rt_tid_cut != s->rt_tid_cut || d->rand_mode != s->rand_mode)
+        return set_err(d, LMAT_E_ARG, "the label modes of the two contexts differ (they shape the list records)");
+    hipSetDevice(s->device);
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    if (d->device != s->device) {  // direct copies over xGMI when the link allows it; staged by the runtime otherwise
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, d->device, s->device) == hipSuccess && can) {
+            hipSetDevice(d->device);
+            hipError_t e = hipDeviceEnablePeerAccess(s->device, 0);
+            if (e != hipSuccess) (void)hipGetLastError();  // already enabled, or not allowed: the copy still works
+        }
+    }
+    hipSetDevice(d->device);
+    DeviceTables& D = d->dev;
+    const DeviceTables& S = s->dev;
+    if (D.slots) { hipFree(D.slots); D.slots = nullptr; }
+    if (D.ovf_slots) { hipFree(D.ovf_slots); D.ovf_slots = nullptr; }
+    if (D.arena) { hipFree(D.arena); D.arena = nullptr; }
+    const uint64_t nb = S.cpt.nb ? S.cpt.nb : (uint64_t)S.nbuckets;
+    const uint64_t arena_bytes = s->arena_words * 2 + 64;  // (every builder leaves at least 16 bytes of slack behind the records)
+    HIPCHK(d, hipMalloc((void**)&D.slots, nb * 64));
+    HIPCHK(d, hipMemcpyPeerAsync(D.slots, d->device, S.slots, s->device, nb * 64, d->stream));
+    if (S.ovf_slots) {
+        HIPCHK(d, hipMalloc((void**)&D.ovf_slots, (uint64_t)S.ovf_nbuckets * 64));
+        HIPCHK(d, hipMemcpyPeerAsync(D.ovf_slots, d->device, S.ovf_slots, s->device, (uint64_t)S.ovf_nbuckets * 64, d->stream));
+    }
+    HIPCHK(d, hipMalloc((void**)&D.arena, arena_bytes));
+    HIPCHK(d, hipMemsetAsync(D.arena, 0, arena_bytes, d->stream));
+    HIPCHK(d, hipMemcpyPeerAsync(D.arena, d->device, S.arena, s->device, s->arena_words * 2, d->stream));
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    D.nbuckets = S.nbuckets; D.cpt = S.cpt; D.ovf_nbuckets = S.ovf_nbuckets; D.k = S.k;
+    d->n_kmers = s->n_kmers; d->arena_words = s->arena_words; d->n_lists = s->n_lists;
+    d->db_ready = true;
+    return LMAT_OK;
 }
 
 int lmat_db_kmer_length(const lmat_ctx* c) { return c ? c->dev.k : 0; }
@@ -1724,39 +1768,6 @@ int lmat_stream_release(lmat_stream* st) {
     if (sl.state != 3) return set_err(st->c, LMAT_E_ARG, "no batch is checked out");
     sl.state = 0;
     ++st->tail;
-    return LMAT_OK;
-}
-
-// ---------------------------------------------------------------------------------- tallies across contexts
-// The merge of read_label.cpp:1760-1800 for several contexts of ONE process (one per GPU): every context ends up
-// holding the sum.  Host-side: the arrays are ~50 KB, so each is copied out, summed and copied back; no collective
-// library is involved (one process per GPU uses RCCL on lmat_counts_device_ptr instead, as bench.py does).
-int lmat_counts_allreduce(lmat_ctx** ctxs, int n) {
-    if (!ctxs || n < 1) return LMAT_E_ARG;
-    for (int i = 0; i < n; ++i)
-        if (!ctxs[i] || !ctxs[i]->d_counts || ctxs[i]->counts_bytes != ctxs[0]->counts_bytes)
-            return ctxs[i] ? set_err(ctxs[i], LMAT_E_ARG, "contexts must hold the same taxonomy") : LMAT_E_ARG;
-    const uint64_t bytes = ctxs[0]->counts_bytes;
-    const uint32_t ids = ctxs[0]->dev.n_ids;
-    std::vector<unsigned char> sum(bytes, 0), buf(bytes);
-    uint64_t* sc = (uint64_t*)sum.data();
-    double* ss = (double*)(sc + ids);
-    uint64_t* sn = (uint64_t*)(ss + ids);
-    for (int i = 0; i < n; ++i) {
-        lmat_ctx* c = ctxs[i];
-        hipSetDevice(c->device);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy(buf.data(), c->d_counts, bytes, hipMemcpyDeviceToHost));
-        const uint64_t* bc = (const uint64_t*)buf.data();
-        const double* bs = (const double*)(bc + ids);
-        const uint64_t* bn = (const uint64_t*)(bs + ids);
-        for (uint32_t j = 0; j < ids; ++j) { sc[j] += bc[j]; ss[j] += bs[j]; }
-        for (int j = 0; j < 3; ++j) sn[j] += bn[j];
-    }
-    for (int i = 0; i < n; ++i) {
-        hipSetDevice(ctxs[i]->device);
-        HIPCHK(ctxs[i], hipMemcpy(ctxs[i]->d_counts, sum.data(), bytes, hipMemcpyHostToDevice));
-    }
     return LMAT_OK;
 }
 

@@ -194,6 +194,12 @@ struct lmat_ctx {
     float kernel_ms_total = 0, kernel2_ms_total = 0, last_classify_ms = 0, last_decide_ms = 0;
     uint64_t last_launches = 0;
     uint64_t kernel_launches = 0;
+    // RCCL communicators (collective.cpp; opaque here): comm_ranks = this context as one rank of a multi-process job
+    // (lmat_comm_init), comm_local = as one of the contexts of this process (lmat_counts_allreduce), keyed by the device list
+    void* comm_ranks = nullptr;
+    int comm_n = 0, comm_rank = 0;
+    void* comm_local = nullptr;
+    std::string comm_local_key;
 };
 
 namespace lmat {
@@ -206,4 +212,5 @@ int load_null_models(lmat_ctx* c, const char* list_fn);
 void free_null_models(lmat_ctx* c);
 // compute the arena record of one raw list; returns false (err set) on invalid ids
 bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec);
+void comm_free(lmat_ctx* c);
 }  // namespace lmat

@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <set>
@@ -116,9 +117,15 @@ struct Batch {
     Batch& operator=(const Batch&) = delete;
     size_t n() const { return hoff.size() - 1; }
     size_t room() const { return g_pool.cap - nb; }
-    void add_bases(const void* p, size_t len) { memcpy(bases + nb, p, len); nb += len; }
+    bool overflow = false;            // something did not fit the pinned buffer: the batch is unusable and the run fails
+    bool add_bases(const void* p, size_t len) {
+        if (len > room()) { overflow = true; return false; }
+        memcpy(bases + nb, p, len);
+        nb += len;
+        return true;
+    }
     void add_hdr(const char* p, size_t len) { hdr_blob.append(p, len); hoff.push_back(hdr_blob.size()); }
-    void clear() { nb = 0; off.assign(1, 0); hdr_blob.clear(); hoff.assign(1, 0); }
+    void clear() { nb = 0; overflow = false; off.assign(1, 0); hdr_blob.clear(); hoff.assign(1, 0); }
 };
 
 // CPUs this process may actually use: the cgroup quota when there is one (a container with 16 CPUs on a 256-thread host
@@ -159,7 +166,7 @@ static void parse_fasta_piece(const char* p, const char* end, Batch& b) {
             hdr = p + 1;
             hdr_len = len - 1;
         } else if (len > 1) {
-            b.add_bases(p, len);  // a piece is never larger than a pool buffer
+            if (!b.add_bases(p, len)) return;  // the cutter keeps pieces within a pool buffer; if one is not, the caller fails the run
             open = true;
         }
         p = nl ? nl + 1 : end;
@@ -345,16 +352,23 @@ int main(int argc, char* argv[]) {
     if (const char* e = getenv("LMAT_FORMAT_THREADS")) n_fmt_plan = std::max(1, atoi(e));
     std::vector<lmat_stream*> rings(n_gpu, nullptr);
     rings_p = &rings;
-    // every GPU loads the taxonomy and the whole database (the table is replicated, reads are dealt out); the pinned
-    // batch buffers are allocated meanwhile
+    // every GPU loads the taxonomy itself (small); the database is parsed and built ONCE, on the first GPU, and the
+    // others receive a replica of its table, overflow table and list arena device to device (lmat_db_clone:
+    // hipMemcpyPeer over xGMI) -- not one parse of a 64 GB database per GPU.  The pinned batch buffers are allocated meanwhile
     std::vector<std::string> setup_err(n_gpu);
     bool pool_ok = true;
     {
+        std::promise<bool> first_ready;
+        std::shared_future<bool> first_ok = first_ready.get_future().share();
         std::vector<std::thread> th;
         th.emplace_back([&]() { pool_ok = g_pool.init(n_parse + 4 + (size_t)(kSlots + 1) * n_gpu + 4 + n_fmt_plan + 8 + 2, kBatchBases); });
         for (int g = 0; g < n_gpu; ++g)
             th.emplace_back([&, g]() {
                 lmat_ctx* x = ctxs[g];
+                struct Signal {  // whatever way the first GPU's thread leaves, the others stop waiting
+                    std::promise<bool>* p; bool ok = false;
+                    ~Signal() { if (p) p->set_value(ok); }
+                } sig{g == 0 ? &first_ready : nullptr};
                 auto bad = [&](const char* what) { setup_err[g] = std::string(what) + ": " + lmat_last_error(x); };
                 if (lmat_taxonomy_load_files(x, tax_tree_fn.c_str(), depth_file.c_str(), rank_map_file.empty() ? nullptr : rank_map_file.c_str(),
                                              id_bit_conv_fn.empty() ? nullptr : id_bit_conv_fn.c_str(), plasmid_file.empty() ? nullptr : plasmid_file.c_str()) != LMAT_OK)
@@ -362,7 +376,10 @@ int main(int argc, char* argv[]) {
                 if (!rand_hits_file.empty() && lmat_nullmodel_load(x, rand_hits_file.c_str()) != LMAT_OK) return bad("null models");
                 if (lmat_set_label_modes(x, permissive, max_count, max_count > 0 && !rank_table_file.empty() ? rank_table_file.c_str() : nullptr) != LMAT_OK)
                     return bad("label modes");
-                if (is_image) {  // image written by make_db_image (the engine's counterpart of the PERM .db file)
+                if (g > 0) {
+                    if (!first_ok.get()) { setup_err[g] = "k-mer DB: the first GPU's build failed"; return; }
+                    if (lmat_db_clone(x, ctxs[0]) != LMAT_OK) return bad("k-mer DB replica");
+                } else if (is_image) {  // image written by make_db_image (the engine's counterpart of the PERM .db file)
                     if (lmat_db_load_image(x, files[0].c_str(), 0) != LMAT_OK) return bad("k-mer DB image");
                     if (lmat_db_finalize(x) != LMAT_OK) return bad("k-mer DB image");
                 } else {
@@ -371,6 +388,7 @@ int main(int argc, char* argv[]) {
                         if (lmat_db_add_taxhisto(x, fn.c_str()) != LMAT_OK) return bad("k-mer DB");
                     if (lmat_db_finalize(x) != LMAT_OK) return bad("k-mer DB");
                 }
+                if (g == 0) { sig.ok = true; sig.p->set_value(true); sig.p = nullptr; }
                 if (lmat_stream_create(x, kBatch, kBatchBases, cands_per_read, kSlots, &rings[g]) != LMAT_OK) return bad("batch ring");
             });
         for (auto& x : th) x.join();
@@ -413,6 +431,9 @@ int main(int argc, char* argv[]) {
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b_) { return std::chrono::duration<double>(b_ - a).count(); };
     WorkQueue parsed(4), classified(8);
+    std::atomic<bool> failed(false);  // any stage: first message wins, the input queue is closed, the run ends with -1
+    std::mutex fail_m;
+    std::string fail_msg;
     // A FASTA query in a regular file is mapped and cut at '>' lines into pieces that a pool of threads parses, one
     // batch per piece, numbered in file order (FASTQ and stdin keep the sequential reader: its header pairing is
     // line-order dependent).  Batches may reach the writer out of order; it puts them back.
@@ -430,21 +451,37 @@ int main(int argc, char* argv[]) {
     std::thread reader([&]() {  // stage 1: FASTA/FASTQ -> batches
         if (map_base) {
             auto tp0 = now();
+            // Cut points: the first '>' line at or behind start + kPiece; a piece never exceeds a pool buffer (kBatchBases).
+            // A record too long for that is cut between two of its lines (both halves are then reads the engine refuses as
+            // too long -- the run fails loudly, never silently); a single LINE longer than a buffer cannot be cut at all.
             std::vector<size_t> cut(1, 0);
-            while (cut.back() < map_size) {
-                size_t target = cut.back() + kPiece;
+            bool cut_failed = false;
+            while (cut.back() < map_size && !cut_failed) {
+                const size_t start = cut.back();
+                size_t pos = start + kPiece;
                 size_t c = map_size;
-                while (target < map_size) {  // next line that starts with '>'
-                    const char* nl = (const char*)memchr(map_base + target, '\n', map_size - target);
-                    if (!nl) break;
-                    const size_t at = (size_t)(nl - map_base) + 1;
+                while (pos < map_size) {
+                    const char* nl = (const char*)memchr(map_base + pos, '\n', map_size - pos);
+                    const size_t at = nl ? (size_t)(nl - map_base) + 1 : map_size;  // start of the next line (or the end)
+                    if (at - start > kBatchBases) {  // the line that crosses `pos` ends beyond the buffer: cut in front of it
+                        const char* prev = (const char*)memrchr(map_base + start, '\n', pos - start);
+                        const size_t ls = prev ? (size_t)(prev - map_base) + 1 : start;
+                        if (ls <= start) {
+                            std::lock_guard<std::mutex> l(fail_m);
+                            if (!failed.exchange(true)) fail_msg = "input: a line of more than " + std::to_string(kBatchBases) + " bytes exceeds the batch buffer";
+                            cut_failed = true;
+                        }
+                        c = ls;
+                        break;
+                    }
                     if (at >= map_size) break;
-                    if (map_base[at] == '>' && at - cut.back() + (64u << 10) < kBatchBases) { c = at; break; }
-                    if (at - cut.back() + (64u << 10) >= kBatchBases) { c = at; break; }  // one record longer than a piece: cut inside it (reads of that size are refused anyway)
-                    target = at;
+                    if (map_base[at] == '>') { c = at; break; }
+                    if (at - start + (64u << 10) >= kBatchBases) { c = at; break; }  // a record longer than a piece: cut between its lines
+                    pos = at;
                 }
-                cut.push_back(c);
+                if (!cut_failed) cut.push_back(c);
             }
+            if (cut_failed) { parsed.close(); return; }
             const size_t np = cut.size() - 1;
             std::atomic<size_t> next_piece(0);
             std::vector<std::thread> th;
@@ -455,6 +492,12 @@ int main(int argc, char* argv[]) {
                         const size_t j = next_piece.fetch_add(1);
                         if (j >= np) break;
                         parse_fasta_piece(map_base + cut[j], map_base + cut[j + 1], w->b);
+                        if (w->b.overflow) {
+                            std::lock_guard<std::mutex> l(fail_m);
+                            if (!failed.exchange(true)) fail_msg = "input: a piece of the query file exceeds the batch buffer";
+                            parsed.close();
+                            break;
+                        }
                         w->seq = j;
                         read_count += w->b.n();
                         parsed.push(std::move(w));
@@ -479,7 +522,11 @@ int main(int argc, char* argv[]) {
                 if (!have_pending && !rd.next(read, hdr)) { more = false; break; }
                 have_pending = false;
                 if (read.size() > b.room()) {
-                    if (b.n() == 0) { std::cerr << "ERROR! a read of " << read.size() << " bases exceeds the batch buffer" << std::endl; more = false; }
+                    if (b.n() == 0) {
+                        std::lock_guard<std::mutex> l(fail_m);
+                        if (!failed.exchange(true)) fail_msg = "input: a read of " + std::to_string(read.size()) + " bases exceeds the batch buffer";
+                        more = false;
+                    }
                     else have_pending = true;  // goes into the next batch
                     break;
                 }
@@ -591,9 +638,6 @@ int main(int argc, char* argv[]) {
     // stage 2: the GPUs.  One thread per context keeps its ring of pinned slots full: a batch is copied into a slot and
     // queued (copy in, packing, classification and the copy of the results back are asynchronous), the oldest batch in
     // flight is collected when the ring is full or the input has nothing ready.
-    std::atomic<bool> failed(false);
-    std::mutex fail_m;
-    std::string fail_msg;
     std::vector<double> t_gpu_g(n_gpu, 0.0);
     std::vector<std::thread> gpu_threads;
     for (int g = 0; g < n_gpu; ++g)
