@@ -871,6 +871,344 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
     lo |= nl;
 }
 
+// ------------------------------------------------------------------------------------------
+// K4 on the wave: score + sort + findReadLabelVer2 of one read by the 64 lanes of the wave that classified it, the
+// read's taxid table never leaving the wave (no hand-off record, no separate decision kernels).  Lane s = registration
+// slot s on entry.  Taken when the scores are plain k-mer fractions cnt / cand with cand <= 999 and no effective human
+// bias: then two scores are either equal or more than 0.001 apart, TCmp (read_label.cpp:475-485) is the lexicographic
+// order on (count, depth) -- a strict weak order -- and what libstdc++'s std::sort leaves is fixed by its partition
+// steps alone:
+//   * __unguarded_partition compares every element with the pivot only, so the pairs it swaps are "the i-th element
+//     from the left that is not below the pivot with the i-th from the right that is not above it, while they have not
+//     crossed": prefix counts over two ballots, one exchange through LDS per partition (ranges of more than 16 only);
+//   * the final insertion sort of a strict weak order is the stable sort of what the partitions left: a rank count.
+// The sequential float sums of the statistics (read_label.cpp:806-880) keep their order: one wave-uniform add per slot.
+// Lineage building, competitor scan and call (:284-419) run with a candidate per lane (in sorted order) against a
+// lineage entry per lane (in depth order).  Anything outside these preconditions returns false and the read takes the
+// general path (hand-off record -> k4_*_kernel), which restates the reference statement by statement.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rl(uint32_t v, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
+__device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return rl(x, 63);
+}
+__device__ __forceinline__ uint64_t below_mask(int p) { return p <= 0 ? 0ull : (p >= 64 ? ~0ull : ((1ull << p) - 1)); }  // bits < p
+
+typedef const ClassifyArgs __attribute__((address_space(4))) CArgsK4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint64_t bal(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+// The vector pipe is what the classify kernel runs out of, so this step is written for few VECTOR instructions: per-slot
+// loops read their operands as LDS broadcasts, four per load (a v_readlane is a vector instruction, a ds_read is not),
+// wave-uniform integers and lane masks stay on the scalar unit, and nothing branches per lane.
+template <int THM>
+__device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint32_t cand, const u32x4 fz, uint32_t my_cnt,
+                                        uint32_t my_id, const unsigned int* hent, uint32_t* xch, GAS uint64_t* out,
+                                        int valid_kmers, uint32_t len, int bin_sel) {
+    const float hbias = Ap->prm.hbias, sdiff = Ap->prm.sdiff;
+    const int screen_phix = Ap->prm.screen_phix;
+    if (Ap->nm.active | Ap->prm.stop_after) return false;
+    if (cand - 1u > 998u || nT - 1u > 63u) return false;   // cand in 1..999, 1..64 taxids
+    const bool act = (uint32_t)lane < nT;
+    const uint32_t dep = act ? (fz.w & 0xFFFFu) : 0u, fl = act ? (fz.w >> 16) : 0u;
+    if (bal(my_cnt > cand || dep > 0x7FFFu || (hbias != 0.0f && (fl & kFlagHuman)))) return false;  // (a bias of 0 adds 0 * stdev: nothing)
+    float* xs = (float*)xch;      // [64] scores by slot, then squared deviations
+    uint32_t* xk = xch + 64;      // [64] sort keys by array position
+    uint32_t* xx = xch + 128;     // [128] exchange buffer of a partition step
+    const float fcand = (float)cand;
+    const float sc = (float)my_cnt / fcand;   // lanes >= nT: 0
+    xs[lane] = sc;
+    // ---- std::sort(TCmp) (:892-893).  Element = key << 6 | slot, key = count << 15 | depth; lane p = array position p.
+    uint32_t e = act ? (((my_cnt << 15) | dep) << 6) | (uint32_t)lane : 0xFFFFFFFFu;
+    if (nT > 16) {
+        int lg = 0;
+        for (uint32_t t = nT; t > 1; t >>= 1) ++lg;
+        uint32_t st0 = 0, st1 = 0, st2 = 0;  // pending ranges of more than 16: first | last << 8 | depth << 16 (at most 3 of them fit 64 elements)
+        int sp = 0, first = 0, last = (int)nT, depth = 2 * lg;
+        bool busy = true;
+        while (busy) {
+            if (last - first <= 16) {
+                if (sp > 0) {
+                    --sp;
+                    const uint32_t top = sp == 0 ? st0 : (sp == 1 ? st1 : st2);
+                    first = (int)(top & 0xFFu); last = (int)((top >> 8) & 0xFFu); depth = (int)(top >> 16);
+                } else busy = false;
+            } else if (depth == 0) {
+                return false;  // heapsort turn of introsort: the general path replays it
+            } else {
+                --depth;
+                const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                const uint32_t ka = rl(e, ia) >> 6, kb = rl(e, ib) >> 6, kc = rl(e, ic) >> 6;
+                const bool ab = ka < kb, bc = kb < kc, ac = ka < kc;
+                const int pick = ab ? (bc ? ib : (ac ? ic : ia)) : (ac ? ia : (bc ? ic : ib));
+                const uint32_t e_first = rl(e, first), e_pick = rl(e, pick);
+                e = lane == first ? e_pick : (lane == pick ? e_first : e);
+                const uint32_t K = e_pick >> 6;
+                const uint64_t inr = below_mask(last) & ~below_mask(first + 1);
+                const uint64_t GE = bal((e >> 6) >= K) & inr, LE = bal((e >> 6) <= K) & inr;  // where the scan up / the scan down stops
+                const uint32_t pg = prefix_count(GE), pl = prefix_count(LE);
+                const bool le = lane_bit(LE);
+                const uint32_t above_le = (uint32_t)popc64(LE) - pl - (le ? 1u : 0u);
+                const uint64_t SL = bal(above_le > pg) & GE;   // pair pg: its partner from the right lies above this lane
+                const uint64_t SR = bal(pg > above_le) & LE;   // pair above_le: its partner from the left lies below
+                int cut;
+                if (SL) {
+                    const bool swl = lane_bit(SL), swr = lane_bit(SR);
+                    if (swl) xx[pg] = e;
+                    if (swr) xx[64 + above_le] = e;
+                    WSYNC();
+                    if (swl) e = xx[64 + pg];
+                    if (swr) e = xx[above_le];
+                    WSYNC();
+                    const int Lm = 63 - __builtin_clzll(SL), Rm = __builtin_ctzll(SR);
+                    const uint64_t c = GE & ~below_mask(Lm + 1) & below_mask(Rm);
+                    cut = c ? __builtin_ctzll(c) : Rm;
+                } else {
+                    cut = GE ? __builtin_ctzll(GE) : last;
+                }
+                if (last - cut > 16) {
+                    const uint32_t v = (uint32_t)cut | ((uint32_t)last << 8) | ((uint32_t)depth << 16);
+                    if (sp == 0) st0 = v; else if (sp == 1) st1 = v; else st2 = v;
+                    ++sp;
+                }
+                last = cut;
+            }
+        }
+    }
+    // final insertion sort == stable sort by key of the array as it stands: rank = elements before this one
+    const uint32_t keyr = act ? ((e & ~63u) | (uint32_t)lane) : 0xFFFFFFFFu;
+    xk[lane] = keyr;
+    WSYNC();
+    // ---- statistics (read_label.cpp:803-880): sums in registration order; a zero score adds +0.0, so pos_log_sum == log_sum
+    float log_sum = 0.0f;
+    uint32_t rank = 0;
+    for (uint32_t t = 0; t < nT; t += 4) {
+        const f32x4 q = *(const f32x4*)(xs + t);
+        const u32x4 kq = *(const u32x4*)(xk + t);
+        log_sum += q.x; log_sum += q.y; log_sum += q.z; log_sum += q.w;
+        rank += (kq.x < keyr ? 1u : 0u) + (kq.y < keyr ? 1u : 0u);
+        rank += (kq.z < keyr ? 1u : 0u) + (kq.w < keyr ? 1u : 0u);
+    }
+    const uint32_t pos_sig_hits = (uint32_t)popc64(bal(my_cnt > 0));
+    const uint32_t use_sig_hits = pos_sig_hits > 3 ? pos_sig_hits : nT;
+    const float log_avg = log_sum / (float)use_sig_hits;
+    const float dv = log_avg - sc;
+    WSYNC();
+    xs[lane] = act && (pos_sig_hits > 3 ? my_cnt > 0 : true) ? dv * dv : 0.0f;
+    // sorted-position space: lane i holds the candidate at position i of the sorted array (ascending; best = nT - 1)
+    const uint32_t es = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)e);  // lanes >= nT rank nT and collide there: unused
+    const uint32_t pslot4 = (es & 63u) << 2, pdep = (es >> 6) & 0x7FFFu;
+    const uint32_t piv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)fz.z);
+    const uint32_t pfl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)fz.w) >> 16;
+    const uint32_t ptid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)my_id);
+    const float pscore = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)__float_as_uint(sc)));
+    const float top_score = __uint_as_float(rl(__float_as_uint(pscore), (int)nT - 1));  // the largest count sorts last
+    WSYNC();
+    float log_std = 0.0f;
+    for (uint32_t t = 0; t < nT; t += 4) {
+        const f32x4 q = *(const f32x4*)(xs + t);
+        log_std += q.x; log_std += q.y; log_std += q.z; log_std += q.w;
+    }
+    const float stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0.0f;
+    lmat_read_result res;
+    res.status = LMAT_ST_CALL; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = (uint16_t)cand; res.valid_kmers = valid_kmers;
+    res.read_len = (int)len; res.log_avg = log_avg; res.stdev = stdev1; res.call_tid = 0; res.call_score = 0; res.cand_off = 0; res.n_cand = 0;
+    res.bin_sel = bin_sel;
+    uint32_t call_idx = 0;
+    const uint64_t PX = screen_phix ? bal((fl & kFlagPhiX) != 0) : 0ull;  // by slot
+    bool phix = false;
+    if (PX) {  // :841-848: the score of the LAST registered PhiX id against the top score
+        const float phix_score = __uint_as_float(rl(__float_as_uint(sc), 63 - __builtin_clzll(PX)));
+        if (phix_score >= top_score) {
+            phix = true;
+            res.status = LMAT_ST_PHIX; res.match_type = LMAT_MT_DIRECT; res.call_tid = 32630; res.call_score = phix_score;
+            res.log_avg = 0; res.stdev = 0;
+            call_idx = Ap->phix_call_idx;
+        }
+    }
+    if (!phix) {
+        const float diff_thresh = stdev1 * sdiff;
+        const uint32_t ti = piv & 0xFFFFu, oi = piv >> 16;
+        // ---- findReadLabelVer2, lineage building (:295-325): candidates from the best down; the first one that does not fit
+        //      the lineage so far (addToCandLineage :225-262: equal depths, or the shallower one not an ancestor of the deeper) ends it
+        uint64_t F = 0, ACC = 0;
+        int lidx = -1, low_pos = -1, high_pos = -1;
+        uint32_t low_dep = 0, high_dep = 0;
+        for (int j = (int)nT - 1; j >= 0; --j) {
+            if ((F >> j) & 1ull) { lidx = j; break; }
+            ACC |= 1ull << j;
+            const uint32_t dj = rl(pdep, j), ivj = rl(piv, j);
+            const uint32_t tj = ivj & 0xFFFFu, oj = ivj >> 16;
+            const uint64_t fits = (bal(ti < tj) & bal(oj <= oi) & bal(pdep < dj)) | (bal(tj < ti) & bal(oi <= oj) & bal(pdep > dj));
+            F |= ~fits & below_mask(j);
+            if (j == (int)nT - 1 || dj > low_dep) { low_pos = j; low_dep = dj; }
+            if (j == (int)nT - 1 || dj < high_dep) { high_pos = j; high_dep = dj; }
+        }
+        // the top-scoring plasmid the loop meets last (:301-304, 324): it runs on below lidx while the scores stay at the top
+        int plasmid_pos = -1;
+        {
+            const uint64_t am = below_mask((int)nT);
+            const uint64_t GEm = bal(pscore >= top_score) & am, PLm = bal((pfl & kFlagPlasmid) != 0) & am;
+            if (PLm) {
+                const uint64_t Z = ~GEm & below_mask(lidx + 1);
+                const uint64_t seen = Z ? ~below_mask(64 - __builtin_clzll(Z)) : ~0ull;  // above the first position at or below lidx that is under the top score
+                const uint64_t c = GEm & PLm & seen;
+                if (c) plasmid_pos = __builtin_ctzll(c);
+            }
+        }
+        uint8_t match = LMAT_MT_DIRECT;
+        uint32_t call_tid = rl(ptid, low_pos), call_iv = rl(piv, low_pos);  // nothing poisoned: the deepest accepted candidate (:366-369)
+        float call_score = __uint_as_float(rl(__float_as_uint(pscore), low_pos));
+        const bool want_lin = Ap->cands && !Ap->prm.prn_all;
+        uint32_t nlin = 0, b_tid = 0, b_sc = 0;
+        if (lidx >= 0 || want_lin) {
+            // ---- the lineage: accepted candidates in the order taken, then the ancestors of the shallowest one (:326-343)
+            const uint32_t nacc = (uint32_t)popc64(ACC);
+            const uint32_t aidx4 = (lane_bit(ACC) ? nacc - prefix_count(ACC) - 1u : 63u) << 2;  // entry index = accepted positions above; others push to lane 63, an entry only when all 64 are
+            b_tid = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)ptid);
+            uint32_t b_dep = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)pdep);
+            uint32_t b_iv = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)piv);
+            b_sc = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)__float_as_uint(pscore));
+            bool b_regd = (uint32_t)lane < nacc;  // member of all_cand_set
+            nlin = nacc;
+            const uint32_t high_iv = rl(piv, high_pos);
+            const bool have_add = high_dep != 0;
+            if (have_add) {
+                const int high_slot = (int)(rl(es, high_pos) & 63u);
+                const uint32_t aoff = rl(fz.x, high_slot), alen = rl(fz.y, high_slot) & 0xFFFFu;
+                if (nacc + alen > 64u) return false;  // a lineage entry per lane: longer chains take the general path
+                const GAS uint64_t* g_paths8 = (const GAS uint64_t*)Ap->tb.paths8;
+                const bool mine = (uint32_t)lane >= nacc && (uint32_t)lane < nacc + alen;
+                int sl = 0;
+                if (mine) {
+                    const uint64_t pe = g_paths8[aoff + ((uint32_t)lane - nacc)];
+                    b_tid = (uint32_t)(pe & 0xFFFFu); b_dep = (uint32_t)(pe >> 16) & 0xFFFFu; b_iv = (uint32_t)(pe >> 32);
+                    sl = tid_slot(hent, THM, b_tid);
+                    b_regd = sl >= 0;
+                    b_sc = __float_as_uint(-10000.0f);
+                }
+                // score of a registered ancestor: its slot's (another lane's) score, before any bias (:821)
+                const uint32_t s2 = (uint32_t)__builtin_amdgcn_ds_bpermute((sl < 0 ? 0 : sl) << 2, (int)__float_as_uint(sc));
+                if (mine && b_regd) b_sc = s2;
+                nlin = nacc + alen;
+            }
+            const uint64_t lm = below_mask((int)nlin);
+            // depth order (CmpDepth :159-167, :344-351): defined by the comparator alone only when no two depths are equal --
+            // then every rank is taken exactly once; a rank nobody pushed to reads back 0 from ds_permute
+            WSYNC();
+            xk[lane] = lane_bit(lm) ? b_dep + 1u : 0u;
+            WSYNC();
+            uint32_t drank = 0;
+            for (uint32_t t = 0; t < nlin; t += 4) {
+                const u32x4 q = *(const u32x4*)(xk + t);
+                drank += (q.x > b_dep + 1u ? 1u : 0u) + (q.y > b_dep + 1u ? 1u : 0u);
+                drank += (q.z > b_dep + 1u ? 1u : 0u) + (q.w > b_dep + 1u ? 1u : 0u);
+            }
+            const int to_lane = (int)((lane_bit(lm) ? drank : 63u) << 2);  // (ds_permute wraps modulo 64: spare lanes push to lane 63, an entry only when all 64 are)
+            const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)b_iv);
+            const uint32_t d_sc = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)b_sc);
+            const uint32_t d_tid = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)(b_tid | (b_regd ? 0x10000u : 0u) | 0x20000u));
+            if (bal(!(d_tid & 0x20000u)) & lm) return false;  // two entries of one depth: the general path replays std::sort on them
+            // ---- competitors (:355-362, cmpCompLineage :264-282): candidates from lidx down that are not ancestors of the
+            //      shallowest lineage member, each against the lineage from its deepest entry up
+            uint64_t NG = 0;
+            if (lidx >= 0) {
+                const uint32_t htin = high_iv & 0xFFFFu, htout = high_iv >> 16;
+                const uint64_t comp = below_mask(lidx + 1) & ~(have_add ? bal(ti < htin) & bal(htout <= oi) : 0ull);
+                uint64_t active = comp, big = 0;
+                uint32_t mlo = 0, mhi = 0;
+                for (uint32_t j = 0; j < nlin && active; ++j) {
+                    const uint32_t ivj = rl(d_iv, (int)j);
+                    const float ls = __uint_as_float(rl(d_sc, (int)j));
+                    const uint32_t tj = ivj & 0xFFFFu, oj = ivj >> 16;
+                    const uint64_t anc = bal(tj < ti) & bal(oi <= oj);  // the lineage entry is an ancestor of the competitor: the walk ends
+                    const float d = ls - pscore;
+                    const uint64_t isbig = ls != -10000.0f ? bal(d > diff_thresh) : 0ull;
+                    const uint64_t go = active & ~anc & ~isbig;
+                    const uint64_t mark = go & bal(d <= diff_thresh);
+                    const uint32_t bit = 1u << (j & 31u);
+                    if (j < 32) mlo |= lane_bit(mark) ? bit : 0u; else mhi |= lane_bit(mark) ? bit : 0u;
+                    big |= active & ~anc & isbig;
+                    active = go;
+                }
+                // the first competitor (from lidx down) that meets a lineage score beyond the threshold ends the scan; its own
+                // marks up to that entry stand
+                const uint64_t counted = big ? comp & ~below_mask(63 - __builtin_clzll(big)) : comp;
+                const bool cn = lane_bit(counted);
+                NG = (uint64_t)wave_or(cn ? mlo : 0u) | (nlin > 32 ? (uint64_t)wave_or(cn ? mhi : 0u) << 32 : 0ull);
+            }
+            if (NG) {  // :370-408
+                const uint64_t okm = ~NG & lm;
+                if (!okm) {
+                    match = LMAT_MT_LCA_ERROR;
+                    call_tid = 0; call_iv = 0xFFFFFFFFu; call_score = 0;
+                } else {
+                    const int root = __builtin_ctzll(okm);
+                    // std::max over the entries up to and including the first good one (scores are >= 0 or -10000: ordered like their bits as signed integers)
+                    int mv = (int)__float_as_uint(-10000.0f);
+                    for (int j = 0; j <= root; ++j) { const int x = (int)rl(d_sc, j); mv = x > mv ? x : mv; }
+                    float max_val = __uint_as_float((uint32_t)mv);
+                    const uint32_t rt = rl(d_tid, root);
+                    const float rs = __uint_as_float(rl(d_sc, root));
+                    match = LMAT_MT_MULTI;
+                    if ((rt & 0x10000u) && max_val < rs) { match = LMAT_MT_PARTIAL; max_val = rs; }
+                    call_tid = rt & 0xFFFFu;
+                    call_iv = rl(d_iv, root);
+                    call_score = max_val;
+                }
+            }
+        }
+        if (plasmid_pos >= 0 && match != LMAT_MT_LCA_ERROR) {  // :410-416
+            const uint32_t piv_p = rl(piv, plasmid_pos);
+            if ((call_iv & 0xFFFFu) < (piv_p & 0xFFFFu) && (piv_p >> 16) <= (call_iv >> 16)) call_tid = rl(ptid, plasmid_pos);
+        }
+        const GAS uint32_t* g_tid32 = (const GAS uint32_t*)Ap->tb.tid32;
+        res.match_type = match;
+        res.call_tid = call_tid ? g_tid32[call_tid] : 0u;
+        res.call_score = call_score;
+        call_idx = call_tid;
+        // ---- candidates (:898-927): with -p all of them, best first; else, for a multi match, the lineage as built
+        if (Ap->cands) {
+            GAS uint32_t* g_cursor = (GAS uint32_t*)Ap->cursor;
+            const bool prn_all = Ap->prm.prn_all != 0;
+            const uint32_t reserve = prn_all ? nT : nlin;
+            uint32_t coff = 0;
+            if (lane == 0) coff = G_ADD(&g_cursor[0], reserve);
+            coff = (uint32_t)__builtin_amdgcn_readfirstlane((int)coff);
+            GAS uint64_t* co = nullptr;  // lmat_cand {tid, score}
+            if ((uint64_t)coff + reserve <= Ap->cand_cap) co = (GAS uint64_t*)((GAS lmat_cand*)Ap->cands + coff);
+            else if (lane == 0) G_OR((GAS uint32_t*)Ap->err, (uint32_t)kErrCandOverflow);
+            res.cand_off = coff;
+            if (prn_all) {
+                if (co && act) co[nT - 1u - (uint32_t)lane] = (uint64_t)g_tid32[ptid] | ((uint64_t)__float_as_uint(pscore) << 32);
+                if (co) res.n_cand = nT;
+            } else {
+                if (co && (uint32_t)lane < nlin) co[lane] = (uint64_t)g_tid32[b_tid] | ((uint64_t)b_sc << 32);
+                if (co && (match == LMAT_MT_MULTI || match == LMAT_MT_PARTIAL)) res.n_cand = nlin;
+            }
+        }
+    }
+    if (lane == 0) {
+        GAS unsigned long long* tally_count = (GAS unsigned long long*)Ap->counts;
+        GAS double* tally_score = (GAS double*)(tally_count + Ap->tb.n_ids);
+        GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + Ap->tb.n_ids);
+        store_result(out, res);
+        if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {  // tallies, proc_line :1241-1268
+            G_ADD(&tally_nomatch[1], 1ull);
+        } else if (res.call_score >= Ap->prm.min_score) {
+            G_ADD(&tally_count[call_idx], 1ull);
+            G_ADD(&tally_score[call_idx], (double)res.call_score);
+        } else if (res.call_score < Ap->prm.min_score) {
+            G_ADD(&tally_nomatch[2], 1ull);
+        }
+    }
+    return true;
+}
+
 #define WSYNC_WAVE WSYNC
 #pragma push_macro("WSYNC")
 #undef WSYNC
@@ -1876,6 +2214,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         uint16_t* s_tout = leaf;  // counts are dead after the representative-strain pass
         // facts of the id registered in this lane's slot
         const bool sl_p1 = (uint32_t)lane < nT;
+        const uint32_t nT_p1 = nT;
         const uint32_t f_poff = fz.x, f_plen = fz.y & 0xFFFFu, f_sp = fz.y >> 16, f_fl = (fz.w >> 16) & 0xFFu, f_iv = fz.z;
         const uint32_t my_id = sl_p1 ? (uint32_t)reg[lane] : 0u;
         // representative strain per species, one vote per kept id
@@ -1973,6 +2312,9 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             nT += newcnt;
             WSYNC();
         }
+        // the fact records of the ids the closure registered, into their slots' lanes (the decision step at the end wants
+        // every slot's; the load is in flight while the counts are made)
+        if (!overflow && (uint32_t)lane >= nT_p1 && (uint32_t)lane < nT) fz = g_facts16[reg[lane]];
         if (!overflow && W > 0) {
             const bool sl_act = (uint32_t)lane < nT;
             uint32_t tin_s = 0xFFFF, tout_s = 0;
@@ -2064,6 +2406,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 ((GAS uint32_t*)A.ovf_list)[G_ADD(&g_cursor[A.ovf_slot], 1u)] = (uint32_t)r;
             }
             return;
+        }
+        if constexpr (!INK4) {  // the decision on the wave itself, when the read qualifies (k4_wave); else the hand-off below
+            const uint32_t my_cnt = (uint32_t)lane < nT ? (uint32_t)cnt[lane] : 0u, my_id = (uint32_t)lane < nT ? (uint32_t)reg[lane] : 0u;
+            if (k4_wave<THM>(Ap, lane, nT, cand, fz, my_cnt, my_id, hent, (uint32_t*)(lds + L::OFF_R3), out, valid_kmers, len, bin_sel)) return;
         }
         GAS uint32_t* krec = (GAS uint32_t*)A.k4buf + (r - A.result_base) * kK4RecWords;
         if (lane < (int)nT) krec[2 + lane] = (uint32_t)reg[lane] | ((uint32_t)cnt[lane] << 16);

@@ -76,6 +76,8 @@ static KernelParams kparams(const lmat_params& p) {
     k.permissive = 0;
     const char* sa = getenv("LMAT_STOP_AFTER");
     k.stop_after = sa ? atoi(sa) : 0;
+    // LMAT_K4_WAVE=0: every read takes the general decision path (hand-off record -> k4 kernels); 20 stops nothing
+    if (const char* w = getenv("LMAT_K4_WAVE")) if (!k.stop_after && atoi(w) == 0) k.stop_after = 20;
     return k;
 }
 
@@ -203,7 +205,8 @@ int lmat_ingest_lookup(const lmat_ingest* g, uint64_t kmer, uint16_t* tids16, in
 int lmat_genedb_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_bytes) {
     if (!c) return LMAT_E_ARG;
     if (c->db_ready || c->ingest) return set_err(c, LMAT_E_ARG, "a context holds one database: use a fresh context for a gene database");
-    c->gene_mode = 1;
+    const int had_gene_mode = c->gene_mode;
+    c->gene_mode = 1;  // (lmat_db_begin reads it: no taxonomy is needed in this mode)
     if (!c->d_counts) {  // no taxonomy in this mode: the kernels still expect a (minimal) tally buffer
         c->dev.n_ids = 1;
         c->counts_bytes = 16 + 24;
@@ -212,6 +215,7 @@ int lmat_genedb_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_
     }
     const int rc = lmat_db_begin(c, k, n_kmers_hint, table_bytes);
     if (rc == LMAT_OK) c->ingest->raw32 = true;
+    else c->gene_mode = had_gene_mode;  // a refused call leaves the context as it was
     return rc;
 }
 
@@ -981,7 +985,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.cands = want_cands ? (c->out_cands ? c->out_cands : c->d_cands) : nullptr;
     a.cand_cap = cand_cap;
     a.cursor = c->d_cursor;
-    a.err = c->d_err;
+    a.err = c->batch_err ? c->d_cursor + 15 : c->d_err;  // a streamed batch keeps its own flags (word 15 of the per-batch counter block)
     a.counts = c->out_counts ? c->out_counts : c->d_counts;
     auto it = c->tax.index_of.find(32630);
     a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
@@ -1017,12 +1021,14 @@ static void swap_sets(lmat_ctx* c) {
     std::swap(c->ev_done, p.done); std::swap(c->set_in_flight, p.in_flight);
 }
 
-// Measured (64 GiB table, 2 M reads of 150 bp per batch): with the decision kernels of batch i beside the classify kernel of
-// batch i + 1 a step takes 10.4 ms instead of 10.7 -- the classify kernel is bound by vector issue with every register and
-// LDS byte of a CU in use, so whatever runs beside it takes its share (an LDS decision wave displaces five classify waves).
-// The classify kernel alone then reads 9.3 ms instead of 8.2.  Off unless LMAT_PIPELINE=1.
+// Queued launches (lmat_classify_async, the streamed boundary) take the two sets of per-batch buffers in turn, and what follows
+// a batch's classify kernel -- the re-run classes and the general decision path, each over the few reads the fast path passed
+// on -- runs on the side streams beside the next batch's classify kernel.  Round 2 measured +3 % for this with the decision
+// step of EVERY read in those kernels (they took LDS from the classify kernel: 8.2 -> 9.3 ms); now that the decision is made on
+// the classify wave itself the tail is ~0.4 ms of nearly empty launches and hiding it is a plain gain (64 GiB table, 2 M reads
+// per launch: 7.42 -> 7.17 ms per launch).  LMAT_PIPELINE=0 puts every launch back on the context's stream.
 static bool pipeline_on() {
-    static const bool on = getenv("LMAT_PIPELINE") && atoi(getenv("LMAT_PIPELINE")) != 0;
+    static const bool on = !getenv("LMAT_PIPELINE") || atoi(getenv("LMAT_PIPELINE")) != 0;
     return on;
 }
 // pipelined: the launch takes the other set of per-batch buffers and returns with its decision kernels still running on the
@@ -1486,7 +1492,6 @@ struct lmat_stream {
     uint32_t cands_per_read = 0;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     uint64_t head = 0, tail = 0;     // slot of the next acquire / of the oldest batch in flight (monotonic counters)
-    uint32_t reported = 0;           // device error flags already returned to the caller
     void* d_scratch_counts = nullptr;  // tallies of a re-run go nowhere
 };
 
@@ -1577,8 +1582,9 @@ static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch
     c->out_results = sl.d_results;
     c->out_cands = sl.d_cands;
     c->out_counts = to_scratch_counts ? st->d_scratch_counts : nullptr;
+    c->batch_err = true;
     const int rc = run_classify(c, &sl.reads, 0, sl.n, sl.cand_cap != 0, sl.cand_cap, false, pipeline_on());
-    c->out_results = nullptr; c->out_cands = nullptr; c->out_counts = nullptr;
+    c->out_results = nullptr; c->out_cands = nullptr; c->out_counts = nullptr; c->batch_err = false;
     if (rc) return rc;
     // The counters are copied out on the stream the batch's kernels joined on, and the set's `done` event is recorded again
     // behind that copy: the next launch that takes this set of buffers clears the counters, and must not overtake it.
@@ -1588,7 +1594,7 @@ static int stream_launch(lmat_stream* st, lmat_stream::Slot& sl, bool to_scratch
     // kernels behind it.
     hipStream_t js = c->join_stream;
     HIPCHK(c, hipMemcpyAsync(sl.h_cursor, c->d_cursor, 4, hipMemcpyDeviceToHost, js));
-    HIPCHK(c, hipMemcpyAsync(sl.h_cursor + 1, c->d_err, 4, hipMemcpyDeviceToHost, js));
+    HIPCHK(c, hipMemcpyAsync(sl.h_cursor + 1, c->d_cursor + 15, 4, hipMemcpyDeviceToHost, js));  // this batch's own error flags
     HIPCHK(c, hipEventRecord(c->ev_done, js));
     HIPCHK(c, hipEventRecord(sl.ev_done, js));
     if (st->s_d2h != js) HIPCHK(c, hipStreamWaitEvent(st->s_d2h, sl.ev_done, 0));
@@ -1676,6 +1682,10 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
     sl.reads.class_len = max_len;
     const int used = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0);
     for (int j = 0; j < 3; ++j) sl.reads.cls_n[j] = used > 1 ? cn[j] : 0;
+    if ((int)max_len > classify_max_read_len()) {  // refused before anything is queued: the slot goes back untouched
+        sl.state = 0;
+        return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+    }
     if (n) {
         HIPCHK(c, hipMemcpyAsync(sl.d_bases, ext_bases ? ext_bases : sl.h_bases, sl.h_off[n], hipMemcpyHostToDevice, st->s_h2d));
         HIPCHK(c, hipMemcpyAsync(sl.d_off, sl.h_off, (n + 1) * 8, hipMemcpyHostToDevice, st->s_h2d));
@@ -1688,7 +1698,12 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
         lap("copies queued");
         launch_pack_reads(sl.d_bases, sl.d_off, sl.reads.rec_off, sl.reads.words, n, c->stream);
         const int rc = stream_launch(st, sl, false);
-        if (rc) { sl.state = 0; return rc; }
+        if (rc) {  // (an allocation failed: the copies and the pack kernel are already queued on this slot's buffers -- let them drain before the slot is handed out again)
+            hipEventSynchronize(sl.ev_up);
+            hipStreamSynchronize(c->stream);
+            sl.state = 0;
+            return rc;
+        }
         lap("kernels queued");
     }
     sl.state = 2;
@@ -1719,8 +1734,10 @@ int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lm
     if (sl.n) {
         for (;;) {
             HIPCHK(c, hipEventSynchronize(sl.ev_done));
-            const uint32_t fresh = sl.h_cursor[1] & ~st->reported;
-            st->reported |= fresh & ~(uint32_t)kErrCandOverflow;
+            // the batch's own flags (every launch of the stream writes them into its per-batch counter block): an error
+            // belongs to exactly this batch, comes back every time the caller asks for it again, and never leaks into the
+            // batches queued behind it
+            const uint32_t fresh = sl.h_cursor[1];
             nc = sl.h_cursor[0];
             if (!(fresh & kErrCandOverflow)) {
                 if (fresh & kErrReadTooLong) return set_err(c, LMAT_E_CAPACITY, "read longer than the kernel's k-mer capacity");
@@ -1729,12 +1746,10 @@ int lmat_stream_next(lmat_stream* st, const lmat_read_result** results, const lm
                 if (fresh & kErrTidOverflow) return set_err(c, LMAT_E_CAPACITY, "a read exceeds the largest tables (4096 taxids / 16384 list elements)");
                 break;
             }
-            // the batch printed more candidates than the slot holds: wait for the batches queued behind it, grow this slot
-            // fourfold and run it again (packed reads are still resident; its tallies were already counted)
+            // the batch printed more candidates than the slot holds: grow this slot fourfold and run it again (its packed reads
+            // are still resident; its tallies were already counted, so the re-run's go to a scratch buffer).  The batches queued
+            // behind it are left alone -- their flags are their own -- but they use the context's streams: wait for them first.
             HIPCHK(c, hipDeviceSynchronize());
-            HIPCHK(c, hipMemset(c->d_err, 0, 4));
-            for (auto& o : st->slots)  // flags of the batches behind it were in the word just cleared
-                if (&o != &sl && o.state == 2) st->reported &= ~(o.h_cursor[1] & ~(uint32_t)kErrCandOverflow);
             hipFree(sl.d_cands); hipHostFree(sl.h_cands);
             sl.d_cands = nullptr; sl.h_cands = nullptr;
             sl.cand_cap *= 4;

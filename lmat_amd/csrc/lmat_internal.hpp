@@ -187,6 +187,7 @@ struct lmat_ctx {
     lmat_read_result* out_results = nullptr;
     lmat_cand* out_cands = nullptr;
     void* out_counts = nullptr;
+    bool batch_err = false;        // the next launch keeps its error flags in its own counter block (word 15) instead of the sticky word
     uint64_t counts_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;   // around the classify kernel

@@ -734,6 +734,64 @@ def test_error_in_a_middle_launch_surfaces_at_sync(nullmodel_ds, tmp_path):
     eng.close()
 
 
+def test_error_in_a_streamed_batch_belongs_to_that_batch(nullmodel_ds, tmp_path):
+    """The streamed boundary keeps a batch's device-side error flags with the batch: of three queued batches only the middle one
+    meets a taxid without a null model.  The first comes back fine, the second reports the error -- again when asked again, never
+    as a success --, and after it no flag is left behind in the context (lmat_sync) or in the first batch's slot when it is reused."""
+    import gzip
+    from lmat_amd import Engine, Params, Stream
+    from lmat_amd.capi import LmatError
+    ds = nullmodel_ds
+    drop = None
+    nmdir = os.path.join(str(tmp_path), "nm")
+    os.makedirs(nmdir)
+    lst = os.path.join(nmdir, "null_lst.txt")
+    with open(lst, "w") as lf:
+        for line in open(ds["null_lst"]):
+            kc, name = line.split()
+            lf.write(f"{kc} {name}\n")
+            rows = gzip.open(os.path.join(ds["lmat_dir"], name), "rt").read().split("\n")
+            if drop is None:
+                drop = [r.split()[0] for r in rows[1:] if r and r.split()[0] != "1"][0]
+            with gzip.open(os.path.join(nmdir, name), "wt") as g:
+                g.write("\n".join(r for r in rows if not r or r.split()[0] != drop))
+    os.environ["LMAT_DIR"] = nmdir
+    try:
+        eng = Engine(0, Params.run_rl(prn_all=0))
+        eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+        eng.build_db(ds["db"], k=20)
+        eng.load_null_models(lst)
+
+        def blob_of(reads):
+            bs = [r.encode() for r in reads]
+            off = np.zeros(len(bs) + 1, dtype=np.uint64)
+            np.cumsum([len(b) for b in bs], out=off[1:])
+            return np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8), off
+
+        short = ["ACGTACGTAC"] * 64                       # below k: no lookups at all
+        normal = [r for r in ds["reads"] if len(r) >= 100][:512]
+        st = Stream(eng, 1024, 1 << 20, cands_per_read=0, n_slots=3)
+        st.submit(*blob_of(short), tag=1)
+        st.submit(*blob_of(normal), tag=2)
+        st.submit(*blob_of(short), tag=3)
+        res, _, tag = st.next()
+        assert tag == 1 and len(res) == 64
+        for _ in range(2):                                # the failed batch never turns into a success
+            with pytest.raises(LmatError) as ei:
+                st.next()
+            assert ei.value.code == -5 and "NULL MODELS" in str(ei.value)
+        eng.sync()                                        # nothing leaked into the context's sticky word
+        st.close()
+        st = Stream(eng, 1024, 1 << 20, cands_per_read=0, n_slots=2)
+        for t in (4, 5, 6):                               # slots are reused: old flags do not come back
+            st.submit(*blob_of(short), tag=t)
+            assert st.next()[2] == t
+        st.close()
+        eng.close()
+    finally:
+        os.environ["LMAT_DIR"] = ds["lmat_dir"]
+
+
 def test_failed_blocking_launch_leaves_the_tallies_alone(small_dataset):
     """lmat_classify with a candidate buffer that is too small fails with LMAT_E_CAPACITY; the documented retry with a
     larger buffer must not count the batch twice."""
@@ -824,32 +882,39 @@ def test_counts_allreduce_across_contexts(small_dataset):
         e.close()
 
 
-def test_batches_run_beside_each_other_give_the_same_answers():
-    """LMAT_PIPELINE=1: queued launches and the streamed boundary take the two sets of per-batch buffers in turn and the decision
-    kernels of a batch run beside the classify kernel of the next one.  The switch is read once per process, so the tests
-    that queue batches (async launches, sticky errors, the streamed boundary, the CLI) run again in a child process with it on."""
+def _child_run(env_name, env_value, files, kexpr):
+    """Switches read once per process: the named tests run again in a child pytest with the variable set."""
     import subprocess
     import sys
-    if os.environ.get("LMAT_PIPELINE"):
+    if os.environ.get(env_name) is not None:
         pytest.skip("already the child run")
-    env = dict(os.environ, LMAT_PIPELINE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_cli.py"),
-                        "-m", "gpu", "-x", "-q", "-k", "async or sync or stream or tallies or cli_matches or several_contexts"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, **{env_name: env_value})
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(here, f) for f in files], "-m", "gpu", "-x", "-q", "-k", kexpr],
+                       env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_batches_on_one_stream_give_the_same_answers():
+    """Queued launches and the streamed boundary take the two sets of per-batch buffers in turn and the tail of a batch (re-run
+    classes, general decision path) runs beside the classify kernel of the next one; LMAT_PIPELINE=0 keeps every launch on the
+    context's stream.  The tests that queue batches (async launches, sticky errors, the streamed boundary, the CLI) run both ways."""
+    _child_run("LMAT_PIPELINE", "0", ["test_gpu_parity_ext.py", "test_gpu_cli.py"],
+               "async or sync or stream or tallies or cli_matches or several_contexts")
+
+
+def test_general_decision_path_gives_the_same_answers():
+    """The decision step (score statistics, std::sort(TCmp), findReadLabelVer2) is made on the classify wave when a read
+    qualifies (k4_wave: no null models, no effective human bias, at most 999 candidate k-mers) and by the general path -- a
+    statement-by-statement restatement, one lane per read -- otherwise.  LMAT_K4_WAVE=0 sends every read down the general path:
+    the text-parity, capacity and fuzz tests must not notice."""
+    _child_run("LMAT_K4_WAVE", "0", ["test_gpu_parity_ext.py", "test_gpu_parity.py", "test_gpu_fuzz.py"],
+               "text_parity or out_text or parameter_variants or overflow_rerun or many_distinct or degenerate or long_reads or random_configuration or label_modes or example")
 
 
 def test_wide_table_format_gives_the_same_answers():
     """LMAT_TABLE_FORMAT=wide keeps round 1's 8-byte-slot table (the non-compact kernel variants share every step after the
-    probe with the default ones).  Read once per process, so the text-parity tests run again in a child process with it set."""
-    import subprocess
-    import sys
-    if os.environ.get("LMAT_TABLE_FORMAT"):
-        pytest.skip("already the child run")
-    env = dict(os.environ, LMAT_TABLE_FORMAT="wide")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
-                        "-k", "config1_text_parity or parameter_variants or overflow_rerun or many_distinct or degenerate or long_reads or sorteddb"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    probe with the default ones)."""
+    _child_run("LMAT_TABLE_FORMAT", "wide", ["test_gpu_parity_ext.py"],
+               "config1_text_parity or parameter_variants or overflow_rerun or many_distinct or degenerate or long_reads or sorteddb")
