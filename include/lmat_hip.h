@@ -291,6 +291,15 @@ int lmat_ingest_kmer_length(const lmat_ingest* ing);
 int lmat_ingest_lookup(const lmat_ingest* ing, uint64_t kmer, uint16_t* tids16, int cap);
 int lmat_db_from_ingest(lmat_ctx* ctx, lmat_ingest* ing, uint64_t table_bytes);
 
+/* ---- test hook: the decision step on given candidate tables ---------------------------------
+ * Runs the decision kernels' own code -- std::sort(TCmp) (src/read_label.cpp:475-485, 892-893) and findReadLabelVer2
+ * (:284-419) -- on n candidate tables given from outside instead of computed from reads: table i = the (32-bit taxid,
+ * score) pairs off[i] .. off[i+1] (1..64 of them, any order) and the read's standard deviation stdev[i] (the second
+ * statistic read_label prints).  Needs the taxonomy only.  results[i]: call_tid, call_score, match_type.  This is how the
+ * records of the reference's own example run (tests/golden/example_records.json) are put to the GPU kernels directly. */
+int lmat_debug_decide(lmat_ctx* ctx, const uint32_t* tids, const float* scores, const uint64_t* off, const float* stdev,
+                      uint64_t n, lmat_read_result* results);
+
 /* ---- measurement aid ---------------------------------------------------------
  * Random 64-byte bucket gather over the loaded table with the probe kernel's access shape;
  * reports the HIP-event time and the bytes it read (the practical ceiling of the probe). */

@@ -121,6 +121,7 @@ def load_library(path: str | None = None):
         "lmat_comm_size": (i32, [vp]),
         "lmat_comm_destroy": (None, [vp]),
         "lmat_db_clone": (i32, [vp, vp]),
+        "lmat_debug_decide": (i32, [vp, vp, vp, vp, vp, u64, vp]),
         "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
     }
@@ -145,7 +146,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
-            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone"]
+            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide"]
 
 
 def _ptr(a):
@@ -529,6 +530,17 @@ class Engine:
     def comm_allreduce_counts(self):
         """The merge of read_label.cpp:1760-1800 across ranks: every rank's tallies become the sum of all."""
         self._chk(self.lib.lmat_comm_allreduce_counts(self.ctx))
+
+    def debug_decide(self, tables, stdevs):
+        """tables: list of [(taxid32, score), ...]; stdevs: one per table -> results array (call_tid, call_score, match_type)."""
+        off = np.zeros(len(tables) + 1, dtype=np.uint64)
+        np.cumsum([len(t) for t in tables], out=off[1:])
+        tids = np.array([t for tb in tables for t, _ in tb], dtype=np.uint32)
+        sc = np.array([s for tb in tables for _, s in tb], dtype=np.float32)
+        sd = np.ascontiguousarray(stdevs, dtype=np.float32)
+        res = np.zeros(len(tables), dtype=READ_RESULT_DTYPE)
+        self._chk(self.lib.lmat_debug_decide(self.ctx, _ptr(tids), _ptr(sc), _ptr(off), _ptr(sd), len(tables), _ptr(res)))
+        return res
 
     def clone_db_from(self, src: "Engine"):
         self._chk(self.lib.lmat_db_clone(self.ctx, src.ctx))

@@ -664,7 +664,19 @@ template <int LIN>
 __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& S, const uint16_t* cnt, float* score, float* score0,
                          const uint16_t* dep, const uint8_t* sflags, const uint16_t* tin, const uint16_t* tout,
                          const uint16_t* reg, uint16_t* ord, LinEnt* lin, int nT, uint32_t cand, bool use_nm,
-                         const float* nm_rp, const uint8_t* nm_cl, const NullModelDev& ND, K4Key* keys = nullptr) {
+                         const float* nm_rp, const uint8_t* nm_cl, const NullModelDev& ND, K4Key* keys = nullptr,
+                         const float* preset_stdev = nullptr) {
+    if (preset_stdev) {  // lmat_debug_decide: score[] and the standard deviation are given (a record of a reference run):
+                         // straight to the sort and findReadLabelVer2, exactly the code every other read goes through below
+        float top = 0.0f;
+        for (int s = 0; s < nT; ++s) if (s == 0 || score[s] > top) top = score[s];
+        res.cand_kmer_cnt = (uint16_t)cand;
+        res.status = LMAT_ST_CALL;
+        res.log_avg = 0;
+        res.stdev = *preset_stdev;
+        S.done = false;
+        S.top_score = top;
+    }
     bool fnd_phix = false, has_human = false;
     float log_sum = 0.0f, pos_log_sum = 0.0f, top_score = 0.0f, phix_score = 0.0f;
     unsigned sig_hits = 0, pos_sig_hits = 0;
@@ -686,7 +698,7 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
             }
         }
     }
-    for (int s = 0; s < nT; ++s) {
+    for (int s = 0; s < nT && !preset_stdev; ++s) {
         float sc = (float)cnt[s] / fcand;
         if (use_nm) {  // log_odds_score, read_label.cpp:680-690
             const float random_prob = track[nm_cl[s]];
@@ -703,6 +715,8 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
         if (P.screen_phix && (fl & kFlagPhiX)) { phix_score = sc; fnd_phix = true; }
         if (s == 0 || sc > top_score) top_score = sc;
     }
+    float stdev1;
+    if (!preset_stdev) {
     res.cand_kmer_cnt = (uint16_t)cand;
     S.done = false;
     S.top_score = top_score;
@@ -724,13 +738,17 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
         if (sc > 0 && pos_sig_hits > 3) { const float v = log_avg - sc; log_std += (v * v); }
         if (pos_sig_hits <= 3) { const float v = log_avg - sc; log_std += (v * v); }
     }
-    float stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0;
+    stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0;
     res.status = LMAT_ST_CALL;
     res.log_avg = log_avg;
     res.stdev = stdev1;
     if (has_human) {  // :883-891
         for (int s = 0; s < nT; ++s)
             if (sflags[s] & kFlagHuman) score[s] += (P.hbias * stdev1);
+    }
+    } else {
+        stdev1 = *preset_stdev;
+        top_score = S.top_score;
     }
     if (P.stop_after == 14) { S.done = true; return; }  // timing experiments: scores and statistics only
     if (keys) {
@@ -2741,6 +2759,67 @@ __global__ __launch_bounds__(64, 8) void k4_kernel(ClassifyArgs A) {
     }
 }
 
+// lmat_debug_decide: the decision kernels' own code (k4_part1 from the sort on, the ancestors of the shallowest lineage
+// member, k4_part2) on candidate tables given from outside -- taxid + score per candidate and the read's standard deviation,
+// e.g. what a reference run printed.  One lane per record, tables in private memory like k4_kernel.
+__global__ __launch_bounds__(64) void k4_debug_kernel(ClassifyArgs A, const uint32_t* __restrict__ idx, const float* __restrict__ scores,
+                                                      const uint64_t* __restrict__ off, const float* __restrict__ stdevs, uint64_t n) {
+    constexpr int TT = kK4T, LIN = kK4T + 72;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const GAS uint32_t* g_tid32 = (const GAS uint32_t*)A.tb.tid32;
+    const GAS uint64_t* g_paths8 = (const GAS uint64_t*)A.tb.paths8;
+    const GAS u32x4* g_facts16 = (const GAS u32x4*)A.tb.facts16;
+    uint16_t reg[TT], cnt[TT], dep[TT], tin[TT], tout[TT], ord[TT];
+    uint8_t sflags[TT];
+    float score[TT], score0[TT];
+    LinEnt lin[LIN];
+    K4Key keys[TT];
+    lmat_read_result res;
+    res.status = 255; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = 0; res.read_len = 0; res.log_avg = 0;
+    res.stdev = 0; res.call_tid = 0; res.call_score = 0; res.cand_off = 0; res.n_cand = 0; res.bin_sel = 0;
+    const int nT = (int)(off[i + 1] - off[i]);
+    if (nT >= 1 && nT <= TT) {
+        for (int s = 0; s < nT; ++s) {
+            const uint32_t t = idx[off[i] + s];
+            const u32x4 f = g_facts16[t];
+            reg[s] = (uint16_t)t; cnt[s] = 0; score[s] = score0[s] = scores[off[i] + s];
+            dep[s] = (uint16_t)(f.w & 0xFFFFu); sflags[s] = (uint8_t)(f.w >> 16); tin[s] = (uint16_t)(f.z & 0xFFFFu); tout[s] = (uint16_t)(f.z >> 16);
+        }
+        const float sd = stdevs[i];
+        K4State S;
+        k4_part1<LIN>(A.prm, res, S, cnt, score, nullptr, dep, sflags, tin, tout, reg, ord, lin, nT, (uint32_t)nT, false, nullptr, nullptr, A.nm, keys, &sd);
+        int nlin = S.nlin;
+        const uint32_t high_tid = S.highest >= 0 ? reg[S.highest] : 0;
+        const bool have_add = S.highest_depth != 0 && high_tid != 0;
+        uint32_t high_tin = 0xFFFF, high_tout = 0xFFFF;
+        bool trunc = false;
+        if (have_add) {  // ancestors of the shallowest accepted node with their all_cand_set scores or -10000 (:326-343)
+            high_tin = tin[S.highest];
+            high_tout = tout[S.highest];
+            const u32x4 hf = g_facts16[high_tid];
+            const uint32_t alen = hf.y & 0xFFFFu, aoff = hf.x;
+            for (uint32_t j = 0; j < alen && !trunc; ++j) {
+                if (nlin >= LIN) { trunc = true; break; }
+                const uint64_t pe = g_paths8[aoff + j];
+                const uint32_t a = (uint32_t)(pe & 0xFFFFu);
+                int sl = -1;
+                for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
+                LinEnt en;
+                en.tid = (uint16_t)a;
+                en.score = sl >= 0 ? score0[sl] : -10000.0f;
+                en.dep = (uint16_t)(pe >> 16); en.tin = (uint16_t)(pe >> 32); en.tout = (uint16_t)(pe >> 48);
+                lin[nlin++] = en;
+            }
+        }
+        if (!trunc) {
+            uint32_t ncand = 0, call_idx = 0;
+            k4_part2<LIN>(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, nullptr, &ncand, &call_idx);
+        } else res.status = 255;
+    }
+    store_result((GAS uint64_t*)(A.results + i), res);
+}
+
 // Random 64-byte bucket gather with the probe's access shape (4 lanes x 16 B per bucket, 9 wave-loads = 144 buckets
 // in flight per wave): the practical ceiling of K2 on this table, and a known byte count to calibrate the
 // FETCH_SIZE counter against.
@@ -2977,6 +3056,12 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     if (a.count_ptr && INK4 && grid > 512) grid = 512;  // the lists of the large classes are short; the E = 512 class may get a tenth of a batch
     if (grid < 1) grid = 1;
     classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
+}
+
+void launch_k4_debug(const ClassifyArgs& a, const uint32_t* idx, const float* scores, const uint64_t* off, const float* stdevs, uint64_t n,
+                     hipStream_t stream) {
+    if (!n) return;
+    k4_debug_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(a, idx, scores, off, stdevs, n);
 }
 
 int classify_max_read_len() { return kGmemU + 19; }

@@ -64,6 +64,8 @@ void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stre
                      hipEvent_t forked);
 void launch_k4_end(const ClassifyArgs& a, hipStream_t join_stream, hipStream_t stream2, hipStream_t stream3, hipStream_t small_stream,
                    hipEvent_t joined2, hipEvent_t joined3, hipEvent_t joined_small, hipEvent_t done);
+void launch_k4_debug(const ClassifyArgs& a, const uint32_t* idx, const float* scores, const uint64_t* off, const float* stdevs, uint64_t n,
+                     hipStream_t stream);
 int classify_max_read_len();
 size_t classify_gmem_scratch_bytes();
 // issues ~n_probes random bucket reads (rounded up to 144 per wave x 4096 waves)

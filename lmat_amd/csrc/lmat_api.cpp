@@ -1388,6 +1388,45 @@ int lmat_nullmodel_clear(lmat_ctx* c) {
     return LMAT_OK;
 }
 
+// Test hook: the decision kernels' code on candidate tables given from outside (include/lmat_hip.h).
+int lmat_debug_decide(lmat_ctx* c, const uint32_t* tids, const float* scores, const uint64_t* off, const float* stdev, uint64_t n,
+                      lmat_read_result* results) {
+    if (!c || !tids || !scores || !off || !stdev || !results) return LMAT_E_ARG;
+    if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy first");
+    if (!n) return LMAT_OK;
+    hipSetDevice(c->device);
+    const uint64_t total = off[n];
+    std::vector<uint32_t> idx(total);
+    for (uint64_t i = 0; i < total; ++i) {
+        auto it = c->tax.index_of.find(tids[i]);
+        if (it == c->tax.index_of.end()) return set_err(c, LMAT_E_TAXONOMY, "taxid " + std::to_string(tids[i]) + " is not in the taxonomy");
+        idx[i] = it->second;
+    }
+    uint32_t* d_idx = nullptr; float *d_sc = nullptr, *d_sd = nullptr; uint64_t* d_off = nullptr; lmat_read_result* d_res = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_idx, std::max<uint64_t>(total, 1) * 4));
+    HIPCHK(c, hipMalloc((void**)&d_sc, std::max<uint64_t>(total, 1) * 4));
+    HIPCHK(c, hipMalloc((void**)&d_sd, n * 4));
+    HIPCHK(c, hipMalloc((void**)&d_off, (n + 1) * 8));
+    HIPCHK(c, hipMalloc((void**)&d_res, n * sizeof(lmat_read_result)));
+    HIPCHK(c, hipMemcpyAsync(d_idx, idx.data(), total * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_sc, scores, total * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_sd, stdev, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    ClassifyArgs a;
+    a.tb = c->dev;
+    a.prm = kparams(c->params);
+    a.prm.stop_after = 0;
+    a.results = d_res;
+    a.nm = NullModelDev();
+    launch_k4_debug(a, d_idx, d_sc, d_off, d_sd, n, c->stream);
+    HIPCHK(c, hipMemcpyAsync(results, d_res, n * sizeof(lmat_read_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_idx); hipFree(d_sc); hipFree(d_sd); hipFree(d_off); hipFree(d_res);
+    for (uint64_t i = 0; i < n; ++i)
+        if (results[i].status == 255) return set_err(c, LMAT_E_CAPACITY, "a candidate table outside 1..64 entries, or a lineage beyond the scratch");
+    return LMAT_OK;
+}
+
 int lmat_last_timing(const lmat_ctx* c, float* classify_ms, float* decide_ms, uint64_t* launches) {
     if (!c) return LMAT_E_ARG;
     if (classify_ms) *classify_ms = c->last_classify_ms;
