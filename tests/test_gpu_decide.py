@@ -43,7 +43,7 @@ def test_decision_kernels_reproduce_the_reference_example_calls(tmp_path):
             tops.add(t)
         cross += len(tops) > 1
     orc.close()
-    assert multi > 300 and cross >= 10   # competitor scans, and candidate sets that span kingdoms, are really exercised
+    assert multi >= 8 and cross >= 10   # poisoned lineages (MultiMatch by the replay itself), and candidate sets that span kingdoms, occur
     # shuffled input order: the sort is part of what is tested
     rng = np.random.default_rng(3)
     shuf = [[tb[i] for i in rng.permutation(len(tb))] for tb in tables]
