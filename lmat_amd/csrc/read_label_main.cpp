@@ -44,6 +44,7 @@
 #include "../../include/lmat_hip.h"
 #include "fastx.hpp"
 #include "outfmt.hpp"
+#include "rollups.hpp"
 
 #define LMAT_VERSION "1.2.4_2018a"
 
@@ -783,6 +784,19 @@ int main(int argc, char* argv[]) {
         std::cout << "Writing NoMatchSum file in " << sbase << ".nomatchsum" << std::endl;
         static const char* names[3] = {"ReadTooShort", "NoDbHits", "LowScore"};
         for (auto& p : nomatch_merge) nom_ofs << names[p.first] << "\t" << p.second << std::endl;
+    }
+    // LMAT_ROLLUPS=<ranks, e.g. plasmid,species,genus>: the roll-ups bin/run_rl.sh makes from the .fastsummary right after
+    // read_label (tolineage.py + fsreport.py, :251-252) written here, from the inputs this run already has: -u names, -c tree,
+    // -w rank table, -r plasmid list (+ $LMAT_DIR/plasmid.names.txt when it exists)
+    if (const char* ru = getenv("LMAT_ROLLUPS")) {
+        RollupInputs in;
+        in.tree_fn = tax_tree_fn; in.rank_fn = rank_map_file; in.plasmid_fn = plasmid_file;
+        if (const char* ld = getenv("LMAT_DIR")) in.plasmid_names_fn = std::string(ld) + "/plasmid.names.txt";
+        std::string err, odir = ".";
+        { const size_t sl = sbase.rfind('/'); if (sl != std::string::npos) odir = sbase.substr(0, sl); }
+        bool ok = rank_ids.empty() || write_lineage(rank_ids, sbase + ".fastsummary", sbase + ".fastsummary.lineage", 10, 0.0, &err);
+        if (ok && !rank_map_file.empty() && !tax_tree_fn.empty()) ok = write_rank_reports(sbase + ".fastsummary", ru, odir, in, &err);
+        if (!ok) { std::cerr << "ERROR! roll-ups: " << err << std::endl; destroy_all(); return -1; }
     }
     // the query timer stops where upstream's does (read_label.cpp:1868): after the summaries, before teardown
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

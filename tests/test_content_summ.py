@@ -89,3 +89,66 @@ def test_content_summ_threshold_and_rank_selection(tmp_path):
     assert ra.keys() == rb.keys() and "taxid=5476" in ra
     assert 0 < tot(rb["taxid=5476"]) < tot(ra["taxid=5476"])                 # fewer reads pass the threshold
     assert all("distinct_kmer_cnt=0 " in l for l in rows(a + ".genus_kmer_cov").values())  # genus not selected: nothing counted
+
+
+# ---- the roll-ups of the .fastsummary (bin/run_rl.sh:251-252: tolineage.py, fsreport.py) ---------------------------------
+UNCALLED_RANKS = {  # NCBI ranks of the tree's nodes that no read was called to (the .fastsummary names the rank of every called one)
+    10239: "superkingdom", 35237: "no rank", 548681: "order", 860343: "no rank", 28384: "no rank", 81077: "no rank",
+    2: "superkingdom", 1224: "phylum", 1236: "class", 72274: "order", 33154: "no rank", 147537: "subphylum", 4891: "class"}
+
+
+def test_fastsummary_rollups_reproduce_the_reference_example(tmp_path):
+    """<fastsummary>.lineage (tolineage.py: read count + ranked lineage names of every call with more than 10 reads) and
+    <fastsummary>.species / .genus (fsreport.py with the gene summary gene_label wrote for the run and its threshold of 10
+    reads, bin/run_gl.sh:162-164): the reference's own files for the example run, byte for byte."""
+    T, rank = example_inputs(tmp_path)
+    nodes = {n["tid"]: n for n in T["nodes"]}
+    names_rank = {}
+    for line in T["files"][""].splitlines():
+        c = line.split("\t")
+        names_rank[int(c[2])] = c[3].split(",", 1)[0]
+    names_rank.update(UNCALLED_RANKS)
+    with open(tmp_path / "names.txt", "w") as f:
+        for t, n in nodes.items():
+            chain = []
+            x = t
+            while x != 1:
+                chain.append(x)
+                x = nodes[x]["parent"]
+            lin = "\t".join(f"{names_rank[a]},{nodes[a]['name']}" for a in reversed(chain))
+            f.write(f"depth={n['depth']},taxid={t},ktaxid={t},entries=-1" + ("\t" + lin if lin else "") + "\n")
+    tar = tarfile.open(os.path.join(G, "example_gene.tar.gz"))
+    (tmp_path / "genesummary_tax").write_bytes(tar.extractfile("genesummary_tax").read())
+    (tmp_path / "plasmids.txt").write_text("")
+    exe = os.path.join(ROOT, "lmat_amd", "csrc", "fs_rollup")
+    fs = str(tmp_path / "run.fastsummary")
+    r = subprocess.run([exe, "-s", fs, "-u", str(tmp_path / "names.txt"), "-c", str(tmp_path / "tax.dat"), "-w", str(tmp_path / "ranks.txt"),
+                        "-r", str(tmp_path / "plasmids.txt"), "-a", "plasmid,species,genus", "-g", str(tmp_path / "genesummary_tax"), "-q", "10"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert open(fs + ".lineage").read() == T["files"][".lineage"]
+    assert open(fs + ".species").read() == T["files"][".species"]
+    assert open(fs + ".genus").read() == T["files"][".genus"]
+    assert not os.path.exists(fs + ".plasmid")          # no plasmid was called: upstream writes no file for an empty rank
+    # without a gene summary: the three gene columns go
+    for f in (".species", ".genus"):
+        os.remove(fs + f)
+    subprocess.run([exe, "-s", fs, "-c", str(tmp_path / "tax.dat"), "-w", str(tmp_path / "ranks.txt")], check=True)
+    want = ["\t".join(c for i, c in enumerate(l.split("\t")) if i not in (3, 4, 5)) for l in T["files"][".species"].splitlines()]
+    assert open(fs + ".species").read().splitlines() == want
+
+
+def test_ordered_reports_reproduce_the_reference_example(tmp_path):
+    """<fastsummary>.ordered.{plasmid,species,genus} (bin/summary.py over content_summ's report, bin/run_cs.sh:150): here made
+    from OUR content_summ's files, and equal to the reference's own -- floats as Python 2 prints them, a node's k sizes in
+    Python 2's dict order (8,17,10,12,14)."""
+    T, rank = example_inputs(tmp_path)
+    fs = str(tmp_path / "run.fastsummary")
+    subprocess.run([EXE, "-c", str(tmp_path / "tax.dat"), "-l", fs, "-k", "8,10,12,14,17", "-f", str(tmp_path / "rl.flst"),
+                    "-r", str(tmp_path / "ranks.txt"), "-a", "plasmid,species,genus", "-o", fs + ".summ"], check=True, capture_output=True)
+    (tmp_path / "plasmids.txt").write_text("")
+    exe = os.path.join(ROOT, "lmat_amd", "csrc", "fs_rollup")
+    subprocess.run([exe, "-s", fs, "-c", str(tmp_path / "tax.dat"), "-w", str(tmp_path / "ranks.txt"), "-r", str(tmp_path / "plasmids.txt"),
+                    "-a", "plasmid,species,genus", "-S", fs + ".summ"], check=True)
+    for r in ("plasmid", "species", "genus"):
+        assert open(fs + ".ordered." + r).read() == T["files"][".ordered." + r], r

@@ -153,3 +153,25 @@ def test_cli_with_two_contexts_clones_the_database(small_dataset, tmp_path):
     assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
     for suffix in ("0.out", ".0.30.fastsummary", ".0.30.nomatchsum"):
         assert open(str(tmp_path / "a") + suffix).read() == open(str(tmp_path / "b") + suffix).read(), suffix
+
+
+def test_cli_writes_the_rollups_itself(small_dataset, tmp_path):
+    """LMAT_ROLLUPS=<ranks>: read_label writes <fastsummary>.lineage and <fastsummary>.<rank> after the summaries -- what
+    bin/run_rl.sh:251-252 runs tolineage.py / fsreport.py for -- from the inputs the run already has; the files equal what the
+    stand-alone tool makes of the same .fastsummary."""
+    ds = small_dataset
+    r = _cli(ds, str(tmp_path / "o"), ds["fasta"], {"LMAT_ROLLUPS": "species,genus"})
+    assert r.returncode == 0, r.stderr
+    fs = str(tmp_path / "o") + ".0.30.fastsummary"
+    got = {s: open(fs + s).read() for s in (".lineage", ".species", ".genus")}
+    assert got[".species"].count("\n") > 3 and got[".lineage"].count("\n") > 3
+    for s in got:
+        os.rename(fs + s, fs + s + ".cli")
+    subprocess.run([os.path.join(ROOT, "lmat_amd", "csrc", "fs_rollup"), "-s", fs, "-u", ds["names"], "-c", ds["tree"], "-w", ds["rank"],
+                    "-a", "species,genus"], check=True)
+    for s in got:
+        assert open(fs + s).read() == got[s], s
+    # every read called at or below a species is in exactly one species row
+    total = sum(int(l.split("\t")[2]) for l in got[".species"].splitlines()[1:])
+    called = sum(int(l.split("\t")[1]) for l in open(fs))
+    assert 0 < total <= called
