@@ -221,6 +221,7 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="the timed window of --steps steps is `value`; this many further windows of the same steps give value_median_of_windows (0: none)")
     ap.add_argument("--as-ranks", type=int, default=1, help="tests: ONE rank classifies the read sets of this many ranks one after the other (what an N-rank run must add up to)")
     ap.add_argument("--tally-out", default=None, help="tests: rank 0 writes the merged per-taxid tallies to this JSON file")
+    ap.add_argument("--genome-len", type=int, default=0, help="bases per strain genome (default: sized so that the table holds ~6.4 k-mers per bucket)")
     ap.add_argument("--spawn-check", action="store_true", help="tests: every rank prints the environment it was started with and exits before touching a GPU")
     args = ap.parse_args()
 
@@ -264,7 +265,7 @@ def main():
     table_bytes = int(args.db_gb * (1 << 30)) // 64 * 64
     n_species, S = 768, 3
     pm = 1.0 - 0.99 ** k
-    G = int(0.8 * (table_bytes / 8) / (n_species * (1.0 + S * pm)))
+    G = args.genome_len or int(0.8 * (table_bytes / 8) / (n_species * (1.0 + S * pm)))
     t0 = time.perf_counter()
     eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes, genus_block_permille=args.genus_permille, list_replicas=args.list_replicas)
     t_build = time.perf_counter() - t0

@@ -140,6 +140,13 @@ int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed
 int lmat_synth_db_build2(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes,
                          uint32_t genus_block_permille, uint32_t list_replicas);
 
+/* Test hook for the synthetic database: what it must hold for the window of `species` (0-based) that starts at base `pos` of the
+ * species ancestor -- the canonical k-mer and its taxid list (the strains that carry the window unmutated; with two or more
+ * owners also their species, and the genus when they span species) -- computed on the HOST from the generator's functions, never
+ * read from the device table.  *n = 0: no strain kept the window.  (The table itself may hold a different list for that k-mer
+ * when another window yields the same 20-mer: about 1 % of them at 6.4 G k-mers; the smaller payload wins.) */
+int lmat_synth_window(lmat_ctx* ctx, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* tids, uint32_t cap, uint32_t* n);
+
 /* ---- gene databases (src/gene_label.cpp) ---------------------------------------------------
  * gene_label runs the same lookup against a database whose lists are 32-bit GENE ids (INDEXDB<uint32_t>, TaxNodeStat
  * <uint32_t>, gene_label.cpp:15-22,218-267) and has no taxonomy step.  A context opened with lmat_genedb_begin (instead of a

@@ -122,6 +122,7 @@ def load_library(path: str | None = None):
         "lmat_comm_destroy": (None, [vp]),
         "lmat_db_clone": (i32, [vp, vp]),
         "lmat_debug_decide": (i32, [vp, vp, vp, vp, vp, u64, vp]),
+        "lmat_synth_window": (i32, [vp, u32, u64, P(u64), vp, u32, P(u32)]),
         "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
     }
@@ -146,7 +147,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
-            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide"]
+            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_synth_window"]
 
 
 def _ptr(a):
@@ -530,6 +531,13 @@ class Engine:
     def comm_allreduce_counts(self):
         """The merge of read_label.cpp:1760-1800 across ranks: every rank's tallies become the sum of all."""
         self._chk(self.lib.lmat_comm_allreduce_counts(self.ctx))
+
+    def synth_window(self, species, pos):
+        """-> (canonical k-mer, [taxid32...]) the synthetic database must hold for that ancestor window (host-derived)."""
+        km, n = C.c_uint64(0), C.c_uint32(0)
+        t = np.zeros(32, dtype=np.uint32)
+        self._chk(self.lib.lmat_synth_window(self.ctx, species, int(pos), C.byref(km), _ptr(t), 32, C.byref(n)))
+        return int(km.value), t[:n.value].tolist()
 
     def debug_decide(self, tables, stdevs):
         """tables: list of [(taxid32, score), ...]; stdevs: one per table -> results array (call_tid, call_score, match_type)."""

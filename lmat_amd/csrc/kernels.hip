@@ -212,8 +212,10 @@ __global__ void insert_pairs_kernel(DeviceTables tb, const uint64_t* __restrict_
                                     const uint32_t* __restrict__ payload, uint64_t n, uint32_t* fail) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride)
+    for (; i < n; i += stride) {
+        if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // a table without room fails once, not once per k-mer after a 16 384-bucket crawl each
         if (!table_insert(tb, kmers[i], payload[i])) atomicAdd(fail, 1u);
+    }
 }
 
 // After a build of the compact layout, per bucket: two inserts of one key that raced into the same bucket are merged
@@ -316,6 +318,7 @@ __global__ void synth_db_kernel(DeviceTables tb, SynthGeo g, int k, const uint16
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long local = 0;
     for (; i < total; i += stride) {
+        if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // no room left: stop, do not crawl (see cpt_displaced_share)
         const uint32_t sp = (uint32_t)(i / npos);
         const uint64_t pos = i % npos;
         const bool inblk = pos + k <= g.blk;
@@ -427,7 +430,7 @@ __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmer
         if (stride) tids[i * stride] = tb.tid32[pay];
         return;
     }
-    const uint32_t eoff = kListUnit * (pay - kListBase);
+    const size_t eoff = LMAT_LIST_OFF(pay, tb.list_shift);
     if (tb.arena[eoff] & 0x8000u) {  // gene database: [0x8000][n][0][id lo, id hi]...
         const uint32_t n = tb.arena[eoff + 1];
         counts[i] = n;
@@ -929,7 +932,18 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
                                         int valid_kmers, uint32_t len, int bin_sel) {
     const float hbias = Ap->prm.hbias, sdiff = Ap->prm.sdiff;
     const int screen_phix = Ap->prm.screen_phix;
-    if (Ap->nm.active | Ap->prm.stop_after) return false;
+    const int stop = Ap->prm.stop_after;   // 30..33: timing experiments (the step ends early with a placeholder record)
+    if (Ap->nm.active || (stop != 0 && (stop < 30 || stop > 33))) return false;
+    auto placeholder = [&]() {
+        if (lane == 0) {
+            lmat_read_result q;
+            q.status = LMAT_ST_SILENT; q.match_type = LMAT_MT_NOMATCH; q.cand_kmer_cnt = (uint16_t)cand; q.valid_kmers = valid_kmers; q.read_len = (int)len;
+            q.log_avg = 0; q.stdev = 0; q.call_tid = 0; q.call_score = 0; q.cand_off = 0; q.n_cand = 0; q.bin_sel = bin_sel;
+            store_result(out, q);
+        }
+        return true;
+    };
+    if (stop == 30) return placeholder();
     if (cand - 1u > 998u || nT - 1u > 63u) return false;   // cand in 1..999, 1..64 taxids
     const bool act = (uint32_t)lane < nT;
     const uint32_t dep = act ? (fz.w & 0xFFFFu) : 0u, fl = act ? (fz.w >> 16) : 0u;
@@ -1032,6 +1046,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         log_std += q.x; log_std += q.y; log_std += q.z; log_std += q.w;
     }
     const float stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0.0f;
+    if (stop == 31) { if (stdev1 == -1.0f || top_score == -1.0f || ptid + pfl + piv == 0xFFFFFFFFu) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
     lmat_read_result res;
     res.status = LMAT_ST_CALL; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = (uint16_t)cand; res.valid_kmers = valid_kmers;
     res.read_len = (int)len; res.log_avg = log_avg; res.stdev = stdev1; res.call_tid = 0; res.call_score = 0; res.cand_off = 0; res.n_cand = 0;
@@ -1066,6 +1081,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
             if (j == (int)nT - 1 || dj > low_dep) { low_pos = j; low_dep = dj; }
             if (j == (int)nT - 1 || dj < high_dep) { high_pos = j; high_dep = dj; }
         }
+        if (stop == 32) { if (lidx == 77 || low_pos == 99 || high_dep == 0xFFFFFFu) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
         // the top-scoring plasmid the loop meets last (:301-304, 324): it runs on below lidx while the scores stay at the top
         int plasmid_pos = -1;
         {
@@ -1180,6 +1196,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
                 }
             }
         }
+        if (stop == 33) { if (call_tid == 0xFFFFFFu && call_score == -5.0f) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
         if (plasmid_pos >= 0 && match != LMAT_MT_LCA_ERROR) {  // :410-416
             const uint32_t piv_p = rl(piv, plasmid_pos);
             if ((call_iv & 0xFFFFu) < (piv_p & 0xFFFFu) && (piv_p >> 16) <= (call_iv >> 16)) call_tid = rl(ptid, plasmid_pos);
@@ -1917,7 +1934,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
             const uint32_t d = d0 + lane;
             uint32_t n = 0;
-            if (d < ndist) n = arena[(size_t)kListUnit * (dpay[d] - kListBase) + 1];
+            if (d < ndist) n = arena[LMAT_LIST_OFF(dpay[d], tb.list_shift) + 1];
             uint32_t incl = n;
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t v = __shfl_up(incl, o);
@@ -1941,7 +1958,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             uint32_t gid = 0, h = 0, m = 0;
             if (act) {
                 const uint32_t d = el_d[e];
-                const size_t at = (size_t)kListUnit * (dpay[d] - kListBase) + kListHdr + 2 * (e - dstart[d]);
+                const size_t at = LMAT_LIST_OFF(dpay[d], tb.list_shift) + kListHdr + 2 * (e - dstart[d]);
                 gid = (uint32_t)arena[at] | ((uint32_t)arena[at + 1] << 16);
                 m = dmult[d];
                 const uint32_t key = gid + 1u;
@@ -2015,7 +2032,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             n = 1;
             w3 = w4 = pay;
             if (pay >= kListBase) {
-                const u32x4 ch = *(const GAS u32x4*)(arena + (size_t)kListUnit * (pay - kListBase));  // [flags][n_kept][n_raw][ids...]
+                const u32x4 ch = *(const GAS u32x4*)(arena + LMAT_LIST_OFF(pay, tb.list_shift));  // [flags][n_kept][n_raw][ids...]
                 fl = ch.x & 0xFFFFu;
                 n = ch.x >> 16;
                 w3 = ch.y >> 16; w4 = ch.z & 0xFFFFu; w5 = ch.z >> 16; w6 = ch.w & 0xFFFFu;
@@ -2066,7 +2083,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             if (e < nel) {
                 const uint32_t d = el_d[e], n = dn[d];
                 if (n > 2) {
-                    const uint32_t eoff = kListUnit * (dpay[d] - kListBase) + kListHdr, j = e - dstart[d];
+                    const size_t eoff = LMAT_LIST_OFF(dpay[d], tb.list_shift) + kListHdr;
+                    const uint32_t j = e - dstart[d];
                     el_t[e] = arena[eoff + j];
                     el_ta[e] = arena[eoff + n + j];
                 }
@@ -3094,6 +3112,25 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
 
 uint32_t synth_strain_base_host(const SynthGeo& g, uint32_t species, uint32_t strain_global, uint64_t pos) {
     return synth_strain_base(g, species, strain_global, pos);
+}
+// what synth_db_kernel files for the ancestor window at (species, pos): the canonical k-mer, the first strain that may carry
+// it, and the mask of those strains (from first_strain on) whose copy of the window has no substitution
+void synth_window_host(const SynthGeo& g, int k, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* first_strain, uint32_t* mask, bool* inblk) {
+    const bool blk = pos + k <= g.blk;
+    const uint32_t sp = blk ? species - species % g.spg : species;
+    uint64_t anc = 0;
+    for (int j = 0; j < k; ++j) anc = (anc << 2) | synth_anc_base(g, sp, pos + j);
+    const uint32_t ns = blk ? g.spg * g.S : g.S;
+    uint32_t m = 0;
+    for (uint32_t s = 0; s < ns; ++s) {
+        bool mut = false;
+        for (int j = 0; j < k; ++j) mut |= synth_strain_mut(g, sp * g.S + s, pos + j);
+        if (!mut) m |= 1u << s;
+    }
+    *kmer = canon_from_fwd(anc, k);
+    *first_strain = sp * g.S;
+    *mask = m;
+    *inblk = blk;
 }
 
 }  // namespace lmat

@@ -75,5 +75,6 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
 
 // host-callable copies of the synthetic genome functions (tests / oracle cross-checks)
 uint32_t synth_strain_base_host(const SynthGeo& g, uint32_t species, uint32_t strain_global, uint64_t pos);
+void synth_window_host(const SynthGeo& g, int k, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* first_strain, uint32_t* mask, bool* inblk);
 
 }  // namespace lmat

@@ -297,14 +297,23 @@ int lmat_db_load_image(lmat_ctx* c, const char* fn, uint64_t table_bytes) {
     return LMAT_OK;
 }
 
-// Share of the k-mers that do not fit their 12-slot bucket at an average of `load` k-mers per bucket (k-mers arrive in
-// minimizer groups of ~2.5, so the tail is heavier than Poisson; scripts/minimizer_sim.py: 6.1 % at 6.4).
-// Share of the k-mers that do not fit their 12-slot bucket at an average of `load` k-mers per bucket.  K-mers arrive in
-// minimizer groups (~2.5 per genome, several times that where many strains share a region), so the tail is far heavier
-// than Poisson: scripts/minimizer_sim.py gives 6.1 % at 6.4 for three strains per species.  The overflow table is sized
-// for twice this estimate plus 1 % at a load of 0.6, and the build refuses a table that ends up more than 85 % full
-// (linear probing there means probe chains of thousands of buckets).
-static double cpt_displaced_share(double load) { return std::min(0.6, 0.061 * std::pow(load / 6.4, 2.5) + 0.01); }
+// Share of the k-mers that do not fit their 12-slot bucket.  Two things drive it:
+//  * the average number of k-mers per bucket (`load`).  K-mers arrive in minimizer groups (~2.5 per genome, several times that
+//    where many strains share a region), so the tail is far heavier than Poisson: scripts/minimizer_sim.py gives 6.1 % at 6.4
+//    for three strains per species;
+//  * how often the table reuses a minimizer VALUE for unrelated k-mers: r = k-mers per canonical m-mer (4^m / 2 of them:
+//    8.6 G for k = 20).  The minimizer is the smallest of four m-mers, so the low-ranked values are chosen four times as often
+//    as the average one, and once r passes ~1 the buckets that hold them fill up whatever the mean load says: a scaled model
+//    (k = 14, same scramblers) gives 12 % displaced at load 4.4, r = 2.2 against 3.4 % from the load alone, and the term
+//    0.019 r^1.8 fits it from r = 0.5 to 3.  This was the build that "did not finish" in round 2: 20 G 20-mers (r = 2.3) into
+//    2^32 buckets with an overflow table sized for 7 % of them met ~12 %, the overflow table filled up, and every further insert
+//    crawled along a 16 384-bucket probe chain before giving up.  (2^32 buckets as such are fine: 6 G k-mers build into them in
+//    5 s.)  Builds now also stop at the first failed insert instead of crawling on.
+// The overflow table is sized for the estimate times a safety factor (2, or 1.4 where the share is large anyway) at a load of
+// 0.6, and the build refuses a table that ends up more than 85 % full.
+static double cpt_displaced_share(double load, double kmers_per_mmer) {
+    return std::min(0.8, 0.061 * std::pow(load / 6.4, 2.5) + 0.01 + 0.019 * std::pow(kmers_per_mmer, 1.8));
+}
 
 static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k) {
     if (c->dev.slots) { hipFree(c->dev.slots); c->dev.slots = nullptr; }
@@ -320,13 +329,11 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int 
         for (int attempt = 0; attempt < 8; ++attempt) {  // the bucket count is quantised: step down while table + overflow exceed the free memory
             CptGeom g = cpt_geometry(k, want);
             if (!g.nb) break;
-            // 2^32 buckets (256 GiB) address correctly, but a 20 G k-mer build into them did not finish on a 288 GiB
-            // device (cause not established): stop at 2^31 buckets unless asked, the rest of the k-mers goes to the overflow table
-            if (g.nb > (1ull << 31) && !getenv("LMAT_ALLOW_4G_BUCKETS")) { want = 1ull << 31; g = cpt_geometry(k, want); }
             const double n_est = n_kmers ? (double)n_kmers : 6.4 * (double)g.nb;
             const double load = n_est / (double)g.nb;
             if (load > 10.0) return set_err(c, LMAT_E_CAPACITY, "table_bytes (or the free device memory) too small for the number of k-mers");
-            double share = cpt_displaced_share(load) * 2.0;
+            const double s0 = cpt_displaced_share(load, n_est / (0.5 * std::pow(4.0, g.m)));
+            double share = s0 * (s0 > 0.15 ? 1.4 : 2.0);
             if (const char* e = getenv("LMAT_OVERFLOW_SHARE")) share = atof(e);
             const uint64_t onb = (uint64_t)(n_est * share / (0.6 * kSlotsPerBucket)) + 1024;
             if (onb > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "overflow table above 2^32 buckets");
@@ -365,15 +372,24 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int 
 // chunk: list records are built the first time a list is seen, so a database streams through without the whole
 // (k-mer, payload) array ever being resident on the host.
 // appends a list record on the next 16-byte boundary of the arena; returns its payload
-static uint32_t arena_append(std::vector<uint16_t>& arena, const std::vector<uint16_t>& rec) {
-    arena.resize((arena.size() + kListUnit - 1) / kListUnit * kListUnit, 0);
-    const uint32_t pay = kListBase + (uint32_t)(arena.size() / kListUnit);
+static uint32_t arena_append(std::vector<uint16_t>& arena, const std::vector<uint16_t>& rec, uint32_t shift) {
+    const size_t unit = (size_t)kListUnit << shift;
+    arena.resize((arena.size() + unit - 1) / unit * unit, 0);
+    const uint32_t pay = kListBase + (uint32_t)(arena.size() / unit);
     arena.insert(arena.end(), rec.begin(), rec.end());
     return pay;
 }
+// The alignment of a streamed build's list records has to be fixed before the first payload goes into the table.  16 bytes
+// (256 MB of records) unless the database is large: from the k-mer count the caller announced -- the distinct lists of the
+// reference's 64 GB-class databases stay well below 256 MB, a 460 GB one is not known to -- or LMAT_LIST_SHIFT=0..4.
+static uint32_t pick_list_shift(uint64_t n_kmers_hint) {
+    if (const char* e = getenv("LMAT_LIST_SHIFT")) return (uint32_t)std::min(std::max(atoi(e), 0), kListShiftMax);
+    return n_kmers_hint > 32000000000ull ? 3u : (n_kmers_hint > 8000000000ull ? 2u : 0u);
+}
 namespace lmat {
 struct StreamBuild {
-    std::vector<uint16_t> arena = std::vector<uint16_t>(kListUnit, 0);  // record 0 reserved
+    uint32_t shift = 0;                 // alignment of the list records (pick_list_shift)
+    std::vector<uint16_t> arena;        // record 0 reserved (sb_begin)
     std::vector<uint32_t> list_pay;     // per canonical list: device payload (0 = not built yet)
     std::vector<uint32_t> single_pay = std::vector<uint32_t>(65536, 0);
     std::vector<uint32_t> pay;
@@ -395,6 +411,8 @@ static int sb_begin(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int k) 
     hipSetDevice(c->device);
     sb_free(c);
     c->sb = new StreamBuild();
+    c->sb->shift = pick_list_shift(n_kmers);
+    c->sb->arena.assign((size_t)kListUnit << c->sb->shift, 0);
     int rc = alloc_table(c, n_kmers, table_bytes, k);
     if (rc) return rc;
     c->dev.k = k;
@@ -429,7 +447,7 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
                         rec[1] = (uint16_t)(l.size() / 2);
                         rec.insert(rec.end(), l.begin(), l.end());
                     } else if (!build_list_record(c, B.lists[p - kListBase], rec)) return LMAT_E_TAXONOMY;
-                    lp = arena_append(S.arena, rec);
+                    lp = arena_append(S.arena, rec, S.shift);
                 }
                 dp = lp;
             } else if (c->gene_mode) {
@@ -448,15 +466,18 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
                     } else {
                         one[0] = (uint16_t)p;
                         if (!build_list_record(c, one, rec)) return LMAT_E_TAXONOMY;
-                        sp = arena_append(S.arena, rec);
+                        sp = arena_append(S.arena, rec, S.shift);
                     }
                 }
                 dp = sp;
             }
             S.pay[i] = dp;
         }
-        if (S.arena.size() / kListUnit + kListBase > kPayloadMask)
-            return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
+        if (S.arena.size() / ((size_t)kListUnit << S.shift) + kListBase > kPayloadMask)
+            return set_err(c, LMAT_E_CAPACITY, "the taxid-list records exceed " + std::to_string(256u << S.shift) +
+                                               " MB, the range of the 24-bit payloads at this record alignment: set LMAT_LIST_SHIFT=" +
+                                               std::to_string(std::min<int>(S.shift + 1, kListShiftMax)) + " (records on " +
+                                               std::to_string(32u << S.shift) + "-byte boundaries) and build again");
         HIPCHK(c, hipMemcpyAsync(S.d_k, B.kmers.data() + s, m * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(S.d_p, S.pay.data(), m * 4, hipMemcpyHostToDevice, c->stream));
         launch_insert_pairs(c->dev, S.d_k, S.d_p, m, S.d_fail, c->stream);
@@ -483,12 +504,13 @@ static int sb_finish(lmat_ctx* c) {
     const size_t arena_words = S.arena.size();
     S.arena.resize(arena_words + 8, 0);  // the kernels read a record's first 16 bytes in one load
     if ((rc = dev_upload(c, &c->dev.arena, S.arena))) return rc;
+    c->dev.list_shift = S.shift;
     c->arena_words = arena_words;
     uint32_t fail = 0;
     HIPCHK(c, hipMemcpy(&fail, S.d_fail, 4, hipMemcpyDeviceToHost));
     uint64_t n = S.inserted;
     sb_free(c);
-    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during insert (n_kmers_hint / table_bytes too small)");
+    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table (or its overflow table) full during insert (n_kmers_hint / table_bytes too small; LMAT_OVERFLOW_SHARE raises the overflow table's share)");
     if (c->dev.cpt.nb) {  // tidy the compact buckets (slot counts; a key fed twice keeps its smaller payload) and count
         unsigned long long* d_n = nullptr;
         unsigned long long cnt[2] = {0, 0};
@@ -588,7 +610,7 @@ int lmat_db_clone(lmat_ctx* d, lmat_ctx* s) {
     HIPCHK(d, hipMemsetAsync(D.arena, 0, arena_bytes, d->stream));
     HIPCHK(d, hipMemcpyPeerAsync(D.arena, d->device, S.arena, s->device, s->arena_words * 2, d->stream));
     HIPCHK(d, hipStreamSynchronize(d->stream));
-    D.nbuckets = S.nbuckets; D.cpt = S.cpt; D.ovf_nbuckets = S.ovf_nbuckets; D.k = S.k;
+    D.nbuckets = S.nbuckets; D.cpt = S.cpt; D.ovf_nbuckets = S.ovf_nbuckets; D.k = S.k; D.list_shift = S.list_shift;
     d->n_kmers = s->n_kmers; d->arena_words = s->arena_words; d->n_lists = s->n_lists;
     d->db_ready = true;
     return LMAT_OK;
@@ -743,9 +765,21 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
         for (auto& x : th) x.join();
     }
     for (int b_ : bad) if (b_) return LMAT_E_TAXONOMY;
-    std::vector<uint16_t> arena(kListUnit, 0);  // record 0 reserved
-    for (auto& v : made)
-        for (auto& m : v) list_payload[m.slot] = arena_append(arena, m.rec);
+    // records on the smallest alignment at which all copies fit the 24-bit payloads (16 bytes: 256 MB ... 256 bytes: 4 GB)
+    std::vector<uint16_t> arena;
+    uint64_t block_units = 0;
+    uint32_t shift = 0;
+    if (const char* e = getenv("LMAT_LIST_SHIFT")) shift = (uint32_t)std::min(std::max(atoi(e), 0), kListShiftMax);
+    for (;; ++shift) {
+        const size_t unit = (size_t)kListUnit << shift;
+        arena.assign(unit, 0);  // record 0 reserved
+        for (auto& v : made)
+            for (auto& m : v) list_payload[m.slot] = arena_append(arena, m.rec, shift);
+        arena.resize((arena.size() + unit - 1) / unit * unit, 0);
+        block_units = arena.size() / unit;   // payload units of one copy of the records
+        if (block_units * list_replicas + kListBase <= kPayloadMask) break;
+        if (shift == (uint32_t)kListShiftMax) return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range even at 256-byte records");
+    }
     made.clear();
     for (uint32_t sp = 0; sp < NS; ++sp)  // single owners: plain strain payloads
         for (uint32_t s = 0; s < S; ++s) list_payload[((uint64_t)sp << S) + (1u << s)] = c->synth_strain_idx[sp * S + s];
@@ -758,9 +792,7 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
                 const uint32_t q = (uint32_t)__builtin_ctz(spmask);  // all owners in species q of the genus: that species' list
                 list_payload[g_off + ((uint64_t)ge << GB) + mask] = list_payload[((uint64_t)(ge * spg + q) << S) + ((mask >> (q * S)) & ((1u << S) - 1))];
             }
-    arena.resize((arena.size() + kListUnit - 1) / kListUnit * kListUnit, 0);
-    const uint64_t block_units = arena.size() / kListUnit;   // payload units of one copy of the records
-    if (block_units * list_replicas + kListBase > kPayloadMask) return set_err(c, LMAT_E_CAPACITY, "taxid-list arena exceeds the 24-bit payload range");
+    c->dev.list_shift = shift;
     int rc;
     {   // the device arena: list_replicas copies back to back (+ 16 bytes of slack: a record's first 16 bytes are one load)
         if (c->dev.arena) { hipFree(c->dev.arena); c->dev.arena = nullptr; }
@@ -795,7 +827,7 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
     HIPCHK(c, hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(ins, d_ins, 32, hipMemcpyDeviceToHost));
     hipFree(d_fail); hipFree(d_ins); hipFree(d_lp);
-    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table full during synthetic build");
+    if (fail) return set_err(c, LMAT_E_CAPACITY, "hash table (or its overflow table) full during the synthetic build: the build stopped at the first k-mer without a slot");
     if (c->dev.cpt.nb && (rc = check_overflow_fill(c, ins[2]))) return rc;
     c->n_kmers = ins[1];
     c->synth_genome_len = G;
@@ -803,6 +835,35 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
     c->synth_geo = geo;
     c->n_lists = (uint64_t)list_payload.size() * list_replicas;
     c->db_ready = true;
+    return LMAT_OK;
+}
+
+// Test hook: what the synthetic database must hold for the ancestor window of `species` at `pos`, derived on the HOST from the
+// generator's own functions (never from the device table): the canonical k-mer and the taxid list tax_histo's LCA closure gives
+// its owners (include/lmat_hip.h).  *n = 0: every strain mutated the window, the k-mer was not filed.
+int lmat_synth_window(lmat_ctx* c, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* tids, uint32_t cap, uint32_t* n) {
+    if (!c || !kmer || !n) return LMAT_E_ARG;
+    if (!c->synth_genome_len) return set_err(c, LMAT_E_ARG, "lmat_synth_db_build first");
+    const SynthGeo& g = c->synth_geo;
+    const int k = c->dev.k;
+    if (species >= g.n_species || pos + k > g.G) return set_err(c, LMAT_E_ARG, "window outside the synthetic genomes");
+    uint32_t first = 0, mask = 0;
+    bool inblk = false;
+    synth_window_host(g, k, species, pos, kmer, &first, &mask, &inblk);
+    const HostTaxonomy& T = c->tax;
+    std::vector<uint32_t> out;
+    const uint32_t S = g.S, ns = inblk ? g.spg * S : S;
+    uint32_t spmask = 0;
+    for (uint32_t s = 0; s < ns; ++s)
+        if (mask & (1u << s)) { out.push_back(T.tid32[c->synth_strain_idx[first + s]]); spmask |= 1u << (s / S); }
+    if (out.size() >= 2) {  // owners + their species, + the genus when they span species (src/kmerdb/TaxTree.hpp:160-260)
+        const uint32_t sp0 = first / S;
+        for (uint32_t q = 0; q < (inblk ? g.spg : 1u); ++q)
+            if (spmask & (1u << q)) out.push_back(T.tid32[c->synth_species_idx[sp0 + q]]);
+        if (__builtin_popcount(spmask) >= 2) out.push_back(T.tid32[T.paths[T.path_off[c->synth_species_idx[sp0]]]]);
+    }
+    *n = (uint32_t)out.size();
+    for (uint32_t i = 0; i < out.size() && i < cap; ++i) if (tids) tids[i] = out[i];
     return LMAT_OK;
 }
 

@@ -28,7 +28,11 @@ static const int kSlotsPerBucket = 8;
 //   [3+n_kept .. 3+2*n_kept)   kept ids ascending by 32-bit taxid
 //   [3+2*n_kept .. +n_raw)     raw list as stored in the DB (16-bit DB ids), for lookups
 static const int kListHdr = 3;
-static const int kListUnit = 8;   // u16 units per payload step
+static const int kListUnit = 8;   // u16 units per payload step at shift 0
+// Larger arenas: a table may place its records on (16 << list_shift)-byte boundaries instead, so that the same 24-bit payloads
+// address 256 MB << list_shift (up to 4 GB); payload 65536 + o is then the record at arena[(kListUnit << list_shift) * o].
+static const int kListShiftMax = 4;
+#define LMAT_LIST_OFF(pay, shift) ((size_t)kListUnit * ((size_t)((pay) - kListBase) << (shift)))
 static const uint16_t kListNegFirst = 1;
 
 // per-taxid flags (internal index space)

@@ -54,6 +54,7 @@ struct DeviceTables {
     uint32_t* conv = nullptr;  // [65536] 16 -> 32, lookup API only
     uint32_t n_ids = 0;
     int k = 0;
+    uint32_t list_shift = 0;   // list records lie on (16 << list_shift)-byte boundaries (lmat_common.hpp)
 };
 
 // Null models on the device (loadRandHits, src/read_label.cpp:512-678).  One table per k-mer-count class

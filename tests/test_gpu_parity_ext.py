@@ -262,6 +262,23 @@ def test_full_size_sample_parity(tmp_path, gb, n_reads, lens):
     kms = np.unique(np.concatenate([orc.extract(bytes(blob[int(off[i]):int(off[i + 1])]), 20)[0] for i in range(ns)]))
     cnts, tids = eng.lookup(kms, stride=32)
     assert (cnts > 0).mean() > 0.5 and 4 < cnts.max() <= 17  # strains + species + genus of a genus-block k-mer
+    # Table CONTENT at full size, against lists derived on the host from the generator's own functions (lmat_synth_window), not
+    # from the table: 3000 random ancestor windows, a third of them inside the genus-shared blocks.  The table must return the
+    # window's list; where another window yields the same 20-mer the smaller payload won (about 1 % at 6.4 G k-mers).
+    rng = np.random.default_rng(17)
+    blk = Glen * 100 // 1000
+    wk, wl = [], []
+    for i in range(3000):
+        sp = int(rng.integers(0, 768))
+        pos = int(rng.integers(0, blk - 20)) if i % 3 == 0 else int(rng.integers(blk, Glen - 20))
+        km, lst = eng.synth_window(sp, pos)
+        if lst:
+            wk.append(km)
+            wl.append(sorted(lst))
+    wc, wt = eng.lookup(np.array(wk, dtype=np.uint64), stride=32)
+    same = sum(sorted(wt[i, :wc[i]].tolist()) == wl[i] for i in range(len(wk)))
+    assert (wc > 0).all() and same >= 0.97 * len(wk) and len(wk) > 2500, (same, len(wk))
+    assert max(len(l) for l in wl) >= 9 and sum(len(l) == 1 for l in wl) > 100   # genus-spanning lists and lone strains both occur
     orc.add_lists32(kms, cnts, tids)
     want, _, _ = orc.classify(np.append(blob, np.uint8(0)), off, 20)
     got = eng.format_out(res[:ns], cands, (np.append(blob, np.uint8(0)), off))
@@ -911,6 +928,14 @@ def test_general_decision_path_gives_the_same_answers():
     the text-parity, capacity and fuzz tests must not notice."""
     _child_run("LMAT_K4_WAVE", "0", ["test_gpu_parity_ext.py", "test_gpu_parity.py", "test_gpu_fuzz.py"],
                "text_parity or out_text or parameter_variants or overflow_rerun or many_distinct or degenerate or long_reads or random_configuration or label_modes or example")
+
+
+def test_list_records_on_wider_boundaries_give_the_same_answers():
+    """LMAT_LIST_SHIFT=2: list records on 64-byte instead of 16-byte boundaries, which is how the 24-bit payloads address an
+    arena of 1 GB instead of 256 MB (up to 4 GB at shift 4).  Taxid lists, gene lists and the lookup API read records through the
+    same offset rule: the parity tests must not notice."""
+    _child_run("LMAT_LIST_SHIFT", "2", ["test_gpu_parity_ext.py", "test_gpu_parity.py", "test_gene_label.py"],
+               "config1_text_parity or out_text or lookup or many_distinct or parameter_variants or gene or sorteddb or build_options")
 
 
 def test_wide_table_format_gives_the_same_answers():
