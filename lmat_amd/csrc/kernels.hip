@@ -1480,8 +1480,12 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         const uint64_t sp = cpt_mix(best >> 4, cm);
         const int lb = tb.cpt.lowbits;
         const uint32_t hi = (uint32_t)(sp >> lb), low = (uint32_t)sp & ((1u << lb) - 1);
-        const uint32_t b = (uint32_t)(((double)hi + 0.5) * tb.cpt.invW);
-        const uint32_t rho = hi - b * tb.cpt.W;
+        // hi / W and hi mod W: a shift and a mask for the usual table sizes (W = 1, 2, 4, 8: 256 ... 32 GiB at k = 20), else the exact
+        // double multiply of cpt_address (a 64-bit-float multiply and a 32-bit integer multiply are several issue slots each)
+        const int wsh = tb.cpt.wshift;
+        uint32_t b, rho;
+        if (wsh >= 0) { b = hi >> wsh; rho = hi & ((1u << wsh) - 1u); }
+        else { b = (uint32_t)(((double)hi + 0.5) * tb.cpt.invW); rho = hi - b * tb.cpt.W; }
         const int rs = 2 * (kCptW - 1 - (int)j);
         const uint32_t other = (uint32_t)((km >> (2 * cm + rs)) << rs) | ((uint32_t)km & ((1u << rs) - 1));
         b_out = b;

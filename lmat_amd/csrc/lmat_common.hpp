@@ -84,6 +84,7 @@ struct CptGeom {
     uint32_t W = 0;        // bucket width in hi-space
     double invW = 0;       // 1.0 / W
     int k = 0, m = 0, lowbits = 0;
+    int wshift = -1;       // log2(W) when W is a power of two (the classify kernel then shifts instead of multiplying in double), else -1
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -131,6 +132,7 @@ LM_HD CptGeom cpt_geometry(int k, uint64_t want_buckets) {
     if (W > wmax) W = wmax;
     const uint64_t nb = (space + W - 1) / W;
     g.nb = nb; g.W = (uint32_t)W; g.invW = 1.0 / (double)W; g.k = k; g.m = m; g.lowbits = lowbits;
+    g.wshift = (W & (W - 1)) == 0 ? 63 - __builtin_clzll(W) : -1;
     return g;
 }
 

