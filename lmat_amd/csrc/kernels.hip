@@ -918,6 +918,15 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t x) {
     x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
     return rl(x, 63);
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return rl(x, 63);
+}
 __device__ __forceinline__ uint64_t below_mask(int p) { return p <= 0 ? 0ull : (p >= 64 ? ~0ull : ((1ull << p) - 1)); }  // bits < p
 
 typedef const ClassifyArgs __attribute__((address_space(4))) CArgsK4;
@@ -944,13 +953,16 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         return true;
     };
     if (stop == 30) return placeholder();
-    if (cand - 1u > 998u || nT - 1u > 63u) return false;   // cand in 1..999, 1..64 taxids
+    if (cand - 1u > 998u || nT - 1u > 63u || !Ap->tb.depth_consistent) return false;   // cand in 1..999, 1..64 taxids, depths that grow along every branch
+    if (Ap->cands && !Ap->prm.prn_all) return false;  // candidates wanted, but without -p: a multi match prints the lineage as built (:917-927) -- the general path's job (bin/run_rl.sh always passes -p)
     const bool act = (uint32_t)lane < nT;
     const uint32_t dep = act ? (fz.w & 0xFFFFu) : 0u, fl = act ? (fz.w >> 16) : 0u;
     if (bal(my_cnt > cand || dep > 0x7FFFu || (hbias != 0.0f && (fl & kFlagHuman)))) return false;  // (a bias of 0 adds 0 * stdev: nothing)
-    float* xs = (float*)xch;      // [64] scores by slot, then squared deviations
-    uint32_t* xk = xch + 64;      // [64] sort keys by array position
-    uint32_t* xx = xch + 128;     // [128] exchange buffer of a partition step
+    float* xs = (float*)xch;      // [64] scores by slot (stay: a registered ancestor's score is read from here)
+    uint32_t* xk = xch + 64;      // [64] sort keys by array position; later the taxid of every sorted position
+    uint32_t* xx = xch + 128;     // [128] exchange buffer of a partition step; later the Euler intervals by sorted position
+    float* xv = (float*)(xch + 256);  // [64] squared deviations
+    uint32_t* xp = xch + 320;     // [64] taxid by sorted position: parked here, fetched where needed (the kernel has 64 registers)
     const float fcand = (float)cand;
     const float sc = (float)my_cnt / fcand;   // lanes >= nT: 0
     xs[lane] = sc;
@@ -1018,35 +1030,35 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     // ---- statistics (read_label.cpp:803-880): sums in registration order; a zero score adds +0.0, so pos_log_sum == log_sum
     float log_sum = 0.0f;
     uint32_t rank = 0;
-    for (uint32_t t = 0; t < nT; t += 4) {
-        const f32x4 q = *(const f32x4*)(xs + t);
-        const u32x4 kq = *(const u32x4*)(xk + t);
-        log_sum += q.x; log_sum += q.y; log_sum += q.z; log_sum += q.w;
+    for (uint32_t t = 0; t < nT; t += 2) {   // (two per step: the kernel has no registers to spare for four)
+        const u32x2 q = *(const u32x2*)((const uint32_t*)xs + t), kq = *(const u32x2*)(xk + t);
+        log_sum += __uint_as_float(q.x); log_sum += __uint_as_float(q.y);
         rank += (kq.x < keyr ? 1u : 0u) + (kq.y < keyr ? 1u : 0u);
-        rank += (kq.z < keyr ? 1u : 0u) + (kq.w < keyr ? 1u : 0u);
     }
     const uint32_t pos_sig_hits = (uint32_t)popc64(bal(my_cnt > 0));
     const uint32_t use_sig_hits = pos_sig_hits > 3 ? pos_sig_hits : nT;
     const float log_avg = log_sum / (float)use_sig_hits;
     const float dv = log_avg - sc;
-    WSYNC();
-    xs[lane] = act && (pos_sig_hits > 3 ? my_cnt > 0 : true) ? dv * dv : 0.0f;
+    xv[lane] = act && (pos_sig_hits > 3 ? my_cnt > 0 : true) ? dv * dv : 0.0f;
     // sorted-position space: lane i holds the candidate at position i of the sorted array (ascending; best = nT - 1)
     const uint32_t es = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)e);  // lanes >= nT rank nT and collide there: unused
-    const uint32_t pslot4 = (es & 63u) << 2, pdep = (es >> 6) & 0x7FFFu;
+    const uint32_t pslot4 = (es & 63u) << 2;
+#define PDEP ((es >> 6) & 0x7FFFu)   /* depth of the candidate at this position (recomputed where used: one register fewer) */
     const uint32_t piv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)fz.z);
-    const uint32_t pfl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)fz.w) >> 16;
-    const uint32_t ptid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)my_id);
+    xp[lane] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)my_id);
+#define PTID_AT(pos) (xp[pos])   /* uniform position: an LDS broadcast */
     const float pscore = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)__float_as_uint(sc)));
     const float top_score = __uint_as_float(rl(__float_as_uint(pscore), (int)nT - 1));  // the largest count sorts last
+    // top-scoring plasmids by position (:301-304), taken now: the flags are not needed again
+    const uint64_t PLtop = bal(((uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)fz.w) >> 16) & kFlagPlasmid) & bal(pscore >= top_score) & below_mask((int)nT);
     WSYNC();
     float log_std = 0.0f;
     for (uint32_t t = 0; t < nT; t += 4) {
-        const f32x4 q = *(const f32x4*)(xs + t);
+        const f32x4 q = *(const f32x4*)(xv + t);
         log_std += q.x; log_std += q.y; log_std += q.z; log_std += q.w;
     }
     const float stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0.0f;
-    if (stop == 31) { if (stdev1 == -1.0f || top_score == -1.0f || ptid + pfl + piv == 0xFFFFFFFFu) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
+    if (stop == 31) { if (stdev1 == -1.0f || top_score == -1.0f || piv == 0xFFFFFFFFu || PLtop == 5) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
     lmat_read_result res;
     res.status = LMAT_ST_CALL; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = (uint16_t)cand; res.valid_kmers = valid_kmers;
     res.read_len = (int)len; res.log_avg = log_avg; res.stdev = stdev1; res.call_tid = 0; res.call_score = 0; res.cand_off = 0; res.n_cand = 0;
@@ -1067,92 +1079,76 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         const float diff_thresh = stdev1 * sdiff;
         const uint32_t ti = piv & 0xFFFFu, oi = piv >> 16;
         // ---- findReadLabelVer2, lineage building (:295-325): candidates from the best down; the first one that does not fit
-        //      the lineage so far (addToCandLineage :225-262: equal depths, or the shallower one not an ancestor of the deeper) ends it
-        uint64_t F = 0, ACC = 0;
-        int lidx = -1, low_pos = -1, high_pos = -1;
-        uint32_t low_dep = 0, high_dep = 0;
-        for (int j = (int)nT - 1; j >= 0; --j) {
-            if ((F >> j) & 1ull) { lidx = j; break; }
-            ACC |= 1ull << j;
-            const uint32_t dj = rl(pdep, j), ivj = rl(piv, j);
-            const uint32_t tj = ivj & 0xFFFFu, oj = ivj >> 16;
-            const uint64_t fits = (bal(ti < tj) & bal(oj <= oi) & bal(pdep < dj)) | (bal(tj < ti) & bal(oi <= oj) & bal(pdep > dj));
-            F |= ~fits & below_mask(j);
-            if (j == (int)nT - 1 || dj > low_dep) { low_pos = j; low_dep = dj; }
-            if (j == (int)nT - 1 || dj < high_dep) { high_pos = j; high_dep = dj; }
+        //      the lineage so far (addToCandLineage :225-262: equal depths, or the shallower one not an ancestor of the deeper) ends it.
+        //      Every candidate above the first misfit was taken, so the lineage is "all positions above lidx" with
+        //      lidx = the highest position that misfits ANY higher one: no sequential walk, one pass over all pairs.  Where every
+        //      node lies deeper (in the -e file) than its parent -- checked once per taxonomy, else the general path takes the read --
+        //      a candidate fits a member iff the two are related, i.e. their Euler intervals [tin, tout] (tout = the largest tin
+        //      below; tins are unique) intersect: max(tin) <= min(tout).  Per member j: a max, a min, a compare, and the highest
+        //      misfitting j kept per lane -- operands as LDS broadcasts, nothing on the scalar unit.
+        uint32_t* xt = xx;
+        uint32_t* xo = xx + 64;
+        xt[lane] = act ? ti : 0u;          // spare positions relate to everything
+        xo[lane] = act ? oi : 0xFFFFu;
+        WSYNC();
+        uint32_t mis = 0;  // highest position this candidate does not fit (0: none -- position 0 is above nobody)
+        for (uint32_t j = 0; j < nT; j += 2) {   // (two members per step: four would need eight more registers than the kernel has)
+            const u32x2 tq = *(const u32x2*)(xt + j), oq = *(const u32x2*)(xo + j);
+            mis = max(mis, max(ti, tq.x) > min(oi, oq.x) ? j : 0u);
+            mis = max(mis, max(ti, tq.y) > min(oi, oq.y) ? j + 1u : 0u);
         }
-        if (stop == 32) { if (lidx == 77 || low_pos == 99 || high_dep == 0xFFFFFFu) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
+        const uint64_t am_ = below_mask((int)nT);
+        const uint64_t F = bal(mis > (uint32_t)lane) & am_;
+        const int lidx = F ? 63 - __builtin_clzll(F) : -1;
+        const uint64_t ACC = am_ & ~below_mask(lidx + 1);
+        // deepest and shallowest member (:316-321; depths within a lineage are all different)
+        const bool accd_ = lane_bit(ACC);
+        const uint32_t kmax = wave_max_u32(accd_ ? (PDEP << 6) | (uint32_t)lane : 0u);
+        const uint32_t kmin = wave_max_u32(accd_ ? ((0x7FFFu - PDEP) << 6) | (uint32_t)lane : 0u);
+        const int low_pos = (int)(kmax & 63u), high_pos = (int)(kmin & 63u);
+        const uint32_t high_dep = 0x7FFFu - (kmin >> 6);
+        if (stop == 32) { if (lidx == 77 || low_pos == 99 || high_dep == 0xFFFFFFu || high_pos == 99) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
         // the top-scoring plasmid the loop meets last (:301-304, 324): it runs on below lidx while the scores stay at the top
         int plasmid_pos = -1;
-        {
-            const uint64_t am = below_mask((int)nT);
-            const uint64_t GEm = bal(pscore >= top_score) & am, PLm = bal((pfl & kFlagPlasmid) != 0) & am;
-            if (PLm) {
-                const uint64_t Z = ~GEm & below_mask(lidx + 1);
-                const uint64_t seen = Z ? ~below_mask(64 - __builtin_clzll(Z)) : ~0ull;  // above the first position at or below lidx that is under the top score
-                const uint64_t c = GEm & PLm & seen;
-                if (c) plasmid_pos = __builtin_ctzll(c);
-            }
+        if (PLtop) {
+            const uint64_t Z = ~bal(pscore >= top_score) & below_mask(lidx + 1);
+            const uint64_t seen = Z ? ~below_mask(64 - __builtin_clzll(Z)) : ~0ull;  // above the first position at or below lidx that is under the top score
+            const uint64_t c = PLtop & seen;
+            if (c) plasmid_pos = __builtin_ctzll(c);
         }
         uint8_t match = LMAT_MT_DIRECT;
-        uint32_t call_tid = rl(ptid, low_pos), call_iv = rl(piv, low_pos);  // nothing poisoned: the deepest accepted candidate (:366-369)
+        uint32_t call_tid = PTID_AT(low_pos), call_iv = rl(piv, low_pos);  // nothing poisoned: the deepest accepted candidate (:366-369)
         float call_score = __uint_as_float(rl(__float_as_uint(pscore), low_pos));
-        const bool want_lin = Ap->cands && !Ap->prm.prn_all;
-        uint32_t nlin = 0, b_tid = 0, b_sc = 0;
-        if (lidx >= 0 || want_lin) {
-            // ---- the lineage: accepted candidates in the order taken, then the ancestors of the shallowest one (:326-343)
+        uint32_t nlin = 0;
+        if (lidx >= 0) {
+            // ---- the lineage (:326-351), sorted by depth (CmpDepth :159-167): the accepted candidates.  Two cases leave this path
+            //      for the general one: the shallowest member is not at depth 0, so its ancestors would join the lineage (:326-343;
+            //      the root is registered with every closure, so this takes -s or an unusual depth file).
+            //      Entry r of the sorted lineage goes to lane r: interval, score, taxid | registered << 16 | present << 17.
+            if (high_dep != 0) return false;
             const uint32_t nacc = (uint32_t)popc64(ACC);
-            const uint32_t aidx4 = (lane_bit(ACC) ? nacc - prefix_count(ACC) - 1u : 63u) << 2;  // entry index = accepted positions above; others push to lane 63, an entry only when all 64 are
-            b_tid = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)ptid);
-            uint32_t b_dep = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)pdep);
-            uint32_t b_iv = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)piv);
-            b_sc = (uint32_t)__builtin_amdgcn_ds_permute((int)aidx4, (int)__float_as_uint(pscore));
-            bool b_regd = (uint32_t)lane < nacc;  // member of all_cand_set
             nlin = nacc;
-            const uint32_t high_iv = rl(piv, high_pos);
-            const bool have_add = high_dep != 0;
-            if (have_add) {
-                const int high_slot = (int)(rl(es, high_pos) & 63u);
-                const uint32_t aoff = rl(fz.x, high_slot), alen = rl(fz.y, high_slot) & 0xFFFFu;
-                if (nacc + alen > 64u) return false;  // a lineage entry per lane: longer chains take the general path
-                const GAS uint64_t* g_paths8 = (const GAS uint64_t*)Ap->tb.paths8;
-                const bool mine = (uint32_t)lane >= nacc && (uint32_t)lane < nacc + alen;
-                int sl = 0;
-                if (mine) {
-                    const uint64_t pe = g_paths8[aoff + ((uint32_t)lane - nacc)];
-                    b_tid = (uint32_t)(pe & 0xFFFFu); b_dep = (uint32_t)(pe >> 16) & 0xFFFFu; b_iv = (uint32_t)(pe >> 32);
-                    sl = tid_slot(hent, THM, b_tid);
-                    b_regd = sl >= 0;
-                    b_sc = __float_as_uint(-10000.0f);
-                }
-                // score of a registered ancestor: its slot's (another lane's) score, before any bias (:821)
-                const uint32_t s2 = (uint32_t)__builtin_amdgcn_ds_bpermute((sl < 0 ? 0 : sl) << 2, (int)__float_as_uint(sc));
-                if (mine && b_regd) b_sc = s2;
-                nlin = nacc + alen;
-            }
-            const uint64_t lm = below_mask((int)nlin);
-            // depth order (CmpDepth :159-167, :344-351): defined by the comparator alone only when no two depths are equal --
-            // then every rank is taken exactly once; a rank nobody pushed to reads back 0 from ds_permute
+            const bool accd = lane_bit(ACC);
+            const uint32_t dkey = PDEP + 1u;
             WSYNC();
-            xk[lane] = lane_bit(lm) ? b_dep + 1u : 0u;
+            xk[lane] = accd ? dkey : 0u;
             WSYNC();
             uint32_t drank = 0;
-            for (uint32_t t = 0; t < nlin; t += 4) {
-                const u32x4 q = *(const u32x4*)(xk + t);
-                drank += (q.x > b_dep + 1u ? 1u : 0u) + (q.y > b_dep + 1u ? 1u : 0u);
-                drank += (q.z > b_dep + 1u ? 1u : 0u) + (q.w > b_dep + 1u ? 1u : 0u);
+            for (uint32_t t = 0; t < nT; t += 2) {
+                const u32x2 q = *(const u32x2*)(xk + t);
+                drank += (q.x > dkey ? 1u : 0u) + (q.y > dkey ? 1u : 0u);
             }
-            const int to_lane = (int)((lane_bit(lm) ? drank : 63u) << 2);  // (ds_permute wraps modulo 64: spare lanes push to lane 63, an entry only when all 64 are)
-            const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)b_iv);
-            const uint32_t d_sc = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)b_sc);
-            const uint32_t d_tid = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)(b_tid | (b_regd ? 0x10000u : 0u) | 0x20000u));
+            const int to_lane = (int)((accd ? drank : 63u) << 2);  // (ds_permute wraps modulo 64: the others push to lane 63, an entry only when all 64 are)
+            const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)piv);
+            const uint32_t d_sc = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)__float_as_uint(pscore));
+            const uint32_t d_tid = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)(xp[lane] | 0x30000u));
+            const uint64_t lm = below_mask((int)nlin);
             if (bal(!(d_tid & 0x20000u)) & lm) return false;  // two entries of one depth: the general path replays std::sort on them
             // ---- competitors (:355-362, cmpCompLineage :264-282): candidates from lidx down that are not ancestors of the
             //      shallowest lineage member, each against the lineage from its deepest entry up
             uint64_t NG = 0;
             if (lidx >= 0) {
-                const uint32_t htin = high_iv & 0xFFFFu, htout = high_iv >> 16;
-                const uint64_t comp = below_mask(lidx + 1) & ~(have_add ? bal(ti < htin) & bal(htout <= oi) : 0ull);
+                const uint64_t comp = below_mask(lidx + 1);  // (no ancestors were added: nobody to leave out, :356)
                 uint64_t active = comp, big = 0;
                 uint32_t mlo = 0, mhi = 0;
                 for (uint32_t j = 0; j < nlin && active; ++j) {
@@ -1199,7 +1195,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         if (stop == 33) { if (call_tid == 0xFFFFFFu && call_score == -5.0f) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
         if (plasmid_pos >= 0 && match != LMAT_MT_LCA_ERROR) {  // :410-416
             const uint32_t piv_p = rl(piv, plasmid_pos);
-            if ((call_iv & 0xFFFFu) < (piv_p & 0xFFFFu) && (piv_p >> 16) <= (call_iv >> 16)) call_tid = rl(ptid, plasmid_pos);
+            if ((call_iv & 0xFFFFu) < (piv_p & 0xFFFFu) && (piv_p >> 16) <= (call_iv >> 16)) call_tid = PTID_AT(plasmid_pos);
         }
         const GAS uint32_t* g_tid32 = (const GAS uint32_t*)Ap->tb.tid32;
         res.match_type = match;
@@ -1209,8 +1205,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         // ---- candidates (:898-927): with -p all of them, best first; else, for a multi match, the lineage as built
         if (Ap->cands) {
             GAS uint32_t* g_cursor = (GAS uint32_t*)Ap->cursor;
-            const bool prn_all = Ap->prm.prn_all != 0;
-            const uint32_t reserve = prn_all ? nT : nlin;
+            const uint32_t reserve = nT;   // (-p: every candidate, best first)
             uint32_t coff = 0;
             if (lane == 0) coff = G_ADD(&g_cursor[0], reserve);
             coff = (uint32_t)__builtin_amdgcn_readfirstlane((int)coff);
@@ -1218,13 +1213,8 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
             if ((uint64_t)coff + reserve <= Ap->cand_cap) co = (GAS uint64_t*)((GAS lmat_cand*)Ap->cands + coff);
             else if (lane == 0) G_OR((GAS uint32_t*)Ap->err, (uint32_t)kErrCandOverflow);
             res.cand_off = coff;
-            if (prn_all) {
-                if (co && act) co[nT - 1u - (uint32_t)lane] = (uint64_t)g_tid32[ptid] | ((uint64_t)__float_as_uint(pscore) << 32);
-                if (co) res.n_cand = nT;
-            } else {
-                if (co && (uint32_t)lane < nlin) co[lane] = (uint64_t)g_tid32[b_tid] | ((uint64_t)b_sc << 32);
-                if (co && (match == LMAT_MT_MULTI || match == LMAT_MT_PARTIAL)) res.n_cand = nlin;
-            }
+            if (co && act) co[nT - 1u - (uint32_t)lane] = (uint64_t)g_tid32[xp[lane]] | ((uint64_t)__float_as_uint(pscore) << 32);
+            if (co) res.n_cand = nT;
         }
     }
     if (lane == 0) {
@@ -1242,6 +1232,8 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         }
     }
     return true;
+#undef PDEP
+#undef PTID_AT
 }
 
 #define WSYNC_WAVE WSYNC
@@ -1334,13 +1326,17 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     GAS double* tally_score = (GAS double*)(tally_count + tb.n_ids);
     GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + tb.n_ids);
     auto emit = [&](uint32_t status, uint32_t cand_cnt) {
+        // The record's words are built on a zero the compiler cannot see through: a word that is a compile-time constant at a call
+        // site (status | match << 8 | 0 << 16, the zero fields) would otherwise be kept in a register of its own across the whole
+        // read loop -- six call sites: ten registers of a kernel that has 64 -- and spilled once the decision step moved in.
         uint32_t z = 0;
-        asm volatile("" : "+v"(z));  // keeps the constant words from being hoisted out of the read loop (and spilled)
-        lmat_read_result q;
-        q.status = (uint8_t)status; q.match_type = LMAT_MT_NOMATCH; q.cand_kmer_cnt = (uint16_t)cand_cnt;
-        q.valid_kmers = valid_kmers; q.read_len = (int)len; q.log_avg = __uint_as_float(z); q.stdev = __uint_as_float(z);
-        q.call_tid = z; q.call_score = __uint_as_float(z); q.cand_off = z; q.n_cand = z; q.bin_sel = bin_sel;
-        store_result(out, q);
+        asm volatile("" : "+v"(z));
+        const uint32_t w0 = z + (status | ((uint32_t)LMAT_MT_NOMATCH << 8) | (cand_cnt << 16));  // status, match_type, cand_kmer_cnt
+        out[0] = (uint64_t)w0 | ((uint64_t)(uint32_t)valid_kmers << 32);     // valid_kmers
+        out[1] = (uint64_t)len | ((uint64_t)z << 32);                        // read_len, log_avg
+        out[2] = (uint64_t)z | ((uint64_t)z << 32);                          // stdev, call_tid
+        out[3] = (uint64_t)z | ((uint64_t)z << 32);                          // call_score, cand_off
+        out[4] = (uint64_t)z | ((uint64_t)(uint32_t)bin_sel << 32);          // n_cand, bin_sel
     };
 
     if ((int)len < k) {  // proc_line :1217-1223
@@ -2872,7 +2868,10 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #undef WSYNC
 #define WSYNC() wsync<(U > 2048)>()
 // resident waves per SIMD each class is compiled for: what its LDS footprint allows (and no more registers than that needs)
-constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? 8 : 5) : (U <= 256 ? (CPT ? 8 : 5) : (CPT ? 4 : 3)))); }
+#ifndef LMAT_FAST_WAVES
+#define LMAT_FAST_WAVES 8   // (A/B builds: -DLMAT_FAST_WAVES=7 compiles the fast classes for 7 waves per SIMD, 72 registers)
+#endif
+constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? LMAT_FAST_WAVES : 5) : (U <= 256 ? (CPT ? LMAT_FAST_WAVES : 5) : (CPT ? 4 : 3)))); }
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];

@@ -59,6 +59,9 @@ int upload_taxonomy(lmat_ctx* c) {
         if ((rc = dev_upload(c, &c->dev.facts16, f16))) return rc;
     }
     c->dev.n_ids = T.n + 1;
+    c->dev.depth_consistent = 1;
+    for (uint32_t i = 1; i <= T.n; ++i)
+        if (T.path_len[i] && T.fdepth[i] <= T.fdepth[T.paths[T.path_off[i]]]) { c->dev.depth_consistent = 0; break; }
     // tallies: u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     if (c->d_counts) { hipFree(c->d_counts); c->d_counts = nullptr; }
     if (c->d_counts_bak) { hipFree(c->d_counts_bak); c->d_counts_bak = nullptr; }

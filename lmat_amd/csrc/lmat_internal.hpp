@@ -55,6 +55,7 @@ struct DeviceTables {
     uint32_t n_ids = 0;
     int k = 0;
     uint32_t list_shift = 0;   // list records lie on (16 << list_shift)-byte boundaries (lmat_common.hpp)
+    uint32_t depth_consistent = 0;  // every node's -e depth is larger than its parent's: "fits the lineage" is then "related to every member"
 };
 
 // Null models on the device (loadRandHits, src/read_label.cpp:512-678).  One table per k-mer-count class

@@ -215,7 +215,8 @@ void build_euler_intervals(HostTaxonomy& T) {
     uint32_t clock = 0;
     std::vector<std::pair<uint16_t, size_t>> st;
     for (uint32_t r = 1; r <= n; ++r) {
-        if (is_child[r] || !has_child[r]) continue;  // roots that own a subtree
+        if (is_child[r]) continue;
+        if (!has_child[r]) continue;  // roots that own a subtree (lone nodes are numbered behind them, below)
         st.push_back(std::make_pair((uint16_t)r, (size_t)0));
         T.tin[r] = (uint16_t)clock++;
         while (!st.empty()) {
@@ -230,6 +231,10 @@ void build_euler_intervals(HostTaxonomy& T) {
             }
         }
     }
+    // a node without parent and children is a tree of its own: an interval of one tick that nothing else touches (every node's
+    // tin is then unique, and "related" is "the intervals intersect" without exceptions -- the decision step on the wave leans on it)
+    for (uint32_t r = 1; r <= n; ++r)
+        if (!is_child[r] && !has_child[r]) { T.tin[r] = T.tout[r] = (uint16_t)clock; ++clock; }
 }
 
 // One raw DB list -> arena record.  Restates the per-k-mer part of retrieve_kmer_labels
