@@ -942,7 +942,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     const float hbias = Ap->prm.hbias, sdiff = Ap->prm.sdiff;
     const int screen_phix = Ap->prm.screen_phix;
     const int stop = Ap->prm.stop_after;   // 30..33: timing experiments (the step ends early with a placeholder record)
-    if (Ap->nm.active || (stop != 0 && (stop < 30 || stop > 33))) return false;
+    if (Ap->nm.active || (stop != 0 && (stop < 30 || stop > 34))) return false;
     auto placeholder = [&]() {
         if (lane == 0) {
             lmat_read_result q;
@@ -952,7 +952,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         }
         return true;
     };
-    if (stop == 30) return placeholder();
+    if (stop == 30 || (stop == 34 && nT <= 16)) return placeholder();   // 34: only the reads with more than 16 taxids take the step
     if (cand - 1u > 998u || nT - 1u > 63u || !Ap->tb.depth_consistent) return false;   // cand in 1..999, 1..64 taxids, depths that grow along every branch
     if (Ap->cands && !Ap->prm.prn_all) return false;  // candidates wanted, but without -p: a multi match prints the lineage as built (:917-927) -- the general path's job (bin/run_rl.sh always passes -p)
     const bool act = (uint32_t)lane < nT;
@@ -1121,34 +1121,56 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         float call_score = __uint_as_float(rl(__float_as_uint(pscore), low_pos));
         uint32_t nlin = 0;
         if (lidx >= 0) {
-            // ---- the lineage (:326-351), sorted by depth (CmpDepth :159-167): the accepted candidates.  Two cases leave this path
-            //      for the general one: the shallowest member is not at depth 0, so its ancestors would join the lineage (:326-343;
-            //      the root is registered with every closure, so this takes -s or an unusual depth file).
-            //      Entry r of the sorted lineage goes to lane r: interval, score, taxid | registered << 16 | present << 17.
-            if (high_dep != 0) return false;
+            // ---- the lineage (:326-351): the accepted candidates and, when the shallowest of them is not at depth 0, its ancestors
+            //      (with their own scores where they are registered, -10000 where not, :326-343), sorted by depth (CmpDepth
+            //      :159-167).  Members sit in the lanes of their sorted positions, the ancestors in the spare lanes behind position
+            //      nT - 1; entry r of the sorted lineage goes to lane r: interval, score, taxid | registered << 16 | present << 17.
+            //      (The comparator alone defines the order only when no two depths are equal: then every rank is taken exactly
+            //      once, and a rank nobody pushed to reads back 0 from ds_permute.)
             const uint32_t nacc = (uint32_t)popc64(ACC);
+            const uint32_t high_iv = rl(piv, high_pos);
+            const bool have_add = high_dep != 0;
+            bool member = lane_bit(ACC);
+            uint32_t m_iv = piv, m_sc = __float_as_uint(pscore), m_tid = xp[lane] | 0x30000u, dkey = PDEP + 1u, nmem = nT;
             nlin = nacc;
-            const bool accd = lane_bit(ACC);
-            const uint32_t dkey = PDEP + 1u;
+            if (have_add) {
+                const u32x4 hf = ((const GAS u32x4*)Ap->tb.facts16)[PTID_AT(high_pos)];  // (fetched again rather than held in registers since the registration)
+                const uint32_t aoff = hf.x, alen = hf.y & 0xFFFFu;
+                if (nT + alen > 64u) return false;  // a lane per candidate and per ancestor: longer chains take the general path
+                const bool mine = (uint32_t)lane >= nT && (uint32_t)lane < nT + alen;
+                if (mine) {
+                    const uint64_t pe = ((const GAS uint64_t*)Ap->tb.paths8)[aoff + ((uint32_t)lane - nT)];
+                    const uint32_t a_ = (uint32_t)(pe & 0xFFFFu);
+                    const int sl = tid_slot(hent, THM, a_);
+                    m_tid = a_ | (sl >= 0 ? 0x30000u : 0x20000u);
+                    dkey = ((uint32_t)(pe >> 16) & 0xFFFFu) + 1u;
+                    m_iv = (uint32_t)(pe >> 32);
+                    m_sc = sl >= 0 ? __float_as_uint(xs[sl]) : __float_as_uint(-10000.0f);  // a registered ancestor's score is its slot's, before any bias (:821)
+                    member = true;
+                }
+                nmem = nT + alen;
+                nlin = nacc + alen;
+            }
             WSYNC();
-            xk[lane] = accd ? dkey : 0u;
+            xk[lane] = member ? dkey : 0u;
             WSYNC();
             uint32_t drank = 0;
-            for (uint32_t t = 0; t < nT; t += 2) {
+            for (uint32_t t = 0; t < nmem; t += 2) {
                 const u32x2 q = *(const u32x2*)(xk + t);
                 drank += (q.x > dkey ? 1u : 0u) + (q.y > dkey ? 1u : 0u);
             }
-            const int to_lane = (int)((accd ? drank : 63u) << 2);  // (ds_permute wraps modulo 64: the others push to lane 63, an entry only when all 64 are)
-            const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)piv);
-            const uint32_t d_sc = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)__float_as_uint(pscore));
-            const uint32_t d_tid = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)(xp[lane] | 0x30000u));
+            const int to_lane = (int)((member ? drank : 63u) << 2);  // (ds_permute wraps modulo 64: the others push to lane 63, an entry only when all 64 are)
+            const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_iv);
+            const uint32_t d_sc = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_sc);
+            const uint32_t d_tid = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_tid);
             const uint64_t lm = below_mask((int)nlin);
             if (bal(!(d_tid & 0x20000u)) & lm) return false;  // two entries of one depth: the general path replays std::sort on them
             // ---- competitors (:355-362, cmpCompLineage :264-282): candidates from lidx down that are not ancestors of the
             //      shallowest lineage member, each against the lineage from its deepest entry up
             uint64_t NG = 0;
             if (lidx >= 0) {
-                const uint64_t comp = below_mask(lidx + 1);  // (no ancestors were added: nobody to leave out, :356)
+                const uint32_t htin = high_iv & 0xFFFFu, htout = high_iv >> 16;
+                const uint64_t comp = below_mask(lidx + 1) & ~(have_add ? bal(ti < htin) & bal(htout <= oi) : 0ull);  // not the added ancestors themselves (:356)
                 uint64_t active = comp, big = 0;
                 uint32_t mlo = 0, mhi = 0;
                 for (uint32_t j = 0; j < nlin && active; ++j) {
@@ -1234,6 +1256,289 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     return true;
 #undef PDEP
 #undef PTID_AT
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 by rows: the same decision step as k4_wave for reads with at most 16 registered taxids (three in four), FOUR reads per
+// wave -- a read per row of 16 lanes, a taxid per lane.  The step is a few hundred instructions whatever the number of lanes
+// that take part, so on the classify wave (one read, 64 lanes) it cost a quarter of that kernel; here four reads share every
+// instruction.  Reads come from the hand-off records of the classify kernel (k4buf, status 251); everything k4_wave keeps on
+// the scalar unit (lane masks, positions, the loop limits of one read) is a per-row value in vector registers here, a "wave
+// ballot" is the row's 16 bits of it, a broadcast within the row is a ds_bpermute or an LDS read at a per-row address, and the
+// rows of a wave run their loops to the longest one's length with the shorter rows padded by neutral elements.  No partition
+// steps: std::sort is a plain insertion sort up to 16 elements, i.e. the stable rank of (count, depth).
+// A read outside k4_wave's preconditions goes on the bail list and is decided by the general path (k4_kernel, last launch).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t row_shr_max_i32(uint32_t x) {  // inclusive running maximum (signed) along a row of 16 lanes
+    auto mx = [](uint32_t a, uint32_t b) { return (int)a > (int)b ? a : b; };
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, false));
+    return x;
+}
+__device__ __forceinline__ uint32_t row_shr_or(uint32_t x) {  // lane 15 of a row ends up with the OR of the row
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    return x;
+}
+__device__ __forceinline__ uint32_t row_shr_max_u32(uint32_t x) {  // lane 15 of a row ends up with the row's maximum (unsigned)
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    return x;
+}
+__device__ __forceinline__ uint32_t low_bits(int p) { return p <= 0 ? 0u : (p >= 32 ? 0xFFFFFFFFu : ((1u << p) - 1u)); }  // bits < p
+
+__global__ __launch_bounds__(64) void k4_row_kernel(ClassifyArgs A) {
+    constexpr int G = 16;
+    __shared__ __align__(16) uint32_t sh[6 * 64];
+    float* xs = (float*)sh;        // scores by slot
+    uint32_t* xk = sh + 64;        // sort keys by slot; later the depth keys of the lineage members
+    uint32_t* xt = sh + 128;       // tin by sorted position; later the sorted lineage's intervals
+    uint32_t* xo = sh + 192;       // tout by sorted position; later the sorted lineage's scores
+    float* xv = (float*)(sh + 256);  // squared deviations
+    const int lane = threadIdx.x & 63, gbase = lane & ~(G - 1), li = lane & (G - 1);
+    auto rowbits = [&](bool p) -> uint32_t { return (uint32_t)(bal(p) >> gbase) & 0xFFFFu; };          // the row's 16 bits of a ballot
+    auto bp = [&](uint32_t x, int idx) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + idx) << 2, (int)x); };  // x of the row's lane idx
+    const GAS uint32_t* g_tid32 = (const GAS uint32_t*)A.tb.tid32;
+    const GAS u32x4* g_facts16 = (const GAS u32x4*)A.tb.facts16;
+    GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
+    GAS unsigned long long* tally_count = (GAS unsigned long long*)A.counts;
+    GAS double* tally_score = (GAS double*)(tally_count + A.tb.n_ids);
+    GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)(tally_score + A.tb.n_ids);
+    const uint64_t n = *(const GAS uint32_t*)(g_cursor + 9);
+    const GAS uint32_t* list = (const GAS uint32_t*)A.k4_row;
+    const float hbias = A.prm.hbias, sdiff = A.prm.sdiff;
+    for (uint64_t base = (uint64_t)blockIdx.x * (64 / G); base < n; base += (uint64_t)gridDim.x * (64 / G)) {
+        const uint64_t ri = base + (uint64_t)(lane / G);
+        const bool vrow = ri < n;
+        const uint64_t it = vrow ? (uint64_t)list[ri] : 0ull;
+        const GAS uint32_t* krec = (const GAS uint32_t*)A.k4buf + it * kK4RecWords;
+        const uint32_t hdr = vrow ? krec[0] : 0u;
+        const uint32_t nT_rec = hdr & 0xFFFFu, cand = hdr >> 16;
+        const uint32_t nT = nT_rec > (uint32_t)G ? 0u : nT_rec;  // (a longer table is not this kernel's: bailed out below, computed as empty)
+        const bool act = (uint32_t)li < nT;
+        const uint32_t w = act ? krec[2 + li] : 0u;
+        const uint32_t reg = w & 0xFFFFu, cnt = w >> 16;
+        const u32x4 f = g_facts16[reg];
+        const uint32_t dep = act ? (f.w & 0xFFFFu) : 0u, fl = act ? (f.w >> 16) : 0u;
+        bool bail = vrow && (cand - 1u > 998u || nT_rec - 1u > (uint32_t)(G - 1) ||
+                             rowbits(act && (cnt > cand || dep > 0x7FFFu || (hbias != 0.0f && (fl & kFlagHuman)))) != 0u);
+        const float fcand = (float)(cand ? cand : 1u);
+        const float sc = act ? (float)cnt / fcand : 0.0f;
+        const uint32_t e = act ? (((cnt << 15) | dep) << 6) | (uint32_t)li : 0xFFFFFFFFu;  // key << 6 | slot; the slot is the array position
+        WSYNC();  // (the previous turn's reads of the arrays are done)
+        xs[lane] = sc;
+        xk[lane] = e;
+        WSYNC();
+        const uint32_t nTmax = max(max(rl(nT, 0), rl(nT, 16)), max(rl(nT, 32), rl(nT, 48)));
+        // ---- statistics + the rank of the insertion sort, slots of shorter rows padded with +0.0 / the largest key
+        float log_sum = 0.0f;
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < nTmax; t += 2) {
+            const u32x2 q = *(const u32x2*)((const uint32_t*)xs + gbase + t), kq = *(const u32x2*)(xk + gbase + t);
+            log_sum += __uint_as_float(q.x); log_sum += __uint_as_float(q.y);
+            rank += (kq.x < e ? 1u : 0u) + (kq.y < e ? 1u : 0u);
+        }
+        const uint32_t pos_sig_hits = (uint32_t)__builtin_popcount(rowbits(cnt > 0));
+        const uint32_t use_sig_hits = pos_sig_hits > 3 ? pos_sig_hits : nT;
+        const float log_avg = log_sum / (float)(use_sig_hits ? use_sig_hits : 1u);
+        const float dv = log_avg - sc;
+        xv[lane] = act && (pos_sig_hits > 3 ? cnt > 0 : true) ? dv * dv : 0.0f;
+        // sorted-position space: lane i of the row holds the candidate at position i (ascending; best = nT - 1)
+        const uint32_t es = (uint32_t)__builtin_amdgcn_ds_permute((gbase + (int)rank) << 2, (int)e);  // spare lanes rank nT: a spare position of their own row
+        const int pslot = (int)(es & 63u);
+        const uint32_t pdep = (es >> 6) & 0x7FFFu;
+        const uint32_t piv = bp(f.z, pslot), pfl = bp(f.w >> 16, pslot), ptid = bp(reg, pslot);
+        const float pscore = __uint_as_float(bp(__float_as_uint(sc), pslot));
+        const float top_score = __uint_as_float(bp(__float_as_uint(pscore), (int)nT - 1));  // the largest count sorts last
+        const uint32_t am = low_bits((int)nT);
+        const uint32_t GEm = rowbits(act && pscore >= top_score);
+        const uint32_t PLtop = rowbits(act && (pfl & kFlagPlasmid)) & GEm;
+        WSYNC();
+        float log_std = 0.0f;
+        for (uint32_t t = 0; t < nTmax; t += 4) {
+            const f32x4 q = *(const f32x4*)(xv + gbase + t);
+            log_std += q.x; log_std += q.y; log_std += q.z; log_std += q.w;
+        }
+        const float stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0.0f;
+        const float diff_thresh = stdev1 * sdiff;
+        // ---- PhiX (:841-848): the score of the LAST registered PhiX id against the top score
+        const uint32_t PX = A.prm.screen_phix ? rowbits(act && (fl & kFlagPhiX)) : 0u;
+        const float phix_score = __uint_as_float(bp(__float_as_uint(sc), PX ? 31 - __builtin_clz(PX) : 0));
+        const bool phix = PX != 0u && phix_score >= top_score;
+        // ---- lineage building (:295-325) as in k4_wave: one pass over all pairs of the row
+        const uint32_t ti = piv & 0xFFFFu, oi = piv >> 16;
+        xt[lane] = act ? ti : 0u;          // spare positions relate to everything
+        xo[lane] = act ? oi : 0xFFFFu;
+        WSYNC();
+        uint32_t mis = 0;
+        for (uint32_t j = 0; j < nTmax; j += 2) {
+            const u32x2 tq = *(const u32x2*)(xt + gbase + j), oq = *(const u32x2*)(xo + gbase + j);
+            mis = max(mis, max(ti, tq.x) > min(oi, oq.x) ? j : 0u);
+            mis = max(mis, max(ti, tq.y) > min(oi, oq.y) ? j + 1u : 0u);
+        }
+        const uint32_t F = rowbits(mis > (uint32_t)li) & am;
+        const int lidx = F ? 31 - __builtin_clz(F) : -1;
+        const uint32_t ACC = am & ~low_bits(lidx + 1);
+        const bool accd = (ACC >> li) & 1u;
+        const uint32_t kmax = bp(row_shr_max_u32(accd ? (pdep << 6) | (uint32_t)li : 0u), 15);
+        const uint32_t kmin = bp(row_shr_max_u32(accd ? ((0x7FFFu - pdep) << 6) | (uint32_t)li : 0u), 15);
+        const int low_pos = (int)(kmax & 63u);
+        const uint32_t high_dep = 0x7FFFu - (kmin >> 6);
+        int plasmid_pos = -1;  // the top-scoring plasmid the reference's loop meets last (:301-304, 324)
+        {
+            const uint32_t Z = ~GEm & low_bits(lidx + 1);
+            const uint32_t seen = Z ? ~low_bits(32 - __builtin_clz(Z)) : 0xFFFFFFFFu;
+            const uint32_t c = PLtop & seen;
+            if (c) plasmid_pos = __builtin_ctz(c);
+        }
+        uint32_t match = LMAT_MT_DIRECT;
+        uint32_t call_tid = bp(ptid, low_pos), call_iv = bp(piv, low_pos);
+        float call_score = __uint_as_float(bp(__float_as_uint(pscore), low_pos));
+        // ---- competitors (:355-362, :264-282) of the rows that have any
+        const bool hascomp = vrow && !phix && lidx >= 0;
+        if (bal(hascomp)) {
+            // the lineage: accepted candidates + the ancestors of the shallowest one where it is not at depth 0 (:326-343), in the
+            // row's spare lanes behind position nT - 1 (a row has 16: a longer lineage is the general path's)
+            const uint32_t nacc = (uint32_t)__builtin_popcount(ACC);
+            const bool have_add = hascomp && high_dep != 0u;
+            const int high_pos = (int)(kmin & 63u);
+            const uint32_t high_iv = bp(piv, high_pos);
+            bool member = accd;
+            uint32_t m_iv = piv, m_sc = __float_as_uint(pscore), m_tid = ptid | 0x30000u, dkey = pdep + 1u, nlin = nacc;
+            if (bal(have_add)) {
+                const u32x4 hf = g_facts16[have_add ? bp(ptid, high_pos) : 0u];
+                const uint32_t aoff = hf.x, alen = have_add ? (hf.y & 0xFFFFu) : 0u;
+                const bool fits = nT + alen <= (uint32_t)G;
+                bail = bail || (have_add && !fits);
+                const bool mine = have_add && fits && (uint32_t)li >= nT && (uint32_t)li < nT + alen;
+                uint32_t a_ = 0;
+                if (mine) {
+                    const uint64_t pe = ((const GAS uint64_t*)A.tb.paths8)[aoff + ((uint32_t)li - nT)];
+                    a_ = (uint32_t)(pe & 0xFFFFu);
+                    dkey = ((uint32_t)(pe >> 16) & 0xFFFFu) + 1u;
+                    m_iv = (uint32_t)(pe >> 32);
+                    member = true;
+                }
+                // a registered ancestor scores as its candidate does (before any bias, :821): look the id up among the row's positions
+                uint32_t hit = 0xFFFFFFFFu;
+                for (uint32_t t = 0; t < nTmax; ++t) hit = (bp(ptid, (int)t) == a_ && t < nT) ? t : hit;
+                const uint32_t hs = bp(__float_as_uint(pscore), hit == 0xFFFFFFFFu ? 0 : (int)hit);
+                if (mine) { m_tid = a_ | (hit != 0xFFFFFFFFu ? 0x30000u : 0x20000u); m_sc = hit != 0xFFFFFFFFu ? hs : __float_as_uint(-10000.0f); }
+                nlin = nacc + (have_add && fits ? alen : 0u);
+            }
+            WSYNC();
+            xk[lane] = member ? dkey : 0u;
+            WSYNC();
+            uint32_t drank = 0;
+            for (uint32_t t = 0; t < (uint32_t)G; t += 2) {
+                const u32x2 q = *(const u32x2*)(xk + gbase + t);
+                drank += (q.x > dkey ? 1u : 0u) + (q.y > dkey ? 1u : 0u);
+            }
+            const int to_lane = (gbase + (int)(member ? drank : 15u)) << 2;  // the others push to the row's last lane, an entry only when all 16 are
+            const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_iv);
+            const uint32_t d_sc = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_sc);
+            const uint32_t d_tid = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_tid);
+            bail = bail || (hascomp && rowbits((uint32_t)li < nlin && !(d_tid & 0x20000u)) != 0u);  // two members of one depth
+            WSYNC();
+            xt[lane] = d_iv;   // the sorted lineage, entry by entry, for the walks below
+            xo[lane] = d_sc;
+            WSYNC();
+            const bool comp = hascomp && act && li <= lidx &&
+                              !(have_add && ti < (high_iv & 0xFFFFu) && (high_iv >> 16) <= oi);  // not the added ancestors themselves (:356)
+            bool active = comp, big = false;
+            uint32_t marks = 0;
+            const uint32_t nl = hascomp ? nlin : 0u;
+            const uint32_t nlmax = max(max(rl(nl, 0), rl(nl, 16)), max(rl(nl, 32), rl(nl, 48)));
+            for (uint32_t j = 0; j < nlmax && bal(active); ++j) {
+                const uint32_t ivj = xt[gbase + j];
+                const float ls = __uint_as_float(xo[gbase + j]);
+                const bool inr = j < nlin;
+                const bool anc = (ivj & 0xFFFFu) < ti && oi <= (ivj >> 16);  // the lineage entry is an ancestor of the competitor: the walk ends
+                const float d = ls - pscore;
+                const bool isbig = ls != -10000.0f && d > diff_thresh;
+                const bool go = active && inr && !anc && !isbig;
+                marks |= go && d <= diff_thresh ? 1u << j : 0u;
+                big = big || (active && inr && !anc && isbig);
+                active = go;
+            }
+            const uint32_t B = rowbits(big);
+            const bool counted = comp && (B ? li >= 31 - __builtin_clz(B) : true);  // the first competitor (from lidx down) beyond the threshold ends the scan
+            const uint32_t NG = hascomp ? bp(row_shr_or(counted ? marks : 0u), 15) : 0u;
+            if (NG) {  // :370-408
+                const uint32_t okm = ~NG & low_bits((int)nlin);
+                if (!okm) {
+                    match = LMAT_MT_LCA_ERROR;
+                    call_tid = 0; call_iv = 0xFFFFFFFFu; call_score = 0;
+                } else {
+                    const int root = __builtin_ctz(okm);
+                    float max_val = __uint_as_float(bp(row_shr_max_i32(d_sc), root));  // std::max over the entries up to the first good one
+                    const uint32_t rt = bp(d_tid, root);
+                    const float rs = __uint_as_float(bp(d_sc, root));
+                    match = LMAT_MT_MULTI;
+                    if ((rt & 0x10000u) && max_val < rs) { match = LMAT_MT_PARTIAL; max_val = rs; }
+                    call_tid = rt & 0xFFFFu;
+                    call_iv = bp(d_iv, root);
+                    call_score = max_val;
+                }
+            }
+        }
+        if (plasmid_pos >= 0 && match != LMAT_MT_LCA_ERROR) {  // :410-416
+            const uint32_t piv_p = bp(piv, plasmid_pos < 0 ? 0 : plasmid_pos);
+            if ((call_iv & 0xFFFFu) < (piv_p & 0xFFFFu) && (piv_p >> 16) <= (call_iv >> 16)) call_tid = bp(ptid, plasmid_pos);
+        }
+        // ---- candidates (-p: all of them, best first), the record, the tallies
+        const bool done = vrow && !bail;
+        uint32_t coff = 0, ncand = 0;
+        if (A.cands && bal(done && !phix)) {
+            uint32_t c0 = 0;
+            if (done && !phix && li == 0) c0 = G_ADD(&g_cursor[0], nT);
+            coff = bp(c0, 0);
+            const bool room = (uint64_t)coff + nT <= A.cand_cap;
+            if (done && !phix && !room && li == 0) G_OR((GAS uint32_t*)A.err, (uint32_t)kErrCandOverflow);
+            if (done && !phix && room && act)
+                ((GAS uint64_t*)((GAS lmat_cand*)A.cands + coff))[nT - 1u - (uint32_t)li] = (uint64_t)g_tid32[ptid] | ((uint64_t)__float_as_uint(pscore) << 32);
+            if (room) ncand = nT;
+        }
+        if (vrow && li == 0) {
+            GAS uint64_t* out = (GAS uint64_t*)(A.results + it);
+            if (bail) {  // the general path takes the read: its record says "pending, small table" again
+                *(GAS uint8_t*)out = 254;
+                ((GAS uint32_t*)A.k4_bail)[G_ADD(&g_cursor[6], 1u)] = (uint32_t)it;
+            } else {
+                lmat_read_result res;
+                uint64_t wv[5];
+                wv[0] = out[0]; wv[1] = out[1]; wv[2] = out[2]; wv[3] = out[3]; wv[4] = out[4];
+                __builtin_memcpy(&res, wv, 40);   // valid_kmers, read_len, bin_sel as the classify kernel left them
+                res.cand_kmer_cnt = (uint16_t)cand;
+                uint32_t call_idx;
+                if (phix) {
+                    res.status = LMAT_ST_PHIX; res.match_type = LMAT_MT_DIRECT; res.call_tid = 32630; res.call_score = phix_score;
+                    res.log_avg = 0; res.stdev = 0; res.cand_off = 0; res.n_cand = 0;
+                    call_idx = A.phix_call_idx;
+                } else {
+                    res.status = LMAT_ST_CALL; res.match_type = (uint8_t)match; res.log_avg = log_avg; res.stdev = stdev1;
+                    res.call_tid = call_tid ? g_tid32[call_tid] : 0u; res.call_score = call_score;
+                    res.cand_off = coff; res.n_cand = ncand;
+                    call_idx = call_tid;
+                }
+                store_result(out, res);
+                if (res.status != LMAT_ST_PHIX && res.match_type == LMAT_MT_NOMATCH) {  // tallies, proc_line :1241-1268
+                    G_ADD(&tally_nomatch[1], 1ull);
+                } else if (res.call_score >= A.prm.min_score) {
+                    G_ADD(&tally_count[call_idx], 1ull);
+                    G_ADD(&tally_score[call_idx], (double)res.call_score);
+                } else if (res.call_score < A.prm.min_score) {
+                    G_ADD(&tally_nomatch[2], 1ull);
+                }
+            }
+        }
+    }
 }
 
 #define WSYNC_WAVE WSYNC
@@ -2443,15 +2748,21 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
             return;
         }
-        if constexpr (!INK4) {  // the decision on the wave itself, when the read qualifies (k4_wave); else the hand-off below
-            const uint32_t my_cnt = (uint32_t)lane < nT ? (uint32_t)cnt[lane] : 0u, my_id = (uint32_t)lane < nT ? (uint32_t)reg[lane] : 0u;
-            if (k4_wave<THM>(Ap, lane, nT, cand, fz, my_cnt, my_id, hent, (uint32_t*)(lds + L::OFF_R3), out, valid_kmers, len, bin_sel)) return;
+        // Where the decision is made: tables of up to 16 taxids go to k4_row_kernel, four reads to a wave (status 251); larger ones
+        // are decided right here on the wave (k4_wave) when the read qualifies; everything else -- null models, an effective human
+        // bias, -y style experiments, more than 999 candidate k-mers ... -- takes the general path, by table size.
+        const bool rows = A.prm.k4_row && nT <= 16u && !A.nm.active && A.prm.stop_after == 0 && tb.depth_consistent && !(A.cands && !A.prm.prn_all);
+        if constexpr (!INK4) {
+            if (!rows) {
+                const uint32_t my_cnt = (uint32_t)lane < nT ? (uint32_t)cnt[lane] : 0u, my_id = (uint32_t)lane < nT ? (uint32_t)reg[lane] : 0u;
+                if (k4_wave<THM>(Ap, lane, nT, cand, fz, my_cnt, my_id, hent, (uint32_t*)(lds + L::OFF_R3), out, valid_kmers, len, bin_sel)) return;
+            }
         }
         GAS uint32_t* krec = (GAS uint32_t*)A.k4buf + (r - A.result_base) * kK4RecWords;
         if (lane < (int)nT) krec[2 + lane] = (uint32_t)reg[lane] | ((uint32_t)cnt[lane] << 16);
         if (lane == 0) {
             krec[0] = nT | (cand << 16);
-            emit(A.nm.active ? 253u : (nT <= (uint32_t)kK4SmallT ? 254u : (nT <= (uint32_t)kK4MidT ? 252u : 253u)), cand);  // pending K4, by table size
+            emit(rows ? 251u : (A.nm.active ? 253u : (nT <= (uint32_t)kK4SmallT ? 254u : (nT <= (uint32_t)kK4MidT ? 252u : 253u))), cand);  // pending K4
         }
         return;
     }
@@ -2693,8 +3004,8 @@ __device__ __forceinline__ bool k4_read(const ClassifyArgs& A, uint64_t it, uint
     return true;
 }
 
-// pending reads of the batch -> three index lists by table size (status 254: small, 252: mid, 253: large); counts in
-// cursor[4], cursor[8], cursor[5]
+// pending reads of the batch -> index lists by table size and path (status 254: small, 252: mid, 253: large -- the general path;
+// 251: up to 16 taxids, decided by k4_row_kernel); counts in cursor[4], cursor[8], cursor[5], cursor[9]
 __global__ __launch_bounds__(256) void k4_compact_kernel(ClassifyArgs A) {
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
     const int lane = threadIdx.x & 63;
@@ -2707,16 +3018,16 @@ __global__ __launch_bounds__(256) void k4_compact_kernel(ClassifyArgs A) {
             const uint64_t it = base + (uint64_t)j * 64 + lane;
             st[j] = it < A.count ? (uint32_t)*(const GAS uint8_t*)(A.results + it) : 0u;  // status is the record's first byte
         }
-        for (int cls = 0; cls < 3; ++cls) {
-            const uint32_t want = cls == 0 ? 254u : (cls == 1 ? 252u : 253u);
+        for (int cls = 0; cls < 4; ++cls) {
+            const uint32_t want = cls == 0 ? 254u : (cls == 1 ? 252u : (cls == 2 ? 253u : 251u));
             uint32_t total = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) total += (uint32_t)popc64(__ballot(st[j] == want));
             if (!total) continue;
             uint32_t pos = 0;
-            if (lane == 0) pos = G_ADD(&g_cursor[cls == 0 ? 4 : (cls == 1 ? 8 : 5)], total);
+            if (lane == 0) pos = G_ADD(&g_cursor[cls == 0 ? 4 : (cls == 1 ? 8 : (cls == 2 ? 5 : 9))], total);
             pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-            GAS uint32_t* list = (GAS uint32_t*)(cls == 0 ? A.k4_small : (cls == 1 ? A.k4_mid : A.k4_large));
+            GAS uint32_t* list = (GAS uint32_t*)(cls == 0 ? A.k4_small : (cls == 1 ? A.k4_mid : (cls == 2 ? A.k4_large : A.k4_row)));
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const uint64_t m = __ballot(st[j] == want);
@@ -3031,6 +3342,12 @@ void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stre
         k4_kernel<false, kK4MidT, 64><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
     }
     hipStreamWaitEvent(stream3, forked, 0);
+    if (!a.nm.active) {  // tables of up to 16 taxids, four reads to a wave (the bulk of a batch when no null models are loaded)
+        uint64_t gr = (a.count + 3) / 4;
+        if (gr > 256 * 64) gr = 256 * 64;
+        if (gr < 1) gr = 1;
+        k4_row_kernel<<<dim3((unsigned)gr), dim3(64), 0, stream3>>>(a);
+    }
     if (!a.nm.active) launch_k4_lds<kK4T>(a, a.count / 8 + 64, stream3);  // 33..64 taxids: few reads, but a pass over them is long
     if (small_stream != stream && small_stream != stream3) hipStreamWaitEvent(small_stream, forked, 0);
     launch_k4_lds<kK4SmallT>(a, a.count, small_stream);

@@ -28,6 +28,7 @@ struct ClassifyArgs {
     uint32_t* k4_mid;          // read indices awaiting K4, up to 32 taxids (count in cursor[8])
     uint32_t* k4_large;        // read indices awaiting K4, large tables (count in cursor[5])
     uint32_t* k4_bail;         // reads the LDS K4 kernel could not hold after all (count in cursor[6])
+    uint32_t* k4_row;          // read indices awaiting k4_row_kernel: up to 16 taxids, decision by rows (count in cursor[9])
     uint32_t k4_slot;          // which of the two lists a k4_kernel launch takes (5 or 6)
     // rand_read_label mode (null-model generation): per (taxid, GC bucket) the largest k-mer fraction over the reads and
     // the number of reads that hit the taxid; the decision step is skipped

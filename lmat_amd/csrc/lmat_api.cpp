@@ -81,6 +81,11 @@ static KernelParams kparams(const lmat_params& p) {
     k.stop_after = sa ? atoi(sa) : 0;
     // LMAT_K4_WAVE=0: every read takes the general decision path (hand-off record -> k4 kernels); 20 stops nothing
     if (const char* w = getenv("LMAT_K4_WAVE")) if (!k.stop_after && atoi(w) == 0) k.stop_after = 20;
+    // LMAT_K4_ROW=1: tables of up to 16 taxids are decided by k4_row_kernel, four reads to a wave, instead of on the classify wave.
+    // Measured (64 GiB table, 2 M reads per launch): that kernel needs 0.95 ms for the 1.5 M such reads of a launch -- its rows turn
+    // every wave-uniform value of k4_wave into vector work, ~1400 instructions per wave of four reads, no cheaper per read than the
+    // ~390 of k4_wave -- and the step takes 7.5 ms instead of 7.1.  Off by default; kept as the measured alternative.
+    k.k4_row = getenv("LMAT_K4_ROW") && atoi(getenv("LMAT_K4_ROW")) != 0;
     return k;
 }
 
@@ -1018,7 +1023,7 @@ static int ensure_scratch(lmat_ctx* c, uint64_t count) {
         if (c->d_k4large) hipFree(c->d_k4large);
         c->d_k4small = c->d_k4large = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_k4small, count * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void**)&c->d_k4large, 2 * count * sizeof(uint32_t)));  // two lists: large tables | up to 32 taxids
+        HIPCHK(c, hipMalloc((void**)&c->d_k4large, 3 * count * sizeof(uint32_t)));  // three lists: large tables | up to 32 taxids | up to 16, by rows
         if (c->d_k4bail) hipFree(c->d_k4bail);
         c->d_k4bail = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_k4bail, count * sizeof(uint32_t)));
@@ -1066,6 +1071,7 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.k4_small = c->d_k4small;
     a.k4_large = c->d_k4large;
     a.k4_mid = c->d_k4large + c->ovf_cap;
+    a.k4_row = c->d_k4large + 2 * c->ovf_cap;
     a.k4_bail = c->d_k4bail;
     a.k4_slot = 5;
     a.nm = c->nm;

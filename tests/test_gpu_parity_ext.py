@@ -930,6 +930,13 @@ def test_general_decision_path_gives_the_same_answers():
                "text_parity or out_text or parameter_variants or overflow_rerun or many_distinct or degenerate or long_reads or random_configuration or label_modes or example")
 
 
+def test_decision_by_rows_gives_the_same_answers():
+    """LMAT_K4_ROW=1: reads with at most 16 registered taxids are decided by k4_row_kernel (four reads to a wave, a read per row of
+    16 lanes) instead of on the classify wave; the measured-slower alternative stays bit-exact."""
+    _child_run("LMAT_K4_ROW", "1", ["test_gpu_parity_ext.py", "test_gpu_parity.py", "test_gpu_fuzz.py"],
+               "config1_text_parity or out_text or parameter_variants or degenerate or random_configuration or example")
+
+
 def test_list_records_on_wider_boundaries_give_the_same_answers():
     """LMAT_LIST_SHIFT=2: list records on 64-byte instead of 16-byte boundaries, which is how the 24-bit payloads address an
     arena of 1 GB instead of 256 MB (up to 4 GB at shift 4).  Taxid lists, gene lists and the lookup API read records through the
