@@ -3182,7 +3182,7 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #ifndef LMAT_FAST_WAVES
 #define LMAT_FAST_WAVES 8   // (A/B builds: -DLMAT_FAST_WAVES=7 compiles the fast classes for 7 waves per SIMD, 72 registers)
 #endif
-constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? LMAT_FAST_WAVES : 5) : (U <= 256 ? (CPT ? LMAT_FAST_WAVES : 5) : (CPT ? 4 : 3)))); }
+constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? LMAT_FAST_WAVES : 5) : (U <= 256 ? (CPT ? LMAT_FAST_WAVES : 5) : (U <= 320 ? (CPT ? 5 : 3) : (CPT ? 4 : 3))))); }
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
@@ -3418,6 +3418,8 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
         LC(160, 64, kFastE, false);
     } else if (P <= 256) {
         if (tcap_class == 0) LC(256, 64, kFastE, false); else LC(256, 1024, 4096, true);
+    } else if (P <= 320 && tcap_class == 0) {
+        LC(320, 64, kFastE, false);   // 257..320 k-mers (reads of up to 339 bp at k = 20): six chunks of registers instead of the nine of the 512 class
     } else if (P <= 512) {
         if (tcap_class == 0) LC(512, 64, kFastE, false); else LC(512, 1024, 4096, true);
     } else if (P <= 2048) {

@@ -991,7 +991,7 @@ void lmat_reads_free(lmat_ctx* c, lmat_reads* r) {
     if (c) hipSetDevice(c->device);
     if (r->words) hipFree(r->words);
     if (r->rec_off) hipFree(r->rec_off);
-    for (int j = 0; j < 3; ++j) if (r->cls_dev[j]) hipFree(r->cls_dev[j]);
+    for (int j = 0; j < kNCls; ++j) if (r->cls_dev[j]) hipFree(r->cls_dev[j]);
     delete r;
 }
 
@@ -1143,30 +1143,30 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         lmat_reads* rw = const_cast<lmat_reads*>(reads);
         const uint32_t k = (uint32_t)c->dev.k;
         if (!rw->preset && rw->cls_k != (int)k && rw->lens.size() == rw->n) {
-            for (int j = 0; j < 3; ++j) { rw->cls_host[j].clear(); if (rw->cls_dev[j]) { hipFree(rw->cls_dev[j]); rw->cls_dev[j] = nullptr; } }
+            for (int j = 0; j < kNCls; ++j) { rw->cls_host[j].clear(); if (rw->cls_dev[j]) { hipFree(rw->cls_dev[j]); rw->cls_dev[j] = nullptr; } }
             for (uint64_t i = 0; i < rw->n; ++i) {
                 const uint32_t P = rw->lens[i] >= k ? rw->lens[i] - k + 1 : 0;
-                rw->cls_host[P <= 160 ? 0 : (P <= 256 ? 1 : 2)].push_back((uint32_t)i);
+                rw->cls_host[len_class(P)].push_back((uint32_t)i);
             }
             int used = 0;
-            for (int j = 0; j < 3; ++j) used += !rw->cls_host[j].empty();
+            for (int j = 0; j < kNCls; ++j) used += !rw->cls_host[j].empty();
             if (used > 1)
-                for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < kNCls; ++j)
                     if (!rw->cls_host[j].empty()) {
                         HIPCHK(c, hipMalloc((void**)&rw->cls_dev[j], rw->cls_host[j].size() * 4));
                         HIPCHK(c, hipMemcpyAsync(rw->cls_dev[j], rw->cls_host[j].data(), rw->cls_host[j].size() * 4, hipMemcpyHostToDevice, c->stream));
                     }
             rw->cls_k = (int)k;
         }
-        const uint32_t cls_len[3] = {160 + k - 1, 256 + k - 1, 512 + k - 1};
-        bool mixed = rw->cls_dev[0] || rw->cls_dev[1] || rw->cls_dev[2];
+        const uint32_t cls_len[kNCls] = {kClsU[0] + k - 1, kClsU[1] + k - 1, kClsU[2] + k - 1, kClsU[3] + k - 1};
+        bool mixed = rw->cls_dev[0] || rw->cls_dev[1] || rw->cls_dev[2] || rw->cls_dev[3];
         if (rw->preset) {  // a stream slot: lists over the whole batch, already on the device
-            const int used = (rw->cls_n[0] != 0) + (rw->cls_n[1] != 0) + (rw->cls_n[2] != 0);
+            const int used = (rw->cls_n[0] != 0) + (rw->cls_n[1] != 0) + (rw->cls_n[2] != 0) + (rw->cls_n[3] != 0);
             if (used <= 1) {
                 if (!launch_classify(a, std::min<uint32_t>(reads->max_len, 512 + k - 1), 0, c->stream))
                     return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
             } else {
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < kNCls; ++j) {
                     if (!rw->cls_n[j]) continue;
                     ClassifyArgs s = a;
                     s.index = rw->cls_dev[j];
@@ -1179,7 +1179,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
             if (!launch_classify(a, std::min<uint32_t>(reads->max_len, 512 + k - 1), 0, c->stream))
                 return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
         } else {
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < kNCls; ++j) {
                 const std::vector<uint32_t>& v = rw->cls_host[j];
                 const size_t lo = std::lower_bound(v.begin(), v.end(), (uint32_t)first) - v.begin();
                 const size_t hi = std::lower_bound(v.begin(), v.end(), (uint32_t)(first + count)) - v.begin();
@@ -1585,7 +1585,7 @@ int lmat_gather_bench(lmat_ctx* c, uint64_t n_probes, uint64_t seed, float* ms, 
 struct lmat_stream {
     struct Slot {
         uint8_t* h_bases = nullptr;  uint64_t* h_off = nullptr;      // pinned: filled by the caller
-        uint64_t* h_rec_off = nullptr; uint32_t* h_cls[3] = {nullptr, nullptr, nullptr};
+        uint64_t* h_rec_off = nullptr; uint32_t* h_cls[kNCls] = {nullptr, nullptr, nullptr, nullptr};
         lmat_read_result* h_results = nullptr; lmat_cand* h_cands = nullptr; uint32_t* h_cursor = nullptr;  // pinned: filled by the engine
         uint8_t* d_bases = nullptr; uint64_t* d_off = nullptr;
         lmat_read_result* d_results = nullptr; lmat_cand* d_cands = nullptr;
@@ -1609,12 +1609,12 @@ static void stream_free(lmat_stream* st) {
     hipSetDevice(st->c->device);
     hipDeviceSynchronize();
     for (auto& sl : st->slots) {
-        void* pinned[] = {sl.h_bases, sl.h_off, sl.h_rec_off, sl.h_cls[0], sl.h_cls[1], sl.h_cls[2], sl.h_results, sl.h_cands, sl.h_cursor};
+        void* pinned[] = {sl.h_bases, sl.h_off, sl.h_rec_off, sl.h_cls[0], sl.h_cls[1], sl.h_cls[2], sl.h_cls[3], sl.h_results, sl.h_cands, sl.h_cursor};
         for (void* p : pinned) if (p) hipHostFree(p);
-        void* dev[] = {sl.d_bases, sl.d_off, sl.d_results, sl.d_cands, sl.reads.words, sl.reads.rec_off, sl.reads.cls_dev[0], sl.reads.cls_dev[1], sl.reads.cls_dev[2]};
+        void* dev[] = {sl.d_bases, sl.d_off, sl.d_results, sl.d_cands, sl.reads.words, sl.reads.rec_off, sl.reads.cls_dev[0], sl.reads.cls_dev[1], sl.reads.cls_dev[2], sl.reads.cls_dev[3]};
         for (void* p : dev) if (p) hipFree(p);
         sl.reads.words = nullptr; sl.reads.rec_off = nullptr;
-        for (int j = 0; j < 3; ++j) sl.reads.cls_dev[j] = nullptr;
+        for (int j = 0; j < kNCls; ++j) sl.reads.cls_dev[j] = nullptr;
         if (sl.ev_up) hipEventDestroy(sl.ev_up);
         if (sl.ev_done) hipEventDestroy(sl.ev_done);
         if (sl.ev_out) hipEventDestroy(sl.ev_out);
@@ -1660,7 +1660,7 @@ int lmat_stream_create(lmat_ctx* c, uint64_t max_reads, uint64_t max_bases, uint
              hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming) == hipSuccess;
-        for (int j = 0; j < 3 && ok; ++j)
+        for (int j = 0; j < kNCls && ok; ++j)
             ok = hipHostMalloc((void**)&sl.h_cls[j], max_reads * 4, hipHostMallocDefault) == hipSuccess &&
                  hipMalloc((void**)&sl.reads.cls_dev[j], max_reads * 4) == hipSuccess;
         if (ok && sl.cand_cap)
@@ -1734,7 +1734,7 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
     // threads when the batch is large (2 M reads took 12 ms in one thread, longer than the GPU needs for them)
     const uint32_t k = (uint32_t)c->dev.k;
     const int nt = n >= (1u << 18) ? 4 : 1;
-    struct Part { uint64_t words = 0, cn[3] = {0, 0, 0}; uint32_t max_len = 0; bool bad = false; };
+    struct Part { uint64_t words = 0, cn[kNCls] = {0, 0, 0, 0}; uint32_t max_len = 0; bool bad = false; };
     std::vector<Part> part(nt);
     auto span = [&](int t, uint64_t& lo, uint64_t& hi) { lo = n * (uint64_t)t / nt; hi = n * (uint64_t)(t + 1) / nt; };
     auto pass1 = [&](int t) {
@@ -1747,20 +1747,20 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
             p.max_len = std::max<uint32_t>(p.max_len, (uint32_t)len);
             p.words += rec_words((uint32_t)len);
             const uint32_t P = len >= k ? (uint32_t)len - k + 1 : 0;
-            p.cn[P <= 160 ? 0 : (P <= 256 ? 1 : 2)]++;
+            p.cn[len_class(P)]++;
         }
     };
-    std::vector<uint64_t> wbase(nt + 1, 0), cbase(3 * (nt + 1), 0);
+    std::vector<uint64_t> wbase(nt + 1, 0), cbase(kNCls * (nt + 1), 0);
     auto pass2 = [&](int t) {
         uint64_t lo, hi;
         span(t, lo, hi);
-        uint64_t w = wbase[t], cpos[3] = {cbase[3 * t], cbase[3 * t + 1], cbase[3 * t + 2]};
+        uint64_t w = wbase[t], cpos[kNCls] = {cbase[kNCls * t], cbase[kNCls * t + 1], cbase[kNCls * t + 2], cbase[kNCls * t + 3]};
         for (uint64_t i = lo; i < hi; ++i) {
             const uint32_t len = (uint32_t)(sl.h_off[i + 1] - sl.h_off[i]);
             sl.h_rec_off[i] = w;
             w += rec_words(len);
             const uint32_t P = len >= k ? len - k + 1 : 0;
-            const int j = P <= 160 ? 0 : (P <= 256 ? 1 : 2);
+            const int j = len_class(P);
             sl.h_cls[j][cpos[j]++] = (uint32_t)i;
         }
     };
@@ -1773,12 +1773,12 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
     };
     run_parts(pass1);
     uint32_t max_len = 0;
-    uint64_t cn[3] = {0, 0, 0};
+    uint64_t cn[kNCls] = {0, 0, 0, 0};
     for (int t = 0; t < nt; ++t) {
         if (part[t].bad) { sl.state = 0; return set_err(c, LMAT_E_ARG, "offsets must ascend"); }
         max_len = std::max(max_len, part[t].max_len);
         wbase[t + 1] = wbase[t] + part[t].words;
-        for (int j = 0; j < 3; ++j) { cbase[3 * (t + 1) + j] = cbase[3 * t + j] + part[t].cn[j]; cn[j] += part[t].cn[j]; }
+        for (int j = 0; j < kNCls; ++j) { cbase[kNCls * (t + 1) + j] = cbase[kNCls * t + j] + part[t].cn[j]; cn[j] += part[t].cn[j]; }
     }
     run_parts(pass2);
     sl.h_rec_off[n] = wbase[nt];
@@ -1789,8 +1789,8 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
     sl.reads.n_words = sl.h_rec_off[n];
     sl.reads.max_len = max_len;
     sl.reads.class_len = max_len;
-    const int used = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0);
-    for (int j = 0; j < 3; ++j) sl.reads.cls_n[j] = used > 1 ? cn[j] : 0;
+    const int used = (cn[0] != 0) + (cn[1] != 0) + (cn[2] != 0) + (cn[3] != 0);
+    for (int j = 0; j < kNCls; ++j) sl.reads.cls_n[j] = used > 1 ? cn[j] : 0;
     if ((int)max_len > classify_max_read_len()) {  // refused before anything is queued: the slot goes back untouched
         sl.state = 0;
         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
@@ -1800,7 +1800,7 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
         HIPCHK(c, hipMemcpyAsync(sl.d_off, sl.h_off, (n + 1) * 8, hipMemcpyHostToDevice, st->s_h2d));
         HIPCHK(c, hipMemcpyAsync(sl.reads.rec_off, sl.h_rec_off, (n + 1) * 8, hipMemcpyHostToDevice, st->s_h2d));
         if (used > 1)
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < kNCls; ++j)
                 if (cn[j]) HIPCHK(c, hipMemcpyAsync(sl.reads.cls_dev[j], sl.h_cls[j], cn[j] * 4, hipMemcpyHostToDevice, st->s_h2d));
         HIPCHK(c, hipEventRecord(sl.ev_up, st->s_h2d));
         HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_up, 0));

@@ -88,7 +88,13 @@ struct KernelParams {
 
 }  // namespace lmat
 
-namespace lmat { struct StreamBuild; }
+namespace lmat {
+struct StreamBuild;
+// k-mer capacities of the fast classify classes: a read of P k-mer positions runs in the smallest class that holds it
+static const int kNCls = 4;
+static const uint32_t kClsU[kNCls] = {160, 256, 320, 512};
+inline int len_class(uint32_t P) { return P <= 160 ? 0 : (P <= 256 ? 1 : (P <= 320 ? 2 : 3)); }
+}
 
 struct lmat_reads {
     uint32_t* words = nullptr;    // device: packed records
@@ -97,16 +103,16 @@ struct lmat_reads {
     uint64_t n_words = 0;
     uint32_t max_len = 0;
     uint32_t class_len = 0;       // length that all but the longest 1 % of the reads stay under
-    // Length classes of the fast kernel (k-mer capacities 160 / 256 / 512): read indices per class, ascending, so a
+    // Length classes of the fast kernel (k-mer capacities 160 / 256 / 320 / 512: lmat::kNCls, lmat::len_class): read indices per class, ascending, so a
     // mixed-length batch runs each read in the smallest class that holds it.  Built on first use for the database's k.
     std::vector<uint32_t> lens;
-    std::vector<uint32_t> cls_host[3];
-    uint32_t* cls_dev[3] = {nullptr, nullptr, nullptr};
+    std::vector<uint32_t> cls_host[lmat::kNCls];
+    uint32_t* cls_dev[lmat::kNCls] = {nullptr, nullptr, nullptr, nullptr};
     int cls_k = 0;
     // a batch slot of a lmat_stream: the class lists are filled by the submitter into buffers the slot owns (cls_dev, cls_n
     // entries each) and always cover the whole batch
     bool preset = false;
-    uint64_t cls_n[3] = {0, 0, 0};
+    uint64_t cls_n[lmat::kNCls] = {0, 0, 0, 0};
 };
 
 struct lmat_ingest {
