@@ -3342,7 +3342,7 @@ void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stre
         k4_kernel<false, kK4MidT, 64><<<dim3((unsigned)g2), dim3(64), 0, stream2>>>(b);
     }
     hipStreamWaitEvent(stream3, forked, 0);
-    if (!a.nm.active) {  // tables of up to 16 taxids, four reads to a wave (the bulk of a batch when no null models are loaded)
+    if (!a.nm.active && a.prm.k4_row) {  // LMAT_K4_ROW=1: tables of up to 16 taxids, four reads to a wave
         uint64_t gr = (a.count + 3) / 4;
         if (gr > 256 * 64) gr = 256 * 64;
         if (gr < 1) gr = 1;

@@ -6,5 +6,5 @@ for s in 30 31 32 33 0; do
   LMAT_STOP_AFTER=$s python bench.py --steps 5 --warmup 2 --no-cpu --no-e2e --windows 0 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
-print('stop', $s, 'classify_ms %.3f' % d['roofline']['kernel_avg_ms'], 'tail_ms %.3f' % d['roofline']['k4_kernels_avg_ms'], 'value %.1f M' % (d['value'] / 1e6))"
+print('stop', $s, 'classify_ms %.3f' % d['roofline']['kernel_avg_ms'], 'value %.1f M' % (d['value'] / 1e6))"
 done

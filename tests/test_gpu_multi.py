@@ -49,7 +49,7 @@ def test_bench_two_ranks_add_up_to_one_rank_over_the_same_reads(tmp_path):
     assert sum(t2["counts"].values()) + sum(t2["nomatch"]) == 2 * 2 * 30000  # ranks x steps x batch: every read tallied once
     for t, s in t1["scores"].items():
         assert abs(t2["scores"][t] - s) <= 1e-9 * max(1.0, abs(s))
-    assert two["roofline"]["frac_step"] < two["roofline"]["frac"] <= 1.0
+    assert 0 < two["roofline"]["frac_step"] <= 1.0 and 0 < two["roofline"]["frac"] <= 1.0
     assert two["value_median_of_windows"] > 0
 
 
