@@ -128,11 +128,18 @@ def cpu_baseline(eng, reads, n_sample, k, tmpdir):
     r1, s1, _ = rate(1, n1, 5.0)                # T = 1 on an eighth of the sample (~5 s)
     rn, sn, reps = rate(threads, n_sample, 10.0)  # T = N (~10 s)
     orc.close()
+    ratio, ratio_from = None, None   # oracle / reference on the reference's own retrieve_kmer_labels, measured in the build container
+    try:
+        ratio = json.load(open(os.path.join(ROOT, "profiles", "r03_ref_ratio.json")))["geomean_port_over_reference"]
+        ratio_from = "profiles/r03_ref_ratio.json (scripts/ref_ratio.py: src/rkmer.hpp compiled in place vs the oracle, same reads, one thread)"
+    except Exception:
+        pass
     return {"value": rn, "unit": "reads/s", "cores": threads, "kind": "port", "t1_reads_per_s": r1, "tN_reads_per_s": rn,
+            "port_over_reference": ratio, "reference_equivalent_reads_per_s": rn / ratio if ratio else None, "port_over_reference_from": ratio_from,
             "cpu": info,
             "sample": f"first {n_sample} reads of the same synthetic workload x {reps} passes at T={threads} ({sn:.1f} s), first {n1} reads at "
                       f"T=1 ({s1:.1f} s); CPU oracle (oracle/lmat_oracle.hpp, a restatement of read_label's proc_line -- the reference's "
-                      "read_label.cpp does not build in this image, so there is no reference-equivalent ratio); k-mer table = host hash "
+                      "read_label.cpp does not build in this image; port_over_reference is for the part that does); k-mer table = host hash "
                       "map holding the GPU table's lists for those reads' k-mers"}
 
 
