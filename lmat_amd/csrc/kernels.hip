@@ -1548,6 +1548,82 @@ __global__ __launch_bounds__(64) void k4_row_kernel(ClassifyArgs A) {
 // The launch arguments are read where they are used, from the kernel-argument segment (scalar loads from constant memory),
 // through a pointer the compiler is made to forget at every phase boundary (REARGS): kept in scalar registers for the whole
 // kernel they did not fit (85 spilled into vector-register lanes, and every spill and refill is a vector instruction).
+// ------------------------------------------------------------------------------------------
+// Tails.  A 150 bp read has 131 k-mer positions: two chunks of 64 lanes and three positions more, and a third chunk for
+// those three costs the classify wave what a full one does (a vector instruction takes its issue slot whatever its lane
+// mask; the kernel is bound by exactly that).  So the positions from 128 on are looked up here, LPR lanes per read with
+// the tails of 64 / LPR reads side by side in a wave, and the classify wave picks the results up: canonical k-mer, bucket,
+// payload, and the three m-mer values the k-mers at 125..127 take their minimizer from.  Reads with 128 < positions <=
+// 128 + LPR only (compact layout); everything else runs its chunks as before.
+// ------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void tail_kernel(ClassifyArgs A) {
+    const uint64_t gi = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t it = gi / LPR;
+    const uint32_t j = (uint32_t)(gi % LPR);
+    if (it >= A.count) return;
+    const uint64_t r = A.index ? (uint64_t)A.index[it] : A.first + it;
+    const DeviceTables& tb = A.tb;
+    const int k = tb.k;
+    const uint64_t off = A.rec_off[r];
+    const uint32_t len = A.words[off];
+    if ((int)len < k) return;
+    const uint32_t P = len - k + 1;
+    if (P <= 128u || P > 128u + LPR) return;
+    const uint32_t p = 128u + j;
+    const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
+    const uint32_t* codes = A.words + off + 1;
+    const uint32_t* vmask = codes + nb;
+    auto cw = [&](uint32_t i) -> uint64_t { return i < nb ? codes[i] : 0u; };   // the record's tail reads as zero, as in the classify wave's copy
+    auto vw = [&](uint32_t i) -> uint64_t { return i < nm ? vmask[i] : 0u; };
+    // the window at p (classify_one's `window`)
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint32_t wmask = (1u << k) - 1;
+    const uint32_t mb = p >> 5, ms = p & 31;
+    const uint64_t m2 = (vw(mb + 1) << 32) | vw(mb);
+    const bool valid = ((uint32_t)(m2 >> ms) & wmask) == wmask;
+    const uint32_t wb = (2 * p) >> 5, ws = (2 * p) & 31;
+    const uint64_t lo = (cw(wb + 1) << 32) | cw(wb);
+    uint64_t w = ws ? ((lo >> ws) | (cw(wb + 2) << (64 - ws))) : lo;
+    w &= kmask;
+    const uint64_t rev = (~w) & kmask;
+    uint64_t f = __builtin_bitreverse64(w);
+    f = ((f & 0x5555555555555555ull) << 1) | ((f >> 1) & 0x5555555555555555ull);
+    f >>= (64 - 2 * k);
+    const bool fc = f < rev;
+    const uint64_t km = fc ? f : rev, kr = fc ? rev : f;
+    const uint64_t ri = r - A.result_base;
+    if (j < 3u) {  // positions 128..130 always hold an m-mer of the read (P > 128: the last one starts at P + 2)
+        const int cm = tb.cpt.m;
+        const uint64_t x = f >> (2 * (kCptW - 1)), xr = rev & ((1ull << (2 * cm)) - 1);
+        ((uint64_t*)A.tail_u)[ri * 4 + j] = (cpt_scramble(x < xr ? x : xr, cm) << 4) | (xr < x ? 2u : 0u) | (x == xr ? 1u : 0u);
+    }
+    u32x4 e = {0u, 0u, 0u, 0u};
+    if (p < P && valid) {
+        uint32_t b, tag;
+        cpt_address(*(const CptGeom*)&tb.cpt, km, kr, b, tag);
+        const uint32_t jj = ((tag - 1u) >> 7) & 3u;  // which m-mer of the canonical k-mer is the minimizer
+        const uint32_t* bk = (const uint32_t*)tb.slots + (uint64_t)b * 16;
+        const u32x4 q0 = *(const u32x4*)bk, q1 = *(const u32x4*)(bk + 4), q2 = *(const u32x4*)(bk + 8), q3 = *(const u32x4*)(bk + 12);
+        const uint32_t tg[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+        const uint32_t pw[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};   // 16-bit payload halves, slots 0..11
+        const uint32_t ph[3] = {q3.x, q3.y, q3.z};                      // payload bits 16..23, a byte per slot
+        uint32_t pay = 0;
+        bool hit = false;
+#pragma unroll
+        for (int i = kCptSlots - 1; i >= 0; --i) {  // the first matching slot wins, as in the classify wave
+            const uint32_t t = (tg[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            if (t == (tag & 0xFFFFu)) {
+                hit = true;
+                pay = ((pw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) | (((ph[i >> 2] >> (8 * (i & 3))) & 0xFFu) << 16);
+            }
+        }
+        if (!hit && (q3.w & kCptOvfFlag)) pay = wide_lookup(tb.ovf_slots, tb.ovf_nbuckets, ovf_bucket_of(b, tag & 0xFFFFu, tb.ovf_nbuckets), km);
+        e = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, pay | (1u << 24) | ((fc ? jj : (uint32_t)(kCptW - 1) - jj) << 30)};
+    }
+    ((u32x4*)A.tail16)[ri * LPR + j] = e;
+}
+
 typedef const ClassifyArgs __attribute__((address_space(4))) CArgs;
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
 __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned char* lds, LAS unsigned char* xl, int lane,
@@ -1658,6 +1734,14 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         }
         return;
     }
+    // tail mode (tail_kernel): this read's positions from 128 on were looked up beforehand.  Re-derived at each of the three
+    // places that ask (a scalar load and two compares) rather than carried: the kernel has no scalar register to spare.
+    constexpr bool TAILOK = CPT && U == 160 && !INK4;
+    auto tail_mode = [&]() -> bool {
+        if constexpr (!TAILOK) return false;
+        const uint32_t lpr = A.tail_lpr;
+        return lpr != 0 && P > 128u && P <= 128u + lpr && !A.nm.active;
+    };
     // ---- packed record -> LDS (coalesced), zero tail so windows past the end are invalid
     const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
 #pragma unroll
@@ -1796,12 +1880,29 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= len) break;
+            if (TAILOK && c == 2 && tail_mode()) {  // looked up beforehand: k-mer, bucket, minimizer offset; the payload goes straight to its place
+                const uint32_t lpr = A.tail_lpr;
+                const uint64_t ri = r - A.result_base;
+                u32x4 te = {0u, 0u, 0u, 0u};
+                uint64_t tu = 0;
+                if ((uint32_t)lane < lpr) te = ((const GAS u32x4*)A.tail16)[ri * lpr + lane];
+                if (lane < 3) tu = ((const GAS uint64_t*)A.tail_u)[ri * 4 + lane];
+                kreg[c] = ((uint64_t)(te.y & 0xFFu) << 32) | te.x;
+                hreg[c] = te.z;
+                treg[c] = te.w & 0xC0000000u;
+                okm[c] = __ballot((te.w >> 24) & 1u);
+                valid_kmers += popc64(okm[c]);
+                ureg[c] = tu;
+                if (128u + (uint32_t)lane < P) upay[128 + lane] = te.w & 0xFFFFFFu;
+                continue;
+            }
             pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c], okm[c], ureg[c], fcm[c]);
         }
         if (CPT) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if ((uint32_t)c * 64 >= P) break;
+                if (TAILOK && c == 2 && tail_mode()) continue;
                 cpt_finish(kreg[c], ureg[c], c + 1 < CH ? ureg[c + 1] : 0ull, fcm[c], hreg[c], treg[c]);
             }
         }
@@ -2116,6 +2217,11 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= P) break;
+            if (TAILOK && c == 2 && tail_mode()) {  // the payloads are in place; a repeat of an earlier k-mer of the read gives its own up
+                if (suspect && 128u + (uint32_t)lane < P && !lane_bit(firstm[c])) upay[128 + lane] = 0u;
+                WSYNC();
+                continue;
+            }
             probe_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c] & 0xFFFFu, lane_bit(okm[c]), lane_bit(firstm[c]));
         }
     } else {
@@ -3400,6 +3506,15 @@ void launch_k4_debug(const ClassifyArgs& a, const uint32_t* idx, const float* sc
                      hipStream_t stream) {
     if (!n) return;
     k4_debug_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(a, idx, scores, off, stdevs, n);
+}
+
+void launch_tail(const ClassifyArgs& a, hipStream_t stream) {
+    if (!a.tail_lpr || !a.count || a.count_ptr) return;
+    const uint64_t lanes = a.count * a.tail_lpr;
+    const dim3 grid((unsigned)((lanes + 255) / 256));
+    if (a.tail_lpr == 4) tail_kernel<4><<<grid, dim3(256), 0, stream>>>(a);
+    else if (a.tail_lpr == 8) tail_kernel<8><<<grid, dim3(256), 0, stream>>>(a);
+    else tail_kernel<16><<<grid, dim3(256), 0, stream>>>(a);
 }
 
 int classify_max_read_len() { return kGmemU + 19; }

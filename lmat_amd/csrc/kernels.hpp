@@ -39,6 +39,12 @@ struct ClassifyArgs {
     unsigned char* gscratch;   // per-workgroup tables of the global-memory class (reads beyond the LDS classes), or null
     NullModelDev nm;           // -n null models (active == 0: scores are plain k-mer fractions)
     uint32_t gene_mode = 0;    // the database holds 32-bit gene-id lists: gene_label's vote instead of the taxonomic call
+    // Tail entries (tail_kernel): the k-mer positions of a read past its last full 64-lane chunk, looked up beforehand with the
+    // tails of many reads side by side in a wave.  The 160-k-mer classes take them instead of running a third chunk for a
+    // handful of lanes.  tail_lpr = entries per read (4, 8 or 16; 0 = off), indexed like `results`.
+    const uint32_t* tail16 = nullptr;  // [reads][tail_lpr] x 16 B: k-mer lo | k-mer hi | bucket | payload, valid << 24, minimizer offset << 30
+    const uint64_t* tail_u = nullptr;  // [reads][4]: the scrambled m-mers at positions 128..130 (what the k-mers at 125..127 need)
+    uint32_t tail_lpr = 0;
 };
 
 // record handed to the K4 kernels: word0 = nT | cand << 16, word1 reserved, then K4T words reg | cnt << 16
@@ -59,6 +65,8 @@ void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t
                         uint64_t seed, const SynthGeo& g, hipStream_t stream);
 void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids,
                    uint32_t stride, hipStream_t stream);
+// fills a.tail16 / a.tail_u for the reads of the launch (a.index / a.first, a.count; not for device-side counts)
+void launch_tail(const ClassifyArgs& a, hipStream_t stream);
 // tcap_class: 0 = fast (T=64, E=128), 2 = the same with E=512, 1 = large (T=1024).  Returns false if max_len exceeds every U class.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
 void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipStream_t small_stream,

@@ -128,7 +128,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc,
+                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_tail, c->parked.d_tail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc,
                     c->d_err, c->parked.d_results, c->parked.d_cands, c->parked.d_cursor, c->parked.d_ovf, c->parked.d_ovf2, c->parked.d_ovf3, c->parked.d_k4buf, c->parked.d_k4small,
                     c->parked.d_k4large, c->parked.d_k4bail};
     for (void* p : ptrs)
@@ -1088,6 +1088,7 @@ static void swap_sets(lmat_ctx* c) {
     std::swap(c->d_cursor, p.d_cursor); std::swap(c->d_ovf, p.d_ovf); std::swap(c->d_ovf2, p.d_ovf2); std::swap(c->d_ovf3, p.d_ovf3);
     std::swap(c->d_k4buf, p.d_k4buf); std::swap(c->d_k4small, p.d_k4small); std::swap(c->d_k4large, p.d_k4large);
     std::swap(c->d_k4bail, p.d_k4bail); std::swap(c->ovf_cap, p.ovf_cap);
+    std::swap(c->d_tail, p.d_tail); std::swap(c->tail_bytes, p.tail_bytes);
     std::swap(c->ev_done, p.done); std::swap(c->set_in_flight, p.in_flight);
 }
 
@@ -1125,6 +1126,35 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     // only OR into it and whoever reports it (lmat_sync, lmat_classify, lmat_rand_label) clears it
     HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 64, c->stream));
     ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
+    // Tails (tail_kernel): where the reads of the 160-k-mer class end a few positions past their second chunk -- 150 bp reads
+    // at k = 20 have 131 -- those positions are looked up beforehand, 4, 8 or 16 lanes per read.  Compact layout, no null
+    // models (their GC accounting walks every chunk).  LMAT_TAIL=0 turns it off.
+    auto setup_tail = [&](bool single_class) {  // single_class: the whole batch runs in the class its longest read asks for
+        static const bool tail_on = !getenv("LMAT_TAIL") || atoi(getenv("LMAT_TAIL")) != 0;
+        static const int tail_force = getenv("LMAT_TAIL_LPR") ? atoi(getenv("LMAT_TAIL_LPR")) : 0;  // experiments: 4, 8 or 16
+        const uint32_t k = (uint32_t)c->dev.k;
+        const uint32_t realP = reads->max_len >= k ? reads->max_len - k + 1 : 0;
+        if (single_class && realP > 160u) return;
+        const uint32_t maxP = std::min<uint32_t>(realP, 160u);
+        uint32_t lpr = 0;
+        if (tail_on && c->dev.cpt.nb && !c->nm.active && maxP > 128u) lpr = maxP <= 132u ? 4u : (maxP <= 136u ? 8u : 16u);
+        if (lpr && (tail_force == 4 || tail_force == 8 || tail_force == 16) && 128u + (uint32_t)tail_force >= std::min(maxP, 144u)) lpr = (uint32_t)tail_force;
+        if (lpr) {
+            const uint64_t need = count * (16ull * lpr + 32ull);
+            if (need > c->tail_bytes) {
+                if (c->d_tail) hipFree(c->d_tail);
+                c->d_tail = nullptr; c->tail_bytes = 0;
+                if (hipMalloc((void**)&c->d_tail, need) == hipSuccess) c->tail_bytes = need;
+                else { (void)hipGetLastError(); lpr = 0; }  // no room for them: the reads run their third chunk
+            }
+        }
+        if (lpr) {
+            a.tail_lpr = lpr;
+            a.tail16 = (const uint32_t*)c->d_tail;
+            a.tail_u = (const uint64_t*)(c->d_tail + count * 16ull * lpr);
+        }
+    };
+    auto tail_launch = [&](const ClassifyArgs& s) { launch_tail(s, c->stream); };  // (on a stream of its own beside the batch before: measured, no gain -- it takes the same wave slots)
     struct Ev {  // timing events of this launch: handed to the context on success, destroyed on any early return
         hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
         ~Ev() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); }
@@ -1135,8 +1165,12 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         HIPCHK(c, hipEventCreate(&e1));
         HIPCHK(c, hipEventCreate(&e2));
         HIPCHK(c, hipEventCreate(&e3));
-        HIPCHK(c, hipEventRecord(e0, c->stream));
     }
+    bool started = false;
+    auto mark_start = [&]() {  // the first timing event brackets the classify kernels only: the tail kernel ahead of them is on the step's account
+        if (timed && !started) hipEventRecord(e0, c->stream);
+        started = true;
+    };
     // Each read runs in the smallest fast class that holds it (160 / 256 / 512 k-mers; 512 = 531 bp at k = 20); longer
     // reads ride the overflow list to the wave-per-read classes behind it.  A batch of one class is one plain launch.
     {
@@ -1162,7 +1196,10 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         bool mixed = rw->cls_dev[0] || rw->cls_dev[1] || rw->cls_dev[2] || rw->cls_dev[3];
         if (rw->preset) {  // a stream slot: lists over the whole batch, already on the device
             const int used = (rw->cls_n[0] != 0) + (rw->cls_n[1] != 0) + (rw->cls_n[2] != 0) + (rw->cls_n[3] != 0);
+            setup_tail(used <= 1);
             if (used <= 1) {
+                tail_launch(a);
+                mark_start();
                 if (!launch_classify(a, std::min<uint32_t>(reads->max_len, 512 + k - 1), 0, c->stream))
                     return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
             } else {
@@ -1171,14 +1208,20 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
                     ClassifyArgs s = a;
                     s.index = rw->cls_dev[j];
                     s.count = rw->cls_n[j];
+                    if (j == 0) tail_launch(s);
+                    mark_start();
                     if (!launch_classify(s, cls_len[j], 0, c->stream))
                         return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
                 }
             }
         } else if (!mixed) {
+            setup_tail(true);
+            tail_launch(a);
+            mark_start();
             if (!launch_classify(a, std::min<uint32_t>(reads->max_len, 512 + k - 1), 0, c->stream))
                 return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
         } else {
+            setup_tail(false);
             for (int j = 0; j < kNCls; ++j) {
                 const std::vector<uint32_t>& v = rw->cls_host[j];
                 const size_t lo = std::lower_bound(v.begin(), v.end(), (uint32_t)first) - v.begin();
@@ -1187,11 +1230,14 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
                 ClassifyArgs s = a;
                 s.index = rw->cls_dev[j] + lo;
                 s.count = hi - lo;
+                if (j == 0) tail_launch(s);
+                mark_start();
                 if (!launch_classify(s, cls_len[j], 0, c->stream))
                     return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
             }
         }
     }
+    mark_start();  // (no class had a read)
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipEventRecord(e2, c->stream));

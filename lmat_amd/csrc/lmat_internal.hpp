@@ -168,6 +168,8 @@ struct lmat_ctx {
     uint32_t* d_k4small = nullptr; // index lists of the reads awaiting K4 (k4_compact_kernel)
     uint32_t* d_k4large = nullptr;
     uint32_t* d_k4bail = nullptr;
+    unsigned char* d_tail = nullptr;  // tail entries of the batch's reads (tail_kernel): [reads][lpr] x 16 B, then [reads][4] x 8 B
+    uint64_t tail_bytes = 0;
     hipStream_t stream2 = nullptr;  // the scratch K4 kernel runs beside the LDS one
     hipStream_t stream3 = nullptr;  // ... and the LDS kernel of the largest tables beside both
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join_small = nullptr;
@@ -181,6 +183,7 @@ struct lmat_ctx {
         uint32_t *d_cursor = nullptr, *d_ovf = nullptr, *d_ovf2 = nullptr, *d_ovf3 = nullptr, *d_k4buf = nullptr, *d_k4small = nullptr,
                  *d_k4large = nullptr, *d_k4bail = nullptr;
         uint64_t ovf_cap = 0;
+        unsigned char* d_tail = nullptr; uint64_t tail_bytes = 0;
         hipEvent_t done = nullptr;   // recorded behind the last kernel that touches the set
         bool in_flight = false;
     } parked;

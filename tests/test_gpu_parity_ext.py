@@ -950,3 +950,54 @@ def test_wide_table_format_gives_the_same_answers():
     probe with the default ones)."""
     _child_run("LMAT_TABLE_FORMAT", "wide", ["test_gpu_parity_ext.py"],
                "config1_text_parity or parameter_variants or overflow_rerun or many_distinct or degenerate or long_reads or sorteddb")
+
+
+def _tail_reads(config1, lo, hi, seed):
+    """Reads whose k-mer positions end a few past the second 64-lane chunk (lengths lo..hi at k = 20), cut from longer reads of
+    config 1, with the cases the looked-up tail has to get right: N's in and before the tail, a tail that repeats an earlier stretch
+    of the same read (its k-mers are then not first occurrences), low-complexity reads, and the plain case."""
+    import random
+    rng = random.Random(seed)
+    src = [r for r in config1["reads"] if len(r) >= 200]
+    out = []
+    for i in range(700):
+        L = rng.randint(lo, hi)
+        r = src[rng.randrange(len(src))]
+        s = rng.randrange(0, len(r) - L + 1)
+        r = list(r[s:s + L])
+        kind = i % 7
+        if kind == 1:    # N inside the tail's windows
+            for _ in range(rng.randint(1, 3)):
+                r[rng.randrange(L - 30, L)] = "N"
+        elif kind == 2:  # N's anywhere
+            for _ in range(rng.randint(1, 4)):
+                r[rng.randrange(L)] = "N"
+        elif kind == 3:  # the tail repeats an earlier stretch: positions 120.. copy positions 20..
+            n = L - 120
+            r[120:] = r[20:20 + n]
+        elif kind == 4:  # low complexity
+            unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 9)))
+            r = list((unit * (L // len(unit) + 1))[:L])
+        elif kind == 5:  # a repeat that straddles the chunk border
+            r[100:] = r[40:40 + L - 100]
+        out.append("".join(r))
+    return out
+
+
+@pytest.mark.parametrize("lo,hi", [(148, 151), (148, 155), (150, 163), (147, 200)])
+def test_reads_ending_just_past_a_chunk(config1, lo, hi):
+    """Tail mode (tail_kernel): k-mer positions 128.. of a read of the 160-k-mer class are looked up beforehand, 4 / 8 / 16
+    lanes per read by the batch's longest read; the last range mixes in reads of the next class, so the batch is split."""
+    eng = _engine(config1)
+    orc = _oracle(config1)
+    res, _, _ = _compare(eng, orc, _tail_reads(config1, lo, hi, lo * 1000 + hi))
+    assert (res["status"] == 0).sum() > 300
+    orc.close()
+    eng.close()
+
+
+def test_without_tail_mode_gives_the_same_answers():
+    """LMAT_TAIL=0: every read runs all of its chunks on the classify wave, as before tail mode -- now the less travelled path
+    for 150 bp reads."""
+    _child_run("LMAT_TAIL", "0", ["test_gpu_parity_ext.py", "test_gpu_parity.py", "test_gpu_fuzz.py"],
+               "config1_text_parity or out_text or full_size_sample or degenerate or random_configuration or past_a_chunk or example")
