@@ -1581,7 +1581,6 @@ __global__ __launch_bounds__(256) void tail_kernel(ClassifyArgs A) {
     const uint32_t wmask = (1u << k) - 1;
     const uint32_t mb = p >> 5, ms = p & 31;
     const uint64_t m2 = (vw(mb + 1) << 32) | vw(mb);
-    const bool valid = ((uint32_t)(m2 >> ms) & wmask) == wmask;
     const uint32_t wb = (2 * p) >> 5, ws = (2 * p) & 31;
     const uint64_t lo = (cw(wb + 1) << 32) | cw(wb);
     uint64_t w = ws ? ((lo >> ws) | (cw(wb + 2) << (64 - ws))) : lo;
@@ -1599,7 +1598,7 @@ __global__ __launch_bounds__(256) void tail_kernel(ClassifyArgs A) {
         ((uint64_t*)A.tail_u)[ri * 4 + j] = (cpt_scramble(x < xr ? x : xr, cm) << 4) | (xr < x ? 2u : 0u) | (x == xr ? 1u : 0u);
     }
     u32x4 e = {0u, 0u, 0u, 0u};
-    if (p < P && valid) {
+    if (p < P) {  // (the bucket is asked for whether or not the window is valid: its address needs the bases only, and the validity words are one more round trip away)
         uint32_t b, tag;
         cpt_address(*(const CptGeom*)&tb.cpt, km, kr, b, tag);
         const uint32_t jj = ((tag - 1u) >> 7) & 3u;  // which m-mer of the canonical k-mer is the minimizer
@@ -1618,8 +1617,11 @@ __global__ __launch_bounds__(256) void tail_kernel(ClassifyArgs A) {
                 pay = ((pw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) | (((ph[i >> 2] >> (8 * (i & 3))) & 0xFFu) << 16);
             }
         }
-        if (!hit && (q3.w & kCptOvfFlag)) pay = wide_lookup(tb.ovf_slots, tb.ovf_nbuckets, ovf_bucket_of(b, tag & 0xFFFFu, tb.ovf_nbuckets), km);
-        e = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, pay | (1u << 24) | ((fc ? jj : (uint32_t)(kCptW - 1) - jj) << 30)};
+        const bool valid = ((uint32_t)(m2 >> ms) & wmask) == wmask;
+        if (valid) {
+            if (!hit && (q3.w & kCptOvfFlag)) pay = wide_lookup(tb.ovf_slots, tb.ovf_nbuckets, ovf_bucket_of(b, tag & 0xFFFFu, tb.ovf_nbuckets), km);
+            e = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, pay | (1u << 24) | ((fc ? jj : (uint32_t)(kCptW - 1) - jj) << 30)};
+        }
     }
     ((u32x4*)A.tail16)[ri * LPR + j] = e;
 }
@@ -2187,9 +2189,11 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 const uint32_t t4 = bk[4], t5 = bk[5];
                 const uint32_t key2 = tag | (tag << 16);
                 // z(x): each 16-bit half is 0 where the slot's tag equals the k-mer's, else 1 (tags are never 0, empty slots are)
+                // (v_pk_min_u16 by name: the element-wise min builtin came out as two 16-bit compares, two selects and a byte permute)
                 auto z = [&](uint32_t x) -> uint32_t {
-                    const u16x2 d = __builtin_bit_cast(u16x2, x ^ key2), one = {1, 1};
-                    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(d, one));
+                    uint32_t r;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x ^ key2), "v"(0x00010001u));
+                    return r;
                 };
                 const uint32_t miss = z(t0.x) | (z(t0.y) << 1) | (z(t0.z) << 2) | (z(t0.w) << 3) | (z(t4) << 4) | (z(t5) << 5);
                 const uint32_t acc = ~miss & 0x003F003Fu;  // bit i: slot 2i matches, bit 16 + i: slot 2i + 1
@@ -2252,7 +2256,41 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     //      payload d and its multiplicity in registers); the LDS hash is only for reads with more than 64.
     uint32_t ndist = 0;
     bool many = false;
-    {
+    if constexpr (U <= 320) {  // (the 512 class would hold eight chunk masks in scalar registers it does not have)
+        // all positions of the read at once, a chunk per register: a payload is then peeled exactly once, where it first occurs,
+        // and counted in every later chunk in the same step -- no search for "seen in an earlier chunk" (a read's payloads span
+        // chunks: the chunk-by-chunk form below met each one about twice, and this step is mostly scalar instructions)
+        constexpr int KP = (U + 63) / 64;
+        uint32_t pv[KP];
+        uint64_t rm[KP];
+#pragma unroll
+        for (int c = 0; c < KP; ++c) {
+            const uint32_t i = (uint32_t)c * 64 + lane;
+            pv[c] = i < nscan ? upay[i] : 0u;
+            rm[c] = __ballot(pv[c] != 0u);
+        }
+        uint32_t dp_reg = 0, dm_reg = 0;
+#pragma unroll
+        for (int c0 = 0; c0 < KP; ++c0) {
+            while (rm[c0] && !many) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pv[c0], __builtin_ctzll(rm[c0]));
+                uint32_t cn = 0;
+#pragma unroll
+                for (int c = c0; c < KP; ++c) {
+                    const uint64_t m = __ballot(pv[c] == v);
+                    cn += (uint32_t)popc64(m);
+                    rm[c] &= ~m;
+                }
+                if (ndist >= 64) { many = true; break; }
+                if ((uint32_t)lane == ndist) { dp_reg = v; dm_reg = cn; }
+                ++ndist;
+            }
+        }
+        if (!many) {
+            if ((uint32_t)lane < ndist) { dpay[lane] = dp_reg; dmult[lane] = (uint16_t)dm_reg; }  // overlay the (dead) k-mer arrays
+            WSYNC();
+        }
+    } else {
         uint32_t dp_reg = 0, dm_reg = 0;
         for (uint32_t i0 = 0; i0 < nscan && !many; i0 += 64) {
             const uint32_t i = i0 + lane;
