@@ -1763,12 +1763,12 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     // packed little-endian, so the 2k-bit window w has base p in its low bits: the reference's
     // "reverse" is ~w and its "forward" is the pair-reversal of w.  `other` = the strand that is not canonical.
     auto window = [&](uint32_t p, uint64_t& canon, uint64_t& other, bool& fwd_canon) -> bool {
+        // funnel shifts (v_alignbit_b32: one instruction per output word, shift 0 included) instead of 64-bit shifts and a branch
         const uint32_t mb = p >> 5, ms = p & 31;
-        const uint64_t m2 = ((uint64_t)vmask[mb + 1] << 32) | vmask[mb];
-        const bool ok = ((uint32_t)(m2 >> ms) & wmask) == wmask;
+        const bool ok = (__builtin_amdgcn_alignbit(vmask[mb + 1], vmask[mb], ms) & wmask) == wmask;
         const uint32_t wb = (2 * p) >> 5, ws = (2 * p) & 31;
-        const uint64_t lo = ((uint64_t)codes[wb + 1] << 32) | codes[wb];
-        uint64_t w = ws ? ((lo >> ws) | ((uint64_t)codes[wb + 2] << (64 - ws))) : lo;
+        const uint32_t c0 = codes[wb], c1 = codes[wb + 1], c2 = codes[wb + 2];
+        uint64_t w = ((uint64_t)__builtin_amdgcn_alignbit(c2, c1, ws) << 32) | __builtin_amdgcn_alignbit(c1, c0, ws);
         w &= kmask;
         const uint64_t rev = (~w) & kmask;
         uint64_t f = __builtin_bitreverse64(w);
@@ -1811,7 +1811,11 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         const uint32_t p = p0 + lane;
         uint64_t km = 0, kr = 0;
         bool fc = false;
-        const bool ok = (CPT ? p < P + (uint32_t)(kCptW - 1) : p < P) && window(p, km, kr, fc);  // false past P: the record's tail is zero
+        // compact path: every lane runs its window -- one that starts past the last k-mer runs into the record's zero tail and is
+        // invalid by itself, and the m-mers of positions P .. P + 2 are wanted anyway (lanes beyond hold garbage nobody reads)
+        bool ok;
+        if constexpr (CPT) ok = window(p, km, kr, fc);
+        else ok = p < P && window(p, km, kr, fc);
         const uint64_t V = __ballot(ok);
         valid_kmers += popc64(V);
         uint32_t h = 0, t = 0;
@@ -2066,7 +2070,6 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             if ((uint32_t)c * 64 >= P) break;
             const uint64_t V = okm[c];
             const uint64_t V1 = (V << 1) | (Vp >> 63), V2 = (V << 2) | (Vp >> 62), V3 = (V << 3) | (Vp >> 61);  // lane - d is valid
-            const bool ok = lane_bit(V);
             const uint32_t b = hreg[c];
             const uint32_t sig = (uint32_t)(kreg[c] ^ (kreg[c] >> 17));
             const uint32_t q = (uint32_t)c * 64 + lane + (treg[c] >> 30);  // where the k-mer's minimizer starts in the read
@@ -2075,14 +2078,19 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps1, (int)sig, 0x138, 0xf, 0xf, false);
             const uint32_t s2 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps2, (int)s1, 0x138, 0xf, 0xf, false);
             const uint32_t s3 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps3, (int)s2, 0x138, 0xf, 0xf, false);
-            bool hit = ok && ((lane_bit(V1) && sig == s1) || (lane_bit(V2) && sig == s2) || (lane_bit(V3) && sig == s3));
-            if (ok && !(lane_bit(V1) && b == bprev && q == qprev)) {  // opens a group
+            // lane masks, combined on the scalar side: a ballot of `a && b` goes through a 0/1 register and a compare, a ballot of
+            // one compare is the compare
+            uint64_t hitm = V & ((V1 & __ballot(sig == s1)) | (V2 & __ballot(sig == s2)) | (V3 & __ballot(sig == s3)));
+            const uint64_t openm = V & ~(V1 & __ballot(b == bprev) & __ballot(q == qprev));  // lanes that open a group
+            uint32_t both = 0;
+            if (lane_bit(openm)) {
                 const uint32_t h1 = b & 2047u, h2 = (b >> 11) & 2047u;
                 const unsigned int oa = __hip_atomic_fetch_or(&bloomA[h1 >> 5], 1u << (h1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const unsigned int ob = __hip_atomic_fetch_or(&bloomB[h2 >> 5], 1u << (h2 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                hit |= ((oa >> (h1 & 31)) & (ob >> (h2 & 31)) & 1u) != 0;
+                both = (oa >> (h1 & 31)) & (ob >> (h2 & 31)) & 1u;
             }
-            seen |= __ballot(hit);
+            hitm |= __ballot(both != 0u);
+            seen |= hitm;
             pb = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
             pq = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
             ps1 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 63);
@@ -2156,18 +2164,18 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
       }
       nov = 0;
     };
-    auto probe_chunk = [&](uint32_t p0, uint64_t km, uint32_t b, uint32_t tag, bool ok, bool first) {
+    auto probe_chunk = [&](uint32_t p0, uint64_t km, uint32_t b, uint32_t tag, uint64_t okmask, uint64_t firstmask) {
         const uint32_t p = p0 + lane;
-        const uint64_t V1 = __ballot(ok) << 1;  // lane - 1 holds a valid k-mer (lane 0 always opens a group)
+        const uint64_t V1 = okmask << 1;  // lane - 1 holds a valid k-mer (lane 0 always opens a group)
         const uint32_t bprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xf, 0xf, false);  // wave_shr:1
-        const bool leader = ok && !(lane_bit(V1) && b == bprev);
-        const uint64_t lm = __ballot(leader);
+        const uint64_t lm = okmask & ~(V1 & __ballot(b == bprev));  // leaders (masks combined on the scalar side, as in the filter)
+        const bool leader = lane_bit(lm);
         const uint32_t ng = (uint32_t)popc64(lm);
         const uint32_t gidx = prefix_count(lm) + (leader ? 1u : 0u) - 1u;  // group of this lane (ok lanes): leaders at or below it, minus one
         if (leader) gbkt[gidx] = b;
         WSYNC();
         uint32_t pay = 0;
-        bool spill = false;
+        uint32_t spillw = 0;  // the bucket's last word where the k-mer is not in it: bit 31 = the bucket spilled
         // the groups' buckets, 32 per round of loads (a chunk of a genome read has ~26 groups: one round)
         for (uint32_t g0 = 0; g0 < ng; g0 += 32) {
 #pragma unroll
@@ -2183,7 +2191,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
             __builtin_amdgcn_s_waitcnt(0);
             WSYNC();
-            if (ok && gidx - g0 < 32u) {
+            if (lane_bit(okmask & __ballot(gidx - g0 < 32u))) {
                 const LAS uint32_t* bk = stage + (gidx - g0) * 16;
                 const u32x4 t0 = *(const LAS u32x4*)bk;
                 const uint32_t t4 = bk[4], t5 = bk[5];
@@ -2202,17 +2210,17 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     const uint32_t slot = 2 * (bit & 15u) + (bit >> 4);
                     pay = (uint32_t)((const LAS uint16_t*)bk)[12 + slot] | ((uint32_t)((const LAS uint8_t*)bk)[48 + slot] << 16);
                 } else {
-                    spill = (bk[15] & kCptOvfFlag) != 0;
+                    spillw = bk[15];
                 }
             }
             if (g0 + 32 < ng) WSYNC();  // the next round overwrites the stage
         }
-        if (p < P) upay[p] = first ? pay : 0u;
-        const bool pend = first && spill;
-        const uint64_t pm = __ballot(pend);
+        static_assert(kCptOvfFlag == 0x80000000u, "the spill flag is the sign bit");
+        if (p < P) upay[p] = lane_bit(firstmask) ? pay : 0u;
+        const uint64_t pm = firstmask & __ballot((int32_t)spillw < 0);
         if (pm) {
             if (nov + (uint32_t)popc64(pm) > 64u) { WSYNC(); ovf_pass(); WSYNC(); }  // the list holds 64 entries: one chunk's worth
-            if (pend) olist[nov + prefix_count(pm)] = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, tag | (p << 16)};
+            if (lane_bit(pm)) olist[nov + prefix_count(pm)] = u32x4{(uint32_t)km, (uint32_t)(km >> 32), b, tag | (p << 16)};
             nov += (uint32_t)popc64(pm);
         }
         WSYNC();
@@ -2226,7 +2234,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 WSYNC();
                 continue;
             }
-            probe_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c] & 0xFFFFu, lane_bit(okm[c]), lane_bit(firstm[c]));
+            probe_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c] & 0xFFFFu, okm[c], firstm[c]);
         }
     } else {
         for (uint32_t p0 = 0; p0 < P; p0 += 64) {
@@ -2240,8 +2248,9 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 cpt_address(*(const CptGeom*)&tb.cpt, km, kr, b, t);
                 first = (uint32_t)(hv[lds_find(hv, L::H - 1, km)] & 0xFFFF) == p;
             }
-            nuniq += (uint32_t)popc64(__ballot(first));
-            probe_chunk(p0, km, b, t, ok, first);
+            const uint64_t fm = __ballot(first);
+            nuniq += (uint32_t)popc64(fm);
+            probe_chunk(p0, km, b, t, __ballot(ok), fm);
         }
     }
     if (nov) { ovf_pass(); WSYNC(); }
