@@ -944,11 +944,14 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     const int stop = Ap->prm.stop_after;   // 30..33: timing experiments (the step ends early with a placeholder record)
     if (Ap->nm.active || (stop != 0 && (stop < 30 || stop > 34))) return false;
     auto placeholder = [&]() {
-        if (lane == 0) {
-            lmat_read_result q;
-            q.status = LMAT_ST_SILENT; q.match_type = LMAT_MT_NOMATCH; q.cand_kmer_cnt = (uint16_t)cand; q.valid_kmers = valid_kmers; q.read_len = (int)len;
-            q.log_avg = 0; q.stdev = 0; q.call_tid = 0; q.call_score = 0; q.cand_off = 0; q.n_cand = 0; q.bin_sel = bin_sel;
-            store_result(out, q);
+        if (lane == 0) {  // (on a zero the compiler cannot see through, as classify_one's emit: constant words would sit in registers across the read loop)
+            uint32_t z = 0;
+            asm volatile("" : "+v"(z));
+            out[0] = (uint64_t)(z + ((uint32_t)LMAT_ST_SILENT | ((uint32_t)LMAT_MT_NOMATCH << 8) | (cand << 16))) | ((uint64_t)(uint32_t)valid_kmers << 32);
+            out[1] = (uint64_t)len | ((uint64_t)z << 32);
+            out[2] = (uint64_t)z | ((uint64_t)z << 32);
+            out[3] = (uint64_t)z | ((uint64_t)z << 32);
+            out[4] = (uint64_t)z | ((uint64_t)(uint32_t)bin_sel << 32);
         }
         return true;
     };
@@ -957,7 +960,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     if (Ap->cands && !Ap->prm.prn_all) return false;  // candidates wanted, but without -p: a multi match prints the lineage as built (:917-927) -- the general path's job (bin/run_rl.sh always passes -p)
     const bool act = (uint32_t)lane < nT;
     const uint32_t dep = act ? (fz.w & 0xFFFFu) : 0u, fl = act ? (fz.w >> 16) : 0u;
-    if (bal(my_cnt > cand || dep > 0x7FFFu || (hbias != 0.0f && (fl & kFlagHuman)))) return false;  // (a bias of 0 adds 0 * stdev: nothing)
+    if (bal(my_cnt > cand) | bal(dep > 0x7FFFu) | (hbias != 0.0f ? bal((fl & kFlagHuman) != 0) : 0ull)) return false;  // (a bias of 0 adds 0 * stdev: nothing)
     float* xs = (float*)xch;      // [64] scores by slot (stay: a registered ancestor's score is read from here)
     uint32_t* xk = xch + 64;      // [64] sort keys by array position; later the taxid of every sorted position
     uint32_t* xx = xch + 128;     // [128] exchange buffer of a partition step; later the Euler intervals by sorted position
@@ -2581,11 +2584,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             atomicMin(&hent[h], t | ((0x8000u | (uint32_t)lane) << 16));
         }
         WSYNC();
-        const bool isnew = act && (hent[h] >> 16) == (0x8000u | (uint32_t)lane);
-        const uint64_t nm_ = __ballot(isnew);
+        const uint64_t nm_ = __ballot(e < nel) & __ballot((hent[h] >> 16) == (0x8000u | (uint32_t)lane));  // (idle lanes read entry 0: harmless)
         const uint32_t newcnt = popc64(nm_);
         if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
-        if (isnew) {
+        if (lane_bit(nm_)) {
             const uint32_t s = nT + prefix_count(nm_);
             hent[h] = t | (s << 16);
             reg[s] = (uint16_t)t; stamp[s] = 0xFFFF;
@@ -2792,11 +2794,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 atomicMin(&hent[h], a | ((0x8000u | (uint32_t)lane) << 16));
             }
             WSYNC();
-            const bool isnew = act && (hent[h] >> 16) == (0x8000u | (uint32_t)lane);
-            const uint64_t nm_ = __ballot(isnew);
+            const uint64_t nm_ = __ballot(i < W) & __ballot((hent[h] >> 16) == (0x8000u | (uint32_t)lane));
             const uint32_t newcnt = popc64(nm_);
             if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
-            if (isnew) {
+            if (lane_bit(nm_)) {
                 const uint32_t s = nT + prefix_count(nm_);
                 hent[h] = a | (s << 16);
                 reg[s] = (uint16_t)a;
@@ -2822,7 +2823,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 todo &= todo - 1;
                 const uint32_t tin_x = (uint32_t)__builtin_amdgcn_readlane((int)tin_s, sx);
                 const uint32_t tout_x = (uint32_t)__builtin_amdgcn_readlane((int)tout_s, sx);
-                const uint64_t am = __ballot(sl_act && tin_s < tin_x && tout_x <= tout_s);
+                const uint64_t am = __ballot(tin_s < tin_x) & __ballot(tout_x <= tout_s);  // (idle slots hold tin 0xFFFF: never below)
                 if (lane == sx) { anc_lo = (uint32_t)am; anc_hi = (uint32_t)(am >> 32); }
             }
             // (3b) lane d = position set d (at most 64 of them here): the slots it keeps, and the ancestors of its eligible ids
