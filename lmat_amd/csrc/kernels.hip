@@ -1765,7 +1765,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     // canonical k-mer of the window starting at base p (read_label.cpp:992-1009).  Bases are
     // packed little-endian, so the 2k-bit window w has base p in its low bits: the reference's
     // "reverse" is ~w and its "forward" is the pair-reversal of w.  `other` = the strand that is not canonical.
-    auto window = [&](uint32_t p, uint64_t& canon, uint64_t& other, bool& fwd_canon) -> bool {
+    // windowfr: the two strands as they are (forward, reverse complement); window: ordered (canonical, other)
+    auto windowfr = [&](uint32_t p, uint64_t& fwd, uint64_t& rc) -> bool {
         // funnel shifts (v_alignbit_b32: one instruction per output word, shift 0 included) instead of 64-bit shifts and a branch
         const uint32_t mb = p >> 5, ms = p & 31;
         const bool ok = (__builtin_amdgcn_alignbit(vmask[mb + 1], vmask[mb], ms) & wmask) == wmask;
@@ -1773,10 +1774,18 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         const uint32_t c0 = codes[wb], c1 = codes[wb + 1], c2 = codes[wb + 2];
         uint64_t w = ((uint64_t)__builtin_amdgcn_alignbit(c2, c1, ws) << 32) | __builtin_amdgcn_alignbit(c1, c0, ws);
         w &= kmask;
-        const uint64_t rev = (~w) & kmask;
-        uint64_t f = __builtin_bitreverse64(w);
-        f = ((f & 0x5555555555555555ull) << 1) | ((f >> 1) & 0x5555555555555555ull);
-        f >>= (64 - 2 * k);
+        rc = (~w) & kmask;
+        // pair-reversal: reverse the bits of each word (the words swap places), then swap the two bits of every base --
+        // (m & a) | (~m & b) is one v_bfi_b32 -- and bring the 2k bits down from the top
+        auto pairswap = [](uint32_t t) -> uint32_t { return (0xAAAAAAAAu & (t << 1)) | (~0xAAAAAAAAu & (t >> 1)); };
+        const uint32_t fh = pairswap(__builtin_bitreverse32((uint32_t)w)), fl = pairswap(__builtin_bitreverse32((uint32_t)(w >> 32)));
+        const uint32_t sh = 64u - 2u * (uint32_t)k;  // 24 at k = 20; k >= 16 here (the compact path's k is 10..20: see below)
+        fwd = (((uint64_t)fh << 32) | fl) >> sh;
+        return ok;
+    };
+    auto window = [&](uint32_t p, uint64_t& canon, uint64_t& other, bool& fwd_canon) -> bool {
+        uint64_t f, rev;
+        const bool ok = windowfr(p, f, rev);
         canon = f < rev ? f : rev;
         other = f < rev ? rev : f;
         fwd_canon = f < rev;
@@ -1799,7 +1808,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     for (int c = 0; c < (CACHE ? CH : 1); ++c) {
         if (CACHE) { kreg[c] = 0; hreg[c] = 0; treg[c] = 0; okm[c] = 0; }
     }
-    const bool want_gc = A.nm.active != 0;
+    const uint32_t want_gc = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.nm.active);  // (a scalar, not a lane mask)
     // compact layout: the minimizer of a k-mer is the smallest of the 4 m-mers it covers, and neighbouring k-mers
     // share 3 of them, so every lane scrambles ONE m-mer -- the one starting at its own position -- and the window
     // minimum runs over the lanes (cpt_finish).  u = scrambled canonical m-mer << 4 | (reverse strand is the smaller)
@@ -1817,14 +1826,18 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         // compact path: every lane runs its window -- one that starts past the last k-mer runs into the record's zero tail and is
         // invalid by itself, and the m-mers of positions P .. P + 2 are wanted anyway (lanes beyond hold garbage nobody reads)
         bool ok;
-        if constexpr (CPT) ok = window(p, km, kr, fc);
-        else ok = p < P && window(p, km, kr, fc);
+        uint64_t f = 0, rv = 0;
+        if constexpr (CPT) {
+            ok = windowfr(p, f, rv);
+            fc = f < rv;
+            km = fc ? f : rv;
+            if (!CACHE) kr = fc ? rv : f;
+        } else ok = p < P && window(p, km, kr, fc);
         const uint64_t V = __ballot(ok);
         valid_kmers += popc64(V);
         uint32_t h = 0, t = 0;
         if (!CPT) { if (ok) h = lds_min_insert(hv, L::H - 1, km, p); }
         else if (CACHE) {
-            const uint64_t f = fc ? km : kr, rv = fc ? kr : km;
             const uint64_t x = f >> (2 * (kCptW - 1)), xr = rv & ((1ull << (2 * cm)) - 1);  // the m-mer at p and its reverse complement
             u_out = (cpt_scramble(x < xr ? x : xr, cm) << 4) | (xr < x ? 2u : 0u) | (x == xr ? 1u : 0u);
             fc_out = __ballot(fc);
