@@ -1569,22 +1569,24 @@ __global__ __launch_bounds__(256) void tail_kernel(ClassifyArgs A) {
     const DeviceTables& tb = A.tb;
     const int k = tb.k;
     const uint64_t off = A.rec_off[r];
-    const uint32_t len = A.words[off];
+    const uint32_t p = 128u + j;
+    const uint32_t wb = (2 * p) >> 5, ws = (2 * p) & 31;
+    // the code words are asked for together with the length (the buffer is padded: reading past a short record is harmless, and
+    // what lies past this record's code words is replaced by zero below) -- one round trip fewer before the bucket's address
+    const uint32_t* codes = A.words + off + 1;
+    const uint32_t len = A.words[off], cr0 = codes[wb], cr1 = codes[wb + 1], cr2 = codes[wb + 2];
     if ((int)len < k) return;
     const uint32_t P = len - k + 1;
     if (P <= 128u || P > 128u + LPR) return;
-    const uint32_t p = 128u + j;
     const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
-    const uint32_t* codes = A.words + off + 1;
     const uint32_t* vmask = codes + nb;
-    auto cw = [&](uint32_t i) -> uint64_t { return i < nb ? codes[i] : 0u; };   // the record's tail reads as zero, as in the classify wave's copy
+    auto cw = [&](uint32_t i) -> uint64_t { const uint32_t v = i == wb ? cr0 : (i == wb + 1 ? cr1 : cr2); return i < nb ? v : 0u; };   // the record's tail reads as zero, as in the classify wave's copy
     auto vw = [&](uint32_t i) -> uint64_t { return i < nm ? vmask[i] : 0u; };
     // the window at p (classify_one's `window`)
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t wmask = (1u << k) - 1;
     const uint32_t mb = p >> 5, ms = p & 31;
     const uint64_t m2 = (vw(mb + 1) << 32) | vw(mb);
-    const uint32_t wb = (2 * p) >> 5, ws = (2 * p) & 31;
     const uint64_t lo = (cw(wb + 1) << 32) | cw(wb);
     uint64_t w = ws ? ((lo >> ws) | (cw(wb + 2) << (64 - ws))) : lo;
     w &= kmask;
@@ -2727,21 +2729,18 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         const uint32_t f_poff = fz.x, f_plen = fz.y & 0xFFFFu, f_sp = fz.y >> 16, f_fl = (fz.w >> 16) & 0xFFu, f_iv = fz.z;
         const uint32_t my_id = sl_p1 ? (uint32_t)reg[lane] : 0u;
         // representative strain per species, one vote per kept id
-        if (!PERM && sl_p1 && (f_fl & kFlagStrain) && f_sp) {
-            const uint32_t h = tid_find_or_claim(hent, THM, f_sp);
-            atomicMax(&best[h], ((uint32_t)leaf[lane] << 16) | (0xFFFFu - my_id));
+        uint32_t hs = 0;  // where the species of this lane's strain sits in the hash (kept for the check below: one search, not two)
+        const uint64_t STR = PERM ? 0ull : (__ballot((uint32_t)lane < nT) & __ballot((f_fl & kFlagStrain) != 0) & __ballot(f_sp != 0));
+        if (lane_bit(STR)) {
+            hs = tid_find_or_claim(hent, THM, f_sp);
+            atomicMax(&best[hs], ((uint32_t)leaf[lane] << 16) | (0xFFFFu - my_id));
         }
         WSYNC();
         // which kept ids take part in the closure (:1184-1190): everything but strains, and of the strains the representative
-        bool es = false;
-        if (!PERM && sl_p1) {
-            if (!(f_fl & kFlagStrain)) es = true;
-            else if (f_sp) {
-                const int h = tid_find(hent, THM, f_sp);
-                es = h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - my_id);
-            }
-        }
-        const uint64_t ES = __ballot(es);
+        const uint32_t bh = best[hs];  // (lanes without a strain read entry 0: unused)
+        const uint64_t ES = PERM ? 0ull
+                                 : ((__ballot((uint32_t)lane < nT) & ~__ballot((f_fl & kFlagStrain) != 0)) |
+                                    (STR & __ballot(bh != 0u) & __ballot((bh & 0xFFFFu) == (0xFFFFu - my_id))));
         WSYNC();  // leaf and best are dead from here
         unsigned int* first = best;  // per slot: its first eligible element
         if (sl_p1) { s_tin[lane] = (uint16_t)(f_iv & 0xFFFFu); s_tout[lane] = (uint16_t)(f_iv >> 16); }
