@@ -3357,33 +3357,48 @@ __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_
     // scratch block of the compact-layout probe: always real LDS
     LAS unsigned char* xl = (LAS unsigned char*)(U > 2048 ? lds_smem : lds_smem + WL<U, T, E, INK4, CPT>::OFF_XL);
     const int lane = threadIdx.x & 63;
-    const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
-    const GAS uint32_t* index = (const GAS uint32_t*)A.index;
-    const GAS uint64_t* rec_off = (const GAS uint64_t*)A.rec_off;
-    const GAS uint32_t* words = (const GAS uint32_t*)A.words;
-    auto r_of = [&](uint64_t it) -> uint64_t { return index ? (uint64_t)index[it] : A.first + it; };
     // Software pipeline over the reads of this wave: the record offset is fetched two reads ahead and the
     // record words one read ahead, so a read never starts with a chain of dependent HBM round trips.
+    // What the loop needs from the kernel arguments (read count, list and record pointers) is read again in every trip -- scalar
+    // loads from the argument segment -- instead of being carried across classify_one, where every carried scalar is one more
+    // value spilled to a lane of a vector register around the decision step (the kernel has 78 scalar registers).
     constexpr int NW = (WL<U, T, E, INK4, CPT>::RD_WORDS + 1 + 63) / 64;
-    const uint64_t G = gridDim.x;
-    uint64_t it = blockIdx.x;
-    if (it >= count) return;
+    const uint32_t G = gridDim.x;
+    uint32_t it = blockIdx.x;
     uint32_t wcur[NW], wnext[NW];
     uint32_t nmacc[2] = {0, 0};
-    const uint64_t off0 = rec_off[r_of(it)];
-    uint64_t off1 = it + G < count ? rec_off[r_of(it + G)] : 0;
+    uint64_t off1 = 0;
+    {
+        const uint64_t count = A.count_ptr ? (uint64_t)*(const GAS uint32_t*)A.count_ptr : A.count;
+        if (it >= count) return;
+        const GAS uint32_t* index = (const GAS uint32_t*)A.index;
+        const GAS uint64_t* rec_off = (const GAS uint64_t*)A.rec_off;
+        const GAS uint32_t* words = (const GAS uint32_t*)A.words;
+        auto r_of = [&](uint64_t i) -> uint64_t { return index ? (uint64_t)index[i] : A.first + i; };
+        const uint64_t off0 = rec_off[r_of(it)];
+        off1 = (uint64_t)it + G < count ? rec_off[r_of((uint64_t)it + G)] : 0;
 #pragma unroll
-    for (int j = 0; j < NW; ++j) wcur[j] = words[off0 + lane + 64 * j];  // may run past the record: the buffer is padded
-    while (it < count) {
-        const uint64_t off2 = it + 2 * G < count ? rec_off[r_of(it + 2 * G)] : 0;
+        for (int j = 0; j < NW; ++j) wcur[j] = words[off0 + lane + 64 * j];  // may run past the record: the buffer is padded
+    }
+    while (true) {
+        CArgs* Ap = (CArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(Ap));  // (a fresh look at the arguments every trip: nothing derived from them is carried around the loop)
+        const uint64_t count = Ap->count_ptr ? (uint64_t)*(const GAS uint32_t*)Ap->count_ptr : Ap->count;  // (it < count here: checked before the first trip and by `more` after that)
+        const GAS uint32_t* index = (const GAS uint32_t*)Ap->index;
+        const GAS uint64_t* rec_off = (const GAS uint64_t*)Ap->rec_off;
+        const GAS uint32_t* words = (const GAS uint32_t*)Ap->words;
+        auto r_of = [&](uint64_t i) -> uint64_t { return index ? (uint64_t)index[i] : Ap->first + i; };
+        const uint64_t off2 = (uint64_t)it + 2 * (uint64_t)G < count ? rec_off[r_of((uint64_t)it + 2 * (uint64_t)G)] : 0;
+        const bool more = (uint64_t)it + G < count;
 #pragma unroll
-        for (int j = 0; j < NW; ++j) wnext[j] = it + G < count ? words[off1 + lane + 64 * j] : 0u;
-        classify_one<U, T, E, INK4, PERM, CPT>((CArgs*)__builtin_amdgcn_kernarg_segment_ptr(), r_of(it), smem, xl, lane, wcur, nmacc);
+        for (int j = 0; j < NW; ++j) wnext[j] = more ? words[off1 + lane + 64 * j] : 0u;
+        classify_one<U, T, E, INK4, PERM, CPT>(Ap, r_of(it), smem, xl, lane, wcur, nmacc);
         WSYNC();
 #pragma unroll
         for (int j = 0; j < NW; ++j) wcur[j] = wnext[j];
         off1 = off2;
-        it += G;
+        if (!more) break;
+        it += G;  // (below count <= 2^32 - 1: no wrap)
     }
     if (lane == 0) {  // ReadTooShort / NoDbHits counts of this wave's reads, one atomic each
         GAS unsigned long long* tally_nomatch = (GAS unsigned long long*)A.counts + 2 * (uint64_t)A.tb.n_ids;
