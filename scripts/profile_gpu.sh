@@ -3,7 +3,7 @@
 # (gpurun refuses --pmc together with sys/runtime traces).  Output under gpurun_out/prof_<tag>/.
 set -o pipefail
 TAG=${1:-r01}
-ARGS=${2:-"--no-cpu --steps 10 --warmup 2"}
+ARGS=${2:-"--no-cpu --no-e2e --steps 10 --warmup 2"}  # (--no-e2e: the streamed leg launches the same kernel over batches of 2 M reads, which would mix two launch sizes into one average)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
