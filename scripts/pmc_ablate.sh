@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for s in ${STOPS:-1 2 3 4 5 6 0}; do
   OUT=$ROOT/gpurun_out/pmc_ab/s$s; mkdir -p $OUT
-  LMAT_STOP_AFTER=$s rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT -o p -- python3 $ROOT/bench.py --no-cpu --steps 2 --warmup 1 --batch 1000000 > /dev/null 2>&1
+  LMAT_STOP_AFTER=$s rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT -o p -- python3 $ROOT/bench.py --no-cpu --no-e2e --windows 0 --steps 2 --warmup 1 --batch 1000000 $BENCH_EXTRA > /dev/null 2>&1
   python3 - <<PY
 import csv, collections
 agg=collections.defaultdict(list)
