@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--reads", type=int, default=2000000)
     ap.add_argument("--threads", type=int, default=8, help="-t: output shards / formatting threads")
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--repeat", type=int, default=1, help="the FASTA file concatenated this many times (a longer steady state without generating more reads)")
     ap.add_argument("--only", default=None, help="run only the flag set whose label contains this text")
     a = ap.parse_args()
     from lmat_amd import synth
@@ -30,6 +31,15 @@ def main():
         info["n_reads"] = a.reads
         json.dump(info, open(cache, "w"))
     gen_s = time.time() - t0
+    if a.repeat > 1:
+        big = os.path.join(d, f"reads_x{a.repeat}.fa")
+        if not os.path.exists(big):
+            with open(big, "wb") as o:
+                blob = open(info["fasta"], "rb").read()
+                for _ in range(a.repeat):
+                    o.write(blob)
+        info["fasta"] = big
+        info["n_reads"] = info["n_reads"] * a.repeat
     csrc = os.path.join(ROOT, "lmat_amd", "csrc")
     img = os.path.join(d, "db.img")
     subprocess.run([os.path.join(csrc, "make_db_image"), "-i", info["db"], "-o", img, "-k", "20", "-f", info["idmap"]],
