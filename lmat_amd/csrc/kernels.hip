@@ -78,42 +78,59 @@ __device__ __forceinline__ uint32_t hash32(uint64_t x) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K0: ASCII -> packed records.  One wave per read, one base per lane and step (coalesced 64-byte loads): the 2-bit
-// codes of 16 neighbouring lanes are OR-ed into a word with row-wide DPP shifts, the validity bits of all 64 lanes
-// are one ballot.
+// K0: ASCII -> packed records.  Four reads per wave, a lane per code word: 16 bases read as five aligned dwords, funnel-
+// shifted to the read's byte offset and translated four at a time inside a register (letter tests as zero-byte tests, the
+// 2-bit code from bits 1..2 of the letter).  A base per lane (round 2) was 3 steps of ~40 instructions for a 150 bp read;
+// this is one step of ~150 for four reads.  The input buffer is padded by 32 bytes (the dword holding a read's last base).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t z) {  // 0x80 in every byte of z that is zero, 0 elsewhere (exact)
+    const uint32_t t = (z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | z | 0x7F7F7F7Fu);
+}
 __global__ __launch_bounds__(256) void pack_reads_kernel(const uint8_t* __restrict__ bases,
                                                          const uint64_t* __restrict__ off,
                                                          const uint64_t* __restrict__ rec_off,
                                                          uint32_t* __restrict__ words, uint64_t n) {
     const int lane = threadIdx.x & 63;
+    const uint32_t sub = (uint32_t)lane & 15u;   // this lane's code word within a stretch of 256 bases
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    for (uint64_t r = wave; r < n; r += nw) {
-        const uint64_t b0 = off[r];
-        const uint32_t len = (uint32_t)(off[r + 1] - b0);
-        uint32_t* rec = words + rec_off[r];
-        if (lane == 0) rec[0] = len;
+    for (uint64_t r0 = wave * 4; r0 < n; r0 += nw * 4) {
+        const uint64_t r = r0 + ((uint32_t)lane >> 4);
+        const bool have = r < n;
+        const uint64_t b0 = have ? off[r] : 0;
+        const uint32_t len = have ? (uint32_t)(off[r + 1] - b0) : 0u;
+        uint32_t* rec = words + (have ? rec_off[r] : 0);
+        if (have && sub == 0) rec[0] = len;
         const uint32_t nb = (len + 15) / 16;
-        for (uint32_t p0 = 0; p0 < len; p0 += 64) {
-            const uint32_t p = p0 + lane;
-            uint32_t t = 4;
+        for (uint32_t p0 = 0; __ballot(p0 < len) != 0; p0 += 256) {
+            const uint32_t p = p0 + 16u * sub;
+            uint32_t code = 0, valid16 = 0;
             if (p < len) {
-                const uint32_t ch = bases[b0 + p] & 0xDFu;  // ENCODE is case-insensitive (read_label.cpp:943-950)
-                t = ch == 'A' ? 0u : (ch == 'C' ? 1u : (ch == 'G' ? 2u : (ch == 'T' ? 3u : 4u)));
+                const uint64_t addr = b0 + p, a4 = addr & ~3ull, end = b0 + len;
+                const uint32_t sh = (uint32_t)(addr & 3) * 8u;
+                const uint32_t* src = (const uint32_t*)(bases + a4);
+                uint32_t d[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) d[q] = a4 + 4u * q < end ? src[q] : 0u;  // only dwords that hold a base of this read
+                const uint32_t left = len - p;  // bases from p on (16 or more: the whole word)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t w = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
+                    if (left < 4u * q + 4u) w &= left > 4u * q ? (1u << (8u * (left - 4u * q))) - 1u : 0u;  // bytes past the read's end
+                    const uint32_t x = w & 0xDFDFDFDFu;  // ENCODE is case-insensitive (read_label.cpp:943-950)
+                    const uint32_t vm = zero_bytes(x ^ 0x41414141u) | zero_bytes(x ^ 0x43434343u) | zero_bytes(x ^ 0x47474747u) | zero_bytes(x ^ 0x54545454u);
+                    const uint32_t v1 = vm >> 7;  // 1 per valid byte
+                    // A 0x41 -> 0, C 0x43 -> 1, G 0x47 -> 2, T 0x54 -> 3: bits 1..2 of the letter, the upper one folded onto the lower
+                    const uint32_t c2 = (((x >> 1) & 0x03030303u) ^ ((x >> 2) & 0x01010101u)) & (v1 * 3u);
+                    code |= ((c2 | (c2 >> 6) | (c2 >> 12) | (c2 >> 18)) & 0xFFu) << (8 * q);
+                    valid16 |= ((v1 | (v1 >> 7) | (v1 >> 14) | (v1 >> 21)) & 0xFu) << (4 * q);
+                }
+                if ((p >> 4) < nb) rec[1 + (p >> 4)] = code;
             }
-            const bool ok = t < 4;
-            uint32_t code = ok ? t << (2 * (lane & 15)) : 0u;
-            // OR over each row of 16 lanes: row_shr 8, 4, 2, 1 (lanes without a source keep 0)
-            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x118, 0xf, 0xf, false);
-            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x114, 0xf, 0xf, false);
-            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x112, 0xf, 0xf, false);
-            code |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)code, 0x111, 0xf, 0xf, false);
-            const uint32_t w = (p0 >> 4) + ((uint32_t)lane >> 4);
-            if ((lane & 15) == 15 && w < nb) rec[1 + w] = code;   // the last lane of a row holds the row's OR
-            const uint64_t v = __ballot(ok);
-            if (lane == 0) rec[1 + nb + (p0 >> 5)] = (uint32_t)v;
-            if (lane == 32 && p0 + 32 < len) rec[1 + nb + (p0 >> 5) + 1] = (uint32_t)(v >> 32);
+            // a validity word covers 32 bases: this lane's 16 bits and its odd neighbour's
+            const uint32_t other = (uint32_t)__shfl_xor((int)valid16, 1);
+            if (p < len && (sub & 1u) == 0) rec[1 + nb + (p >> 5)] = valid16 | (other << 16);
         }
     }
 }
@@ -3431,9 +3448,18 @@ static int grid_for(uint64_t n, int per_block, int cap) {
     return (int)b;
 }
 
+// a batch of equal-length reads laid end to end: both offset arrays follow from the length (nothing to copy in)
+__global__ __launch_bounds__(256) void fill_offsets_kernel(uint64_t* __restrict__ off, uint64_t* __restrict__ rec_off, uint64_t n,
+                                                           uint32_t len, uint32_t words_per_rec) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) { off[i] = i * len; rec_off[i] = i * words_per_rec; }
+}
+void launch_fill_offsets(uint64_t* off, uint64_t* rec_off, uint64_t n, uint32_t len, hipStream_t stream) {
+    fill_offsets_kernel<<<dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream>>>(off, rec_off, n, len, rec_words(len));
+}
 void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t* rec_off, uint32_t* words, uint64_t n,
                        hipStream_t stream) {
-    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(n, 4, 8192)), dim3(256), 0, stream, bases, off, rec_off, words, n);
+    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(n, 16, 16384)), dim3(256), 0, stream, bases, off, rec_off, words, n);  // 4 waves x 4 reads per block and pass
 }
 void launch_insert_pairs(const DeviceTables& tb, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
                          uint32_t* fail, hipStream_t stream) {

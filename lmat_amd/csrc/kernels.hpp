@@ -54,6 +54,7 @@ static const int kK4RecWords = 2 + kK4T;
 enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8, kErrNoNullModel = 16 };
 
 // launchers (all asynchronous on `stream`)
+void launch_fill_offsets(uint64_t* off, uint64_t* rec_off, uint64_t n, uint32_t len, hipStream_t stream);  // off[i] = i * len, rec_off[i] = i * rec_words(len), i = 0..n
 void launch_pack_reads(const uint8_t* bases, const uint64_t* off, const uint64_t* rec_off, uint32_t* words, uint64_t n,
                        hipStream_t stream);
 void launch_insert_pairs(const DeviceTables& tb, const uint64_t* kmers, const uint32_t* payload, uint64_t n,
