@@ -124,19 +124,20 @@ def cpu_baseline(eng, reads, n_sample, k, tmpdir):
         dt = time.perf_counter() - t0
         return n * reps / dt, dt, reps
 
-    n1 = max(n_sample // 8, 1000)
-    r1, s1, _ = rate(1, n1, 5.0)                # T = 1 on an eighth of the sample (~5 s)
+    n1 = max(n_sample // 24, 1000)
+    r1, s1, _ = rate(1, n1, 5.0)                # T = 1 on a slice of the sample (~5 s)
     rn, sn, reps = rate(threads, n_sample, 10.0)  # T = N (~10 s)
     orc.close()
+    # the host table: one unordered_map node per k-mer (key + vector header + link + allocator overhead, ~64 B) plus the heap
+    # block of its list (>= 32 B): what a pass over the sample walks, against the caches of the host
+    n_tab = int(kms.size)
+    table_bytes = n_tab * 96.0
     ratio, ratio_from = None, None   # oracle / reference on the reference's own retrieve_kmer_labels, measured in the build container
-    try:
-        ratio = json.load(open(os.path.join(ROOT, "profiles", "r03_ref_ratio.json")))["geomean_port_over_reference"]
-        ratio_from = "profiles/r03_ref_ratio.json (scripts/ref_ratio.py: src/rkmer.hpp compiled in place vs the oracle, same reads, one thread)"
-    except Exception:
-        pass
     return {"value": rn, "unit": "reads/s", "cores": threads, "kind": "port", "t1_reads_per_s": r1, "tN_reads_per_s": rn,
             "port_over_reference": ratio, "reference_equivalent_reads_per_s": rn / ratio if ratio else None, "port_over_reference_from": ratio_from,
             "cpu": info,
+            "table": f"host-resident std::unordered_map of {n_tab} k-mers with their taxid lists, ~{table_bytes / 2**30:.2f} GiB of nodes and list blocks "
+                     "(every pass walks all of it: larger than the L2/L3 a thread sees, so lookups miss to DRAM; the 64 GiB table itself is not copied to the host)",
             "sample": f"first {n_sample} reads of the same synthetic workload x {reps} passes at T={threads} ({sn:.1f} s), first {n1} reads at "
                       f"T=1 ({s1:.1f} s); CPU oracle (oracle/lmat_oracle.hpp, a restatement of read_label's proc_line -- the reference's "
                       "read_label.cpp does not build in this image; port_over_reference is for the part that does); k-mer table = host hash "
@@ -191,10 +192,13 @@ def e2e_stream(eng, reads, batch, steps, warmup, log):
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: N fresh rank processes, one per GPU, started by THIS process, which
     never imports torch or touches HIP itself (a parent that had could not safely start GPU children).  Each child gets the
-    environment a launcher would set; rank 0's stdout (the JSON line) is this process's stdout."""
+    environment a launcher would set; rank 0's stdout (the JSON line) is this process's stdout.  The children are watched
+    together: the first one that exits non-zero (out of memory, a HIP error) takes the others -- which would wait for it in a
+    collective for ever -- down with it; LMAT_BENCH_TIMEOUT_S bounds the whole run."""
     import socket
     import subprocess
-    with socket.socket() as so:
+    with socket.socket() as so:  # (a free port at this moment; rank 0 binds it again a few seconds later)
+        so.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
@@ -205,10 +209,50 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    deadline = time.monotonic() + float(os.environ.get("LMAT_BENCH_TIMEOUT_S", "3000"))
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = max(rc, abs(code))
+        if (rc or time.monotonic() > deadline) and live:
+            if not rc:
+                rc = 124
+                print(f"bench.py: ranks still running after LMAT_BENCH_TIMEOUT_S: stopping them", file=sys.stderr)
+            for p in live:   # exactly the processes started above
+                p.terminate()
+            t_end = time.monotonic() + 10
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            live = []
+        if live:
+            time.sleep(0.05)
     return rc
+
+
+def plan_steps(args, world):
+    """Reads per step and per launch of one rank.  Weak scaling (default): --batch reads per rank and step whatever the
+    number of ranks.  --total-reads N (strong scaling, BASELINE config 4 "50M reads sharded across 8"): the job's N reads are
+    split evenly over the ranks -- contiguous shares, as read_label splits its input -- and a rank's share over --steps steps.
+    A step is a whole number of launches of --launch-reads reads (args.batch is rounded up to that).  -> strong?"""
+    strong = args.total_reads > 0
+    if strong:
+        per_rank = (args.total_reads + world - 1) // world
+        args.batch = max(1, (per_rank + args.steps - 1) // args.steps)
+    args.launch_reads = max(1, min(args.launch_reads, args.batch))
+    lps = (args.batch + args.launch_reads - 1) // args.launch_reads
+    if strong:  # even launches: the step's reads split over its launches instead of a last short one
+        args.launch_reads = (args.batch + lps - 1) // lps
+    args.batch = lps * args.launch_reads
+    return strong
 
 
 def main():
@@ -220,7 +264,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8_000_000, help="reads per step per GPU (rounded up to whole launches)")
     ap.add_argument("--launch-reads", type=int, default=8_000_000, help="reads per classify launch: a step is batch / launch-reads launches (default: one launch per step; rounds 1-3 quoted launches of 2 M: --launch-reads 2000000)")
     ap.add_argument("--read-len", default="150", help="read length, or a comma list for a mixed-length batch (not the headline workload)")
-    ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--cpu-sample", type=int, default=120000, help="reads of the CPU baseline's sample (120 k reads = 15.7 M distinct k-mers = ~1.4 GiB of host table: DRAM-missing)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--list-replicas", type=int, default=1, help="copies of every distinct taxid list in the arena, one per 512-base stretch of a genome (5: 4 M lists, 250 MB -- the most 24-bit payloads address)")
     ap.add_argument("--genus-permille", type=int, default=100, help="share of every genome that is a block shared within its genus (SURVEY 8d: 100)")
@@ -229,6 +273,9 @@ def main():
     ap.add_argument("--as-ranks", type=int, default=1, help="tests: ONE rank classifies the read sets of this many ranks one after the other (what an N-rank run must add up to)")
     ap.add_argument("--tally-out", default=None, help="tests: rank 0 writes the merged per-taxid tallies to this JSON file")
     ap.add_argument("--genome-len", type=int, default=0, help="bases per strain genome (default: sized so that the table holds ~6.4 k-mers per bucket)")
+    ap.add_argument("--total-reads", type=int, default=0, help="STRONG scaling (BASELINE config 4: `50M reads sharded across 8`): this many reads in total, split evenly over the ranks and over --steps steps (overrides --batch; `scaling` becomes \"strong\")")
+    ap.add_argument("--no-cands", action="store_true", help="skip the value_with_candidates leg (the same window with -p: candidate pairs written, as bin/run_rl.sh runs it)")
+    ap.add_argument("--cands-per-read", type=int, default=32, help="capacity of the candidate buffer of the -p leg, pairs per read")
     ap.add_argument("--spawn-check", action="store_true", help="tests: every rank prints the environment it was started with and exits before touching a GPU")
     args = ap.parse_args()
 
@@ -240,6 +287,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.spawn_check:
+        if os.environ.get("LMAT_SPAWN_CHECK_FAIL") == str(rank):   # tests: this rank dies, the others would wait for ever
+            sys.exit(3)
+        if os.environ.get("LMAT_SPAWN_CHECK_FAIL") is not None:
+            time.sleep(120)
         print(json.dumps({"rank": rank, "world": world, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR"),
                           "torch_loaded_in_parent": "torch" in sys.modules}), file=sys.stderr if rank else sys.stdout)
         return
@@ -277,10 +328,8 @@ def main():
     eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes, genus_block_permille=args.genus_permille, list_replicas=args.list_replicas)
     t_build = time.perf_counter() - t0
     log(f"db built: {eng.db_size} k-mers in {t_build:.2f}s, table {table_bytes / 2**30:.1f} GiB, G={G}")
-    # a step = one pass of the path over one batch of --batch reads, classified as launches of --launch-reads reads each
-    args.launch_reads = max(1, min(args.launch_reads, args.batch))
-    lps = (args.batch + args.launch_reads - 1) // args.launch_reads  # launches per step
-    args.batch = lps * args.launch_reads
+    strong = plan_steps(args, world)
+    lps = args.batch // args.launch_reads  # launches per step
     n_steps_total = args.steps + args.warmup
     n_reads = args.batch * n_steps_total
     read_lens = tuple(int(x) for x in str(args.read_len).split(","))
@@ -297,18 +346,30 @@ def main():
         # Should the engine's communicator not come up on some rank (a library that does not load, an IPC setting), every rank
         # falls back to the same all-reduce through torch.distributed (backend "nccl" = RCCL as well) on the same buffers in
         # HBM: the run still measures the path; the line says which merge it used.
+        # Pre-flight first, so that no rank can enter ncclCommInitRank while another never will: every rank checks that
+        # librccl and its entry points load (rank 0 also makes the id), all ranks agree on that (MIN), and only then is the id
+        # broadcast -- by ALL ranks, whatever happened -- and the communicator made.
+        uid = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
         ok = 1
         try:
-            uid = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            if not Engine.comm_available():
+                raise RuntimeError("librccl or one of its entry points did not load")
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(Engine.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, src=0)
-            eng.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
         except Exception as e:  # noqa: BLE001
             ok = 0
-            log(f"engine communicator failed on rank {rank}: {e}")
+            print(f"[bench] rank {rank}: engine communicator unavailable: {e}", file=sys.stderr, flush=True)
         flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            dist.broadcast(uid, src=0)
+            try:
+                eng.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                print(f"[bench] rank {rank}: lmat_comm_init failed: {e}", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         merge_path = "engine_rccl" if int(flag.item()) == 1 else "torch_rccl"
         log(f"tally merge across {world} ranks: {merge_path}")
 
@@ -380,6 +441,30 @@ def main():
         eng.sync()
         barrier()
         win.append(args.batch * args.steps * world / reduce_max(time.perf_counter() - t0))
+    # The same window as `value`, as bin/run_rl.sh:243 runs read_label: with -p, every read's candidate (taxid, score) pairs
+    # written next to its record (8 bytes per pair on top of the algorithmic bytes).  Same steps, same barriers.
+    with_cands = None
+    if not args.no_cands:
+        eng.set_params(Params.run_rl(prn_all=1))
+        cap = args.launch_reads * max(args.cands_per_read, 1)
+
+        def run_step_c(step):
+            for l_ in range(lps):
+                eng.classify_async_cands(reads, (step * lps + l_) * args.launch_reads, args.launch_reads, cap)
+
+        run_step_c(0)
+        eng.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            run_step_c(args.warmup + s)
+        c_kernel_ms, c_launches = eng.sync()
+        c_classify_ms, _, _ = eng.last_timing()
+        barrier()
+        c_dt = reduce_max(time.perf_counter() - t0)
+        tail = eng.fetch_results(0, min(args.launch_reads, 1_000_000))   # records of the last launch: pairs written per read
+        with_cands = {"dt": c_dt, "classify_ms": c_classify_ms, "launches": c_launches, "pairs_per_read": float(tail["n_cand"].mean())}
+        eng.set_params(Params.run_rl(prn_all=0))
     if rank == 0:
         counts, nomatch = merged
         called = sum(c for c, _ in counts.values())
@@ -417,10 +502,10 @@ def main():
             "metric": "reads/s (150 bp) vs 64 GB k-mer DB", "value": value, "unit": "reads/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / (args.steps * args.as_ranks) * 1e3,
             "value_median_of_windows": float(np.median(win)) if win else None, "windows": [round(x) for x in win],
-            "higher_is_better": True, "scaling": "weak", "tally_merge": ("gloo_rehearsal" if rehearse and dist is not None else merge_path), "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "tally_merge": ("gloo_rehearsal" if rehearse and dist is not None else merge_path), "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.batch * args.steps} x {args.read_len} bp reads/GPU vs {args.db_gb:g} GiB "
                                    f"k-mer hash ({eng.db_size} 20-mers, replicated per GPU), run_rl.sh flags -x 0 -j 30 -l 0 -b 1, calls-only",
-                       "reads_per_step_per_gpu": args.batch, "launches_per_step": lps, "reads_per_launch": args.launch_reads, "read_len": args.read_len, "db_gib": args.db_gb,
+                       "total_reads": args.batch * args.steps * world * args.as_ranks, "reads_per_step_per_gpu": args.batch, "launches_per_step": lps, "reads_per_launch": args.launch_reads, "read_len": args.read_len, "db_gib": args.db_gb,
                        "db_kmers": eng.db_size, "k": k, "parallelism": f"reads sharded x{world}, DB replicated",
                        "db_build_s": round(t_build, 2), "genus_block_permille": args.genus_permille, "list_replicas": args.list_replicas, "distinct_lists": eng.n_lists, "list_arena_mib": round(eng.arena_bytes / 2**20, 1), "reads_called": called, "nomatch": nomatch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -433,6 +518,15 @@ def main():
                          "kernel_avg_ms": avg_ms, "kernel_ms_per_2M_reads": avg_ms * 2e6 / args.launch_reads, "step_ms_per_launch": step_ms, "step_ms_per_2M_reads": step_ms * 2e6 / args.launch_reads, "tail_kernels_event_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.launch_reads,
                          "random_64B_gather_ceiling_GBs": gather_gbs},
         }
+        if with_cands:
+            c_avg = with_cands["classify_ms"] / max(with_cands["launches"], 1)
+            c_bytes = mean_b + 8.0 * with_cands["pairs_per_read"]
+            out["value_with_candidates"] = {
+                "value": args.batch * args.steps * world / with_cands["dt"], "unit": "reads/s", "ms_per_step": with_cands["dt"] / args.steps * 1e3,
+                "pairs_per_read": with_cands["pairs_per_read"], "algorithmic_bytes_per_read": c_bytes, "kernel_avg_ms": c_avg,
+                "roofline_frac": c_bytes * args.launch_reads / (c_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "what": "the window of `value` again with -p (prn_all = 1): every read's candidate (taxid, score) pairs written to a device "
+                        f"buffer of {args.cands_per_read} pairs per read, as bin/run_rl.sh:243 runs read_label; +8 B per pair in the byte count"}
         if world == 1 and not args.no_e2e and len(read_lens) == 1:
             e2e_batch = min(args.launch_reads, 2_000_000)  # the streamed boundary in batches of 2 M reads (3 pinned slots of 300 MB)
             per_step = max(1, args.batch // e2e_batch)

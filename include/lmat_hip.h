@@ -202,6 +202,11 @@ int lmat_classify(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64
  * buffer holds the records of the most recent launch only (lmat_results_fetch reads those); the
  * tallies accumulate over all launches. */
 int lmat_classify_async(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count);
+/* The same with the candidate pairs of `-p` (read_label.cpp:898-910; bin/run_rl.sh:243 always passes -p) written to a
+ * device-side buffer of cand_cap pairs (grown on demand, one per set of in-flight buffers); lmat_read_result.cand_off /
+ * n_cand index it.  cand_cap = 0: calls only, as lmat_classify_async.  A buffer that proves too small raises
+ * LMAT_E_CAPACITY at the next lmat_sync. */
+int lmat_classify_async_cands(lmat_ctx* ctx, const lmat_reads* reads, uint64_t first, uint64_t count, uint64_t cand_cap);
 int lmat_sync(lmat_ctx* ctx, float* kernel_ms_total, uint64_t* kernel_launches);
 /* HIP-event times accumulated by the launches the last lmat_sync waited for, split per kernel:
  * classify_ms = classify_kernel (extract + probe + registration/closure, the HBM-bound kernel),
@@ -259,6 +264,9 @@ int lmat_counts_allreduce(lmat_ctx** ctxs, int n_ctx);
  * (ncclAllReduce on the context's stream, u64 counts / f64 score sums / u64 nomatch; returns when it is complete).
  * librccl is opened on first use of these entry points, never by a one-GPU run. */
 #define LMAT_COMM_ID_BYTES 128
+/* 1 when librccl and every entry point the engine uses could be loaded in this process (a pre-flight every rank runs BEFORE
+ * any rank enters lmat_comm_init, so that a rank without the library cannot leave the others waiting inside it), else 0. */
+int lmat_comm_available(void);
 int lmat_comm_unique_id(uint8_t* id /* [LMAT_COMM_ID_BYTES] */);
 int lmat_comm_init(lmat_ctx* ctx, const uint8_t* id, int n_ranks, int rank);
 int lmat_comm_allreduce_counts(lmat_ctx* ctx);

@@ -97,6 +97,8 @@ def load_library(path: str | None = None):
         "lmat_reads_free": (None, [vp, vp]),
         "lmat_classify": (i32, [vp, vp, u64, u64, vp, vp, u64, P(u64)]),
         "lmat_classify_async": (i32, [vp, vp, u64, u64]),
+        "lmat_classify_async_cands": (i32, [vp, vp, u64, u64, u64]),
+        "lmat_comm_available": (i32, []),
         "lmat_sync": (i32, [vp, P(C.c_float), P(u64)]),
         "lmat_last_timing": (i32, [vp, P(C.c_float), P(C.c_float), P(u64)]),
         "lmat_results_fetch": (i32, [vp, u64, u64, vp]),
@@ -143,7 +145,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_ingest_lookup", "lmat_db_from_ingest", "lmat_nullmodel_load", "lmat_nullmodel_clear", "lmat_set_label_modes",
             "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_synth_db_build2", "lmat_reads_upload",
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
-            "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
+            "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_classify_async_cands", "lmat_comm_available", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
@@ -470,6 +472,11 @@ class Engine:
         n = len(reads) - first if count is None else count
         self._chk(self.lib.lmat_classify_async(self.ctx, reads.h, first, n))
 
+    def classify_async_cands(self, reads: Reads, first=0, count=None, cand_cap=0):
+        """As classify_async with the -p candidate pairs written to a device-side buffer of cand_cap pairs."""
+        n = len(reads) - first if count is None else count
+        self._chk(self.lib.lmat_classify_async_cands(self.ctx, reads.h, first, n, int(cand_cap)))
+
     def sync(self):
         ms, nl = C.c_float(0), C.c_uint64(0)
         self._chk(self.lib.lmat_sync(self.ctx, C.byref(ms), C.byref(nl)))
@@ -515,6 +522,11 @@ class Engine:
         return int(self.lib.lmat_counts_device_ptr(self.ctx) or 0)
 
     # tallies across ranks: RCCL inside the engine (collective.cpp) ---------------------
+    @staticmethod
+    def comm_available() -> bool:
+        """librccl and the entry points the engine uses load in this process (pre-flight before any rank enters comm_init)."""
+        return bool(load_library().lmat_comm_available())
+
     @staticmethod
     def comm_unique_id() -> bytes:
         """ncclGetUniqueId: 128 bytes made by one rank and handed to the others by the launcher's own channel."""

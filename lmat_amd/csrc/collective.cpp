@@ -52,6 +52,12 @@ Rccl& rccl() {
 int nccl_err(lmat_ctx* c, const char* what, ncclResult_t e) {
     return set_err(c, LMAT_E_DEVICE, std::string(what) + ": " + rccl().GetErrorString(e));
 }
+// Queued launches leave their last kernels -- which add to the tallies -- on the context's side streams (LMAT_PIPELINE): the
+// merge is ordered behind them here, whatever the caller did or did not wait for.
+void order_behind_launches(lmat_ctx* c) {
+    if (c->set_in_flight && c->ev_done) hipStreamWaitEvent(c->stream, c->ev_done, 0);
+    if (c->parked.in_flight && c->parked.done) hipStreamWaitEvent(c->stream, c->parked.done, 0);
+}
 // the three arrays of a tally buffer, queued on the context's stream (inside a group)
 ncclResult_t queue_tallies(Rccl& R, lmat_ctx* c, ncclComm_t comm) {
     const uint32_t ids = c->dev.n_ids;
@@ -75,6 +81,7 @@ int host_sum(lmat_ctx** ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         lmat_ctx* c = ctxs[i];
         hipSetDevice(c->device);
+        order_behind_launches(c);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(buf.data(), c->d_counts, bytes, hipMemcpyDeviceToHost) != hipSuccess)
             return set_err(c, LMAT_E_DEVICE, "copy of the tallies to the host failed");
         const uint64_t* bc = (const uint64_t*)buf.data();
@@ -102,6 +109,8 @@ void comm_free(lmat_ctx* c) {
 }  // namespace lmat
 
 extern "C" {
+
+int lmat_comm_available(void) { return rccl().ok ? 1 : 0; }
 
 int lmat_comm_unique_id(uint8_t* id) {
     if (!id) return LMAT_E_ARG;
@@ -136,6 +145,7 @@ int lmat_comm_allreduce_counts(lmat_ctx* c) {
     if (!c->comm_ranks) return set_err(c, LMAT_E_ARG, "lmat_comm_init first");
     Rccl& R = rccl();
     hipSetDevice(c->device);
+    order_behind_launches(c);
     ncclResult_t e = R.GroupStart();
     if (e == ncclSuccess) e = queue_tallies(R, c, (ncclComm_t)c->comm_ranks);
     const ncclResult_t e2 = R.GroupEnd();
@@ -182,6 +192,7 @@ int lmat_counts_allreduce(lmat_ctx** ctxs, int n) {
     ncclResult_t e = R.GroupStart();
     for (int i = 0; i < n && e == ncclSuccess; ++i) {
         hipSetDevice(ctxs[i]->device);
+        order_behind_launches(ctxs[i]);
         e = queue_tallies(R, ctxs[i], (ncclComm_t)ctxs[i]->comm_local);
     }
     const ncclResult_t e2 = R.GroupEnd();

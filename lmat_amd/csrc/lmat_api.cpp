@@ -586,6 +586,8 @@ int lmat_db_clone(lmat_ctx* d, lmat_ctx* s) {
     if (!d || !s || d == s) return LMAT_E_ARG;
     if (!s->db_ready) return set_err(d, LMAT_E_ARG, "the source context holds no finalized database");
     if (d->db_ready || d->ingest) return set_err(d, LMAT_E_ARG, "the destination already holds a database");
+    if (s->gene_mode)  // (a gene context is set up by lmat_genedb_begin, which opens an ingest: there is no empty gene context to clone into)
+        return set_err(d, LMAT_E_ARG, "lmat_db_clone replicates taxonomy databases only: build a gene database in each context");
     if (s->gene_mode != d->gene_mode || (!s->gene_mode && (!d->tax.loaded || d->tax.n != s->tax.n || d->tax.tid32 != s->tax.tid32)))
         return set_err(d, LMAT_E_TAXONOMY, "load the same taxonomy into the destination first");
     if (d->permissive != s->permissive || d->rt_tid_cut != s->rt_tid_cut || d->rand_mode != s->rand_mode)
@@ -1359,6 +1361,12 @@ int lmat_classify_async(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
     return run_classify(c, reads, first, count, false, 0, true, pipeline_on());
 }
 
+int lmat_classify_async_cands(lmat_ctx* c, const lmat_reads* reads, uint64_t first, uint64_t count, uint64_t cand_cap) {
+    if (!c || !reads) return LMAT_E_ARG;
+    if (!count) return LMAT_OK;
+    return run_classify(c, reads, first, count, cand_cap != 0, cand_cap, true, pipeline_on());
+}
+
 int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     if (!c) return LMAT_E_ARG;
     hipSetDevice(c->device);
@@ -1830,7 +1838,8 @@ static int stream_submit(lmat_stream* st, uint64_t n, uint64_t tag, const uint8_
     }
     // reads of one length (an untrimmed sequencer run): offsets and record offsets are i * length and i * words -- made on the
     // device, nothing computed here and 16 bytes per read less to copy in
-    const bool uniform = n > 0 && min_len == max_len;
+    // (the slot's own offsets may start anywhere -- the general path copies them as given --, i * length holds from 0 only)
+    const bool uniform = n > 0 && min_len == max_len && sl.h_off[0] == 0;
     if (!uniform) run_parts(pass2);
     sl.h_rec_off[n] = wbase[nt];
     lap("offsets done");

@@ -198,7 +198,8 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
 
 // Euler-tour intervals over the forest defined by paths[]: isAncestor (read_label.cpp:138-150, "a is on
 // b's getPathToRoot") becomes tin[a] < tin[b] && tout[b] <= tout[a] without touching memory per level.
-// Ids that are not tree nodes (empty path, nobody's ancestor) get the empty interval (0xFFFF, 0xFFFF).
+// Ids that are not tree nodes (empty path, nobody's ancestor) are trees of one node: an interval of one tick of their own,
+// numbered behind the real trees (every tin is unique; k4_wave's "related = the intervals intersect" relies on that).
 void build_euler_intervals(HostTaxonomy& T) {
     const uint32_t n = T.n;
     T.tin.assign(n + 1, 0xFFFF);

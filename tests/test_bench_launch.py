@@ -38,3 +38,30 @@ def test_parent_of_the_ranks_never_imports_torch():
     assert "torch" not in names and "lmat_amd" not in names
     body = src[src.index("def main()"):]
     assert body.index("spawn_ranks(args.gpus)") < body.index("import torch")
+
+
+def test_a_dead_rank_takes_the_others_down():
+    """One rank exits non-zero while its siblings would wait (in a collective) for ever: the parent stops them and fails."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--spawn-check"],
+                       env=dict(_env(), LMAT_SPAWN_CHECK_FAIL="1"), capture_output=True, text=True, timeout=100)
+    assert r.returncode == 3 and time.monotonic() - t0 < 60, (r.returncode, r.stderr)
+
+
+def test_step_plan_weak_and_strong():
+    """--total-reads N is strong scaling: N reads over the ranks and the steps; --batch is weak scaling."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    a = argparse.Namespace(total_reads=0, batch=8_000_000, launch_reads=8_000_000, steps=20)
+    assert bench.plan_steps(a, 8) is False and a.batch == 8_000_000 and a.launch_reads == 8_000_000
+    a = argparse.Namespace(total_reads=0, batch=30000, launch_reads=10000, steps=2)
+    assert bench.plan_steps(a, 2) is False and (a.batch, a.launch_reads) == (30000, 10000)
+    for world in (1, 2, 4, 8):   # BASELINE config 4: 50 M reads in all
+        a = argparse.Namespace(total_reads=50_000_000, batch=8_000_000, launch_reads=8_000_000, steps=20)
+        assert bench.plan_steps(a, world) is True
+        total = a.batch * a.steps * world
+        assert 50_000_000 <= total < 50_000_000 + 20 * world * 2 and a.batch % a.launch_reads == 0
+    a = argparse.Namespace(total_reads=400_000_000, batch=1, launch_reads=8_000_000, steps=10)   # a step of several launches
+    assert bench.plan_steps(a, 2) is True and 20_000_000 <= a.batch <= 20_000_002 and a.batch == 3 * a.launch_reads
