@@ -1248,8 +1248,20 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         if (Ap->cands) {
             GAS uint32_t* g_cursor = (GAS uint32_t*)Ap->cursor;
             const uint32_t reserve = nT;   // (-p: every candidate, best first)
+            const uint32_t chunk = Ap->cand_chunk;
             uint32_t coff = 0;
-            if (lane == 0) coff = G_ADD(&g_cursor[0], reserve);
+            if (lane == 0) {
+                if (chunk) {  // from this workgroup's sub-cursor; an exhausted one takes the next chunk off the bump cursor (kernels.hpp)
+                    GAS unsigned long long* sub = (GAS unsigned long long*)(g_cursor + kCursorWords) + 8u * (__builtin_amdgcn_workgroup_id_x() & (uint32_t)(kCandSubs - 1));
+                    const unsigned long long v = __hip_atomic_fetch_add(sub, (unsigned long long)reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    coff = (uint32_t)v;
+                    if ((v & 0xFFFFFFFFull) + reserve > (v >> 32)) {
+                        // (two waves may get here at once: both take a chunk, the later store wins and the other chunk's rest stays unused)
+                        coff = G_ADD(&g_cursor[0], chunk);
+                        __hip_atomic_exchange(sub, (unsigned long long)(coff + reserve) | ((unsigned long long)(coff + chunk) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else coff = G_ADD(&g_cursor[0], reserve);
+            }
             coff = (uint32_t)__builtin_amdgcn_readfirstlane((int)coff);
             GAS uint64_t* co = nullptr;  // lmat_cand {tid, score}
             if ((uint64_t)coff + reserve <= Ap->cand_cap) co = (GAS uint64_t*)((GAS lmat_cand*)Ap->cands + coff);
@@ -3598,7 +3610,7 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     static const int gmult = getenv("LMAT_GRID_MULT") ? atoi(getenv("LMAT_GRID_MULT")) : 32;
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 32 ? 32 : per_cu)) * (gmult > 0 ? gmult : 32);
     if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)a.count;
-    if (a.count_ptr && INK4 && grid > 512) grid = 512;  // the lists of the large classes are short; the E = 512 class may get a tenth of a batch
+    if (a.count_ptr && INK4 && grid > 256 * (per_cu < 2 ? 2 : per_cu)) grid = 256 * (per_cu < 2 ? 2 : per_cu);  // the lists of the large classes are short (the E = 512 class may get a tenth of a batch): a block per wave the LDS holds
     if (grid < 1) grid = 1;
     classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
@@ -3630,6 +3642,13 @@ bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_clas
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
     if (tcap_class == 2) {  // reads whose kept lists add up to more than kFastE elements (many strains per k-mer): 512 of them
         if (P <= 160) LC(160, 64, 512, false); else LC(512, 64, 512, false);
+    } else if (tcap_class == 3) {
+        // the middle tier: up to 256 registered taxids / 1024 list elements, tables in LDS and the decision step on the wave's
+        // first lane like the large class, but in 37 KB instead of 148: four waves per CU instead of one, and room left for the
+        // fast classes beside it.  A near-capacity table returns chance hits for a read's erroneous k-mers (3.4 % of all 20-mers
+        // are in a table of 18.6 G), each with a lineage of its own: 1 % of config 5's reads pass 64 taxids that way.
+        if (P > 512) return false;
+        LC(512, 256, 1024, true);
     } else if (P <= 160 && tcap_class == 0) {
         LC(160, 64, kFastE, false);
     } else if (P <= 256) {

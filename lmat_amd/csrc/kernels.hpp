@@ -16,12 +16,13 @@ struct ClassifyArgs {
     lmat_read_result* results;
     lmat_cand* cands;          // may be null (calls-only)
     uint64_t cand_cap;
-    uint32_t* cursor;          // per-batch counters: [0] candidate bump cursor, [2..] list lengths
+    uint32_t* cursor;          // per-batch counters: [0] candidate bump cursor, [2..] list lengths; behind the 16 words: kCandSubs sub-cursors (64 B apart)
+    uint32_t cand_chunk = 0;   // pairs a sub-cursor takes from the bump cursor at a time (0: every read bumps the cursor itself)
     uint32_t* err;             // sticky error flags: launches only OR into the word
     void* counts;              // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint32_t phix_call_idx;    // internal index of 32630
     uint32_t* ovf_list;        // reads that exceed this launch's capacities are appended here (count in cursor[ovf_slot])
-    uint32_t ovf_slot;         // cursor word that counts ovf_list: 2 fast -> E=512 class, 3 -> large LDS class, 7 -> global-memory class
+    uint32_t ovf_slot;         // cursor word that counts ovf_list: 2 fast -> E=512 class, 3 -> middle tier, 10 -> large LDS class, 7 -> global-memory class
     const uint32_t* count_ptr; // when set, the number of `index` entries is read from device memory
     uint32_t* k4buf;           // per-read records handed from the fast classify kernel to the K4 kernels
     uint32_t* k4_small;        // read indices awaiting K4, small tables (count in cursor[4])
@@ -51,6 +52,14 @@ struct ClassifyArgs {
 static const int kK4T = 64;
 static const int kK4RecWords = 2 + kK4T;
 
+// Candidate space (-p): 8 M reads bumping ONE cursor word is 8 M atomics on one address, which the L2 serves one after the
+// other (~8 ns each: the fast class took 88 ms instead of 24).  The fast classes therefore allocate through kCandSubs
+// sub-cursors -- (next free pair | end of the chunk << 32), one per 64-byte line, picked by the workgroup's number -- each of
+// which takes cand_chunk pairs from the bump cursor at a time.
+static const int kCandSubs = 1024;
+static const int kCursorWords = 16;   // the counter block proper
+static const size_t kCursorBytes = kCursorWords * 4 + (size_t)kCandSubs * 64;
+
 enum { kErrTidOverflow = 1, kErrReadTooLong = 2, kErrCandOverflow = 4, kErrLineageTrunc = 8, kErrNoNullModel = 16 };
 
 // launchers (all asynchronous on `stream`)
@@ -68,7 +77,8 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
                    uint32_t stride, hipStream_t stream);
 // fills a.tail16 / a.tail_u for the reads of the launch (a.index / a.first, a.count; not for device-side counts)
 void launch_tail(const ClassifyArgs& a, hipStream_t stream);
-// tcap_class: 0 = fast (T=64, E=128), 2 = the same with E=512, 1 = large (T=1024).  Returns false if max_len exceeds every U class.
+// tcap_class: 0 = fast (T=64, E=256), 2 = the same with E=512, 3 = middle (T=256, E=1024, reads up to 531 bp), 1 = large (T=1024).
+// Returns false if max_len exceeds every U class of the tier.
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream);
 void launch_k4_begin(const ClassifyArgs& a, hipStream_t stream, hipStream_t stream2, hipStream_t stream3, hipStream_t small_stream,
                      hipEvent_t forked);

@@ -111,10 +111,10 @@ int lmat_ctx_create(int device, const lmat_params* params, lmat_ctx** out) {
     lmat_params def = {1.0f, 3.0f, 0.0f, 35, 1, 0, 1};
     c->params = params ? *params : def;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
-    if (hipMalloc((void**)&c->d_cursor, 64) != hipSuccess || hipMalloc((void**)&c->parked.d_cursor, 64) != hipSuccess ||
+    if (hipMalloc((void**)&c->d_cursor, kCursorBytes) != hipSuccess || hipMalloc((void**)&c->parked.d_cursor, kCursorBytes) != hipSuccess ||
         hipMalloc((void**)&c->d_err, 64) != hipSuccess) { delete c; return LMAT_E_DEVICE; }
-    hipMemset(c->d_cursor, 0, 64);
-    hipMemset(c->parked.d_cursor, 0, 64);
+    hipMemset(c->d_cursor, 0, kCursorBytes);
+    hipMemset(c->parked.d_cursor, 0, kCursorBytes);
     hipMemset(c->d_err, 0, 64);
     *out = c;
     return LMAT_OK;
@@ -128,7 +128,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
                     c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
-                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_tail, c->parked.d_tail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc,
+                    c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_ovf4, c->parked.d_ovf4, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_tail, c->parked.d_tail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc,
                     c->d_err, c->parked.d_results, c->parked.d_cands, c->parked.d_cursor, c->parked.d_ovf, c->parked.d_ovf2, c->parked.d_ovf3, c->parked.d_k4buf, c->parked.d_k4small,
                     c->parked.d_k4large, c->parked.d_k4bail};
     for (void* p : ptrs)
@@ -1032,9 +1032,11 @@ static int ensure_scratch(lmat_ctx* c, uint64_t count) {
         HIPCHK(c, hipMalloc((void**)&c->d_ovf, count * sizeof(uint32_t)));
         if (c->d_ovf2) hipFree(c->d_ovf2);
         if (c->d_ovf3) hipFree(c->d_ovf3);
-        c->d_ovf2 = c->d_ovf3 = nullptr;
+        if (c->d_ovf4) hipFree(c->d_ovf4);
+        c->d_ovf2 = c->d_ovf3 = c->d_ovf4 = nullptr;
         HIPCHK(c, hipMalloc((void**)&c->d_ovf2, count * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_ovf3, count * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_ovf4, count * sizeof(uint32_t)));
         c->ovf_cap = count;
     }
     return LMAT_OK;
@@ -1055,6 +1057,17 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     a.results = c->out_results ? c->out_results : c->d_results;
     a.cands = want_cands ? (c->out_cands ? c->out_cands : c->d_cands) : nullptr;
     a.cand_cap = cand_cap;
+    // Large candidate buffers are handed out through sub-cursors, a chunk at a time (kernels.hpp): at most kCandSubs chunks lie
+    // partly unused at the end of a launch, an eighth of the buffer in the worst case.  Small ones -- few reads, no contention --
+    // are bumped read by read as before.  (LMAT_CAND_CHUNK=0 turns the sub-cursors off.)
+    a.cand_chunk = 0;
+    if (want_cands && cand_cap <= 0x7FFFFFFFull) {   // (a sub-cursor's two halves are 32 bits wide each)
+        static const int forced = getenv("LMAT_CAND_CHUNK") ? atoi(getenv("LMAT_CAND_CHUNK")) : -1;
+        uint64_t ch = cand_cap / (8 * (uint64_t)kCandSubs);
+        ch = ch >= 2048 ? 2048 : (ch >= 1024 ? 1024 : (ch >= 512 ? 512 : (ch >= 256 ? 256 : 0)));
+        if (forced >= 0) ch = forced >= 64 ? (uint64_t)forced : 0;
+        a.cand_chunk = (uint32_t)ch;
+    }
     a.cursor = c->d_cursor;
     a.err = c->batch_err ? c->d_cursor + 15 : c->d_err;  // a streamed batch keeps its own flags (word 15 of the per-batch counter block)
     a.counts = c->out_counts ? c->out_counts : c->d_counts;
@@ -1087,7 +1100,7 @@ static void swap_sets(lmat_ctx* c) {
     auto& p = c->parked;
     std::swap(c->d_results, p.d_results); std::swap(c->results_cap, p.results_cap);
     std::swap(c->d_cands, p.d_cands); std::swap(c->cands_cap, p.cands_cap);
-    std::swap(c->d_cursor, p.d_cursor); std::swap(c->d_ovf, p.d_ovf); std::swap(c->d_ovf2, p.d_ovf2); std::swap(c->d_ovf3, p.d_ovf3);
+    std::swap(c->d_cursor, p.d_cursor); std::swap(c->d_ovf, p.d_ovf); std::swap(c->d_ovf2, p.d_ovf2); std::swap(c->d_ovf3, p.d_ovf3); std::swap(c->d_ovf4, p.d_ovf4);
     std::swap(c->d_k4buf, p.d_k4buf); std::swap(c->d_k4small, p.d_k4small); std::swap(c->d_k4large, p.d_k4large);
     std::swap(c->d_k4bail, p.d_k4bail); std::swap(c->ovf_cap, p.ovf_cap);
     std::swap(c->d_tail, p.d_tail); std::swap(c->tail_bytes, p.tail_bytes);
@@ -1126,7 +1139,7 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         HIPCHK(c, hipMalloc((void**)&c->d_gscratch, classify_gmem_scratch_bytes()));
     // per-launch counters: the candidate cursor [0] and the list lengths [2..]; the error word (d_err) is sticky -- launches
     // only OR into it and whoever reports it (lmat_sync, lmat_classify, lmat_rand_label) clears it
-    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, want_cands ? kCursorBytes : (size_t)kCursorWords * 4, c->stream));  // (the sub-cursors start empty: next free = end = 0)
     ClassifyArgs a = make_args(c, reads, first, count, want_cands, cand_cap);
     // Tails (tail_kernel): where the reads of the 160-k-mer class end a few positions past their second chunk -- 150 bp reads
     // at k = 20 have 131 -- those positions are looked up beforehand, 4, 8 or 16 lanes per read.  Compact layout, no null
@@ -1276,13 +1289,22 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         static const bool rerun_side = getenv("LMAT_RERUN_SIDE") && atoi(getenv("LMAT_RERUN_SIDE")) != 0;  // experiments
         hipStream_t rs = k4 && (pipelined || rerun_side) ? c->stream3 : c->stream;
         const bool lds_class = reads->max_len <= 2048 + 19;
+        static const bool mid_on = !getenv("LMAT_MID_TIER") || atoi(getenv("LMAT_MID_TIER")) != 0;  // (0: as before this tier existed, for A/B runs)
+        const bool mid_tier = mid_on && reads->max_len <= 512 + (uint32_t)c->dev.k - 1;
         ClassifyArgs b = a;
         b.index = c->d_ovf2;
         b.count_ptr = c->d_cursor + 3;
-        b.ovf_list = lds_class ? c->d_ovf3 : nullptr;  // the global-memory class is the last resort
-        b.ovf_slot = 7;
         b.count = 0;
         b.gscratch = c->d_gscratch;
+        if (mid_tier) {  // first the middle tier (256 taxids, 1024 list elements; four waves per CU), whose leftovers go on
+            b.ovf_list = c->d_ovf4;
+            b.ovf_slot = 10;
+            launch_classify(b, reads->max_len, 3, rs);
+            b.index = c->d_ovf4;
+            b.count_ptr = c->d_cursor + 10;
+        }
+        b.ovf_list = lds_class ? c->d_ovf3 : nullptr;  // the global-memory class is the last resort
+        b.ovf_slot = 7;
         launch_classify(b, reads->max_len, 1, rs);
         if (lds_class) {  // what even that class cannot hold goes to the global-memory class
             ClassifyArgs g = b;
@@ -1397,11 +1419,13 @@ int lmat_sync(lmat_ctx* c, float* kernel_ms_total, uint64_t* kernel_launches) {
     c->kernel2_ms_total = 0;
     c->kernel_launches = 0;
     if (getenv("LMAT_DEBUG")) {
-        uint32_t cur[6];
-        HIPCHK(c, hipMemcpy(cur, c->d_cursor, 24, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&cur[1], c->d_err, 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags (all launches since the last report) %u, reads re-run by the large class %u, "
-                        "by the global-memory class %u; K4 with small tables %u, with large tables %u\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5]);
+        uint32_t cur[16];
+        uint32_t err = 0;
+        HIPCHK(c, hipMemcpy(cur, c->d_cursor, 64, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&err, c->d_err, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[lmat] last launch: cand cursor %u, error flags (all launches since the last report) %u; reads passed on by the fast classes %u, "
+                        "by the E=512 class %u, by the middle tier (T=256) %u, by the large LDS class %u; general decision path: small tables %u, large %u\n",
+                cur[0], err, cur[2], cur[3], cur[10], cur[7], cur[4], cur[5]);
     }
     return report_device_errors(c, nullptr);  // flags of every launch since the last report, not just the last one
 }

@@ -164,6 +164,7 @@ struct lmat_ctx {
     uint32_t* d_k4buf = nullptr;   // records handed from the fast classify kernel to the K4 kernels
     uint32_t* d_ovf2 = nullptr;    // second overflow list: reads beyond the E=512 class
     uint32_t* d_ovf3 = nullptr;    // third: reads beyond the large LDS class
+    uint32_t* d_ovf4 = nullptr;    // reads beyond the middle tier (T = 256): the large LDS class takes them
     unsigned char* d_gscratch = nullptr;  // tables of the global-memory class, allocated on first use
     uint32_t* d_k4small = nullptr; // index lists of the reads awaiting K4 (k4_compact_kernel)
     uint32_t* d_k4large = nullptr;
@@ -180,7 +181,7 @@ struct lmat_ctx {
     struct BatchSet {
         lmat_read_result* d_results = nullptr; uint64_t results_cap = 0;
         lmat_cand* d_cands = nullptr; uint64_t cands_cap = 0;
-        uint32_t *d_cursor = nullptr, *d_ovf = nullptr, *d_ovf2 = nullptr, *d_ovf3 = nullptr, *d_k4buf = nullptr, *d_k4small = nullptr,
+        uint32_t *d_cursor = nullptr, *d_ovf = nullptr, *d_ovf2 = nullptr, *d_ovf3 = nullptr, *d_ovf4 = nullptr, *d_k4buf = nullptr, *d_k4small = nullptr,
                  *d_k4large = nullptr, *d_k4bail = nullptr;
         uint64_t ovf_cap = 0;
         unsigned char* d_tail = nullptr; uint64_t tail_bytes = 0;

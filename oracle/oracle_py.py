@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "liblmat_oracle.so")
+LIB = os.environ.get("LMAT_ORACLE_LIB") or os.path.join(_HERE, "liblmat_oracle.so")  # (LMAT_ORACLE_LIB: the sanitizer build, scripts/sanitize_cpu.sh)
 
 
 def build():
