@@ -146,6 +146,13 @@ int lmat_synth_db_build2(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t see
  * read from the device table.  *n = 0: no strain kept the window.  (The table itself may hold a different list for that k-mer
  * when another window yields the same 20-mer: about 1 % of them at 6.4 G k-mers; the smaller payload wins.) */
 int lmat_synth_window(lmat_ctx* ctx, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* tids, uint32_t cap, uint32_t* n);
+/* ... and for a synthetic READ: the k-mers read r of lmat_reads_synth(lengths, n_lengths, seed) must find, with their lists, derived
+ * on the host from the read generator and the genome generator alone -- every window that lies in the read's strain genome
+ * without a substituted base: the ancestor window's list where the strain carries it unmutated, else the strain alone.  Windows
+ * with an error, random and low-complexity reads yield nothing (what the table returns for those is a chance hit).
+ * kmers[cap], tids[cap][stride], counts[cap]; *n = windows written. */
+int lmat_synth_read_windows(lmat_ctx* ctx, const uint32_t* lengths, uint32_t n_lengths, uint64_t seed, uint64_t r, uint64_t* kmers,
+                            uint32_t* tids, uint32_t* counts, uint32_t cap, uint32_t stride, uint32_t* n, uint32_t* read_len);
 
 /* ---- gene databases (src/gene_label.cpp) ---------------------------------------------------
  * gene_label runs the same lookup against a database whose lists are 32-bit GENE ids (INDEXDB<uint32_t>, TaxNodeStat

@@ -3690,4 +3690,39 @@ void synth_window_host(const SynthGeo& g, int k, uint32_t species, uint64_t pos,
     *inblk = blk;
 }
 
+// What synth_reads_kernel makes of read r, re-derived on the host: its length, and for every k-mer window that lies in a genome
+// (a sampled read, kinds 11..99), holds no substituted base and not the N: where the window starts in the strain's genome (forward
+// coordinates) -- the caller asks synth_window_host what the database must hold there.  Returns the number of such windows.
+uint32_t synth_read_windows_host(const SynthGeo& g, const uint32_t* lengths, uint32_t n_lengths, uint64_t seed, uint64_t r, int k,
+                                 uint32_t* len_out, uint32_t* strain_global, uint64_t* gpos, uint32_t* rpos, uint32_t cap) {
+    const uint64_t h0 = splitmix(seed ^ (r * 0x9E3779B97F4A7C15ull));
+    const uint32_t len = lengths[(uint32_t)((h0 >> 48) % n_lengths)];
+    *len_out = len;
+    const uint32_t kind = (uint32_t)(h0 % 100);
+    const uint32_t sg = (uint32_t)((h0 >> 8) % ((uint64_t)g.n_species * g.S));
+    *strain_global = sg;
+    if (kind <= 10 || (int)len < k) return 0;  // random bases / low complexity: no genome behind the read
+    const uint64_t maxoff = g.G > len ? g.G - len : 0;
+    const uint64_t goff = (splitmix(h0) >> 4) % (maxoff + 1);
+    const bool rc = (h0 >> 40) & 1;
+    const uint32_t npos = (uint32_t)((splitmix(h0 ^ 77) >> 7) % len);
+    std::vector<uint8_t> bad(len, 0);
+    for (uint32_t p = 0; p < len; ++p) {
+        const uint64_t e = splitmix(h0 ^ ((uint64_t)p << 24) ^ 0xABCDEF);
+        const uint64_t gp = rc ? goff + (len - 1 - p) : goff + p;
+        bad[p] = (e % 100) == 0 || (kind == 11 && p == npos) || gp >= g.G;
+    }
+    uint32_t n = 0, run = 0;
+    for (uint32_t p = 0; p < len; ++p) {
+        run = bad[p] ? 0 : run + 1;
+        if (run >= (uint32_t)k && n < cap) {
+            const uint32_t p0 = p + 1 - (uint32_t)k;   // window start in the read
+            rpos[n] = p0;
+            gpos[n] = rc ? goff + (len - 1 - p) : goff + p0;  // ... and in the genome (the window's lowest coordinate)
+            ++n;
+        }
+    }
+    return n;
+}
+
 }  // namespace lmat

@@ -877,6 +877,58 @@ int lmat_synth_window(lmat_ctx* c, uint32_t species, uint64_t pos, uint64_t* kme
     return LMAT_OK;
 }
 
+// Test hook: the k-mers a synthetic read must find in the database, derived on the HOST from the two generators (reads and
+// genomes) alone.  For read r of lmat_reads_synth(lengths, seed): every window that lies in its strain's genome without a
+// substituted base or the N -> the canonical k-mer and the list the database must hold for it: the ancestor window's list
+// (lmat_synth_window) where the strain carries the window unmutated, else the strain alone (its own mutated copy was filed as a
+// singleton).  Windows with an error, random and low-complexity reads give nothing: whatever the table returns for those is a
+// chance hit.  tids: [cap][stride]; -> *n windows, *read_len.
+int lmat_synth_read_windows(lmat_ctx* c, const uint32_t* lengths, uint32_t n_lengths, uint64_t seed, uint64_t r, uint64_t* kmers,
+                            uint32_t* tids, uint32_t* counts, uint32_t cap, uint32_t stride, uint32_t* n, uint32_t* read_len) {
+    if (!c || !lengths || !n_lengths || !kmers || !tids || !counts || !n || !stride) return LMAT_E_ARG;
+    if (!c->synth_genome_len) return set_err(c, LMAT_E_ARG, "lmat_synth_db_build first");
+    const SynthGeo& g = c->synth_geo;
+    const int k = c->dev.k;
+    const HostTaxonomy& T = c->tax;
+    std::vector<uint64_t> gpos(cap);
+    std::vector<uint32_t> rpos(cap);
+    uint32_t len = 0, sg = 0;
+    const uint32_t nw = synth_read_windows_host(g, lengths, n_lengths, seed, r, k, &len, &sg, gpos.data(), rpos.data(), cap);
+    if (read_len) *read_len = len;
+    const uint32_t S = g.S, sp = sg / S;
+    for (uint32_t w = 0; w < nw; ++w) {
+        uint64_t km = 0;
+        uint32_t first = 0, mask = 0;
+        bool inblk = false;
+        synth_window_host(g, k, sp, gpos[w], &km, &first, &mask, &inblk);
+        uint32_t* out = tids + (size_t)w * stride;
+        uint32_t cnt = 0;
+        auto put = [&](uint32_t t) { if (cnt < stride) out[cnt] = t; ++cnt; };
+        if (mask & (1u << (sg - first))) {  // the strain carries the ancestor's window: its owners' list
+            const uint32_t ns = inblk ? g.spg * S : S;
+            uint32_t spmask = 0, owners = 0;
+            for (uint32_t s_ = 0; s_ < ns; ++s_)
+                if (mask & (1u << s_)) { put(T.tid32[c->synth_strain_idx[first + s_]]); spmask |= 1u << (s_ / S); ++owners; }
+            if (owners >= 2) {
+                const uint32_t sp0 = first / S;
+                for (uint32_t q = 0; q < (inblk ? g.spg : 1u); ++q)
+                    if (spmask & (1u << q)) put(T.tid32[c->synth_species_idx[sp0 + q]]);
+                if (__builtin_popcount(spmask) >= 2) put(T.tid32[T.paths[T.path_off[c->synth_species_idx[sp0]]]]);
+            }
+        } else {  // its own copy of the window, filed under the strain alone
+            uint64_t f = 0;
+            for (int j = 0; j < k; ++j) f = (f << 2) | synth_strain_base_host(g, sp, sg, gpos[w] + j);
+            const uint64_t rcw = revcomp_fwd(f, k);
+            km = f < rcw ? f : rcw;
+            put(T.tid32[c->synth_strain_idx[sg]]);
+        }
+        kmers[w] = km;
+        counts[w] = cnt;
+    }
+    *n = nw;
+    return LMAT_OK;
+}
+
 // ---------------------------------------------------------------------------------- reads
 // The fast kernel's capacity class follows the bulk of the batch, not its longest read: the length below which
 // 99 % of the reads fall; longer ones are re-run by a larger class through the device-side overflow list.
