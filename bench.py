@@ -56,12 +56,18 @@ def sample_algorithmic_bytes(eng, reads, n_sample, k):
                 b += 64.0 * km.size
         total += b
         bucket_only += b
+    probes = None
     if all_k:
         cat = np.concatenate(all_k)
         counts, _ = eng.lookup(cat, stride=1)
         multi = counts[counts > 1].astype(np.float64)
         total += float(np.sum(64.0 * np.ceil(2.0 * multi / 64.0)))
-    return total / n_sample, bucket_only / n_sample
+        probes = eng.probe_stats(cat)   # where these lookups end: the share that needs the overflow table is a second dependent request
+        n_all = max(sum(probes[x] for x in ("home_hit", "absent_one_request", "overflow_hit", "overflow_miss")), 1)
+        probes["lookups"] = n_all
+        probes["overflow_probe_share"] = (probes["overflow_hit"] + probes["overflow_miss"]) / n_all
+        probes["hits_found_in_overflow_share"] = probes["overflow_hit"] / max(probes["overflow_hit"] + probes["home_hit"], 1)
+    return total / n_sample, bucket_only / n_sample, probes
 
 
 def cpu_info():
@@ -472,7 +478,7 @@ def main():
             with open(args.tally_out, "w") as f:
                 json.dump({"n_gpus": world, "counts": {str(t): c for t, (c, _) in sorted(counts.items())},
                            "scores": {str(t): sc for t, (_, sc) in sorted(counts.items())}, "nomatch": nomatch}, f)
-        mean_b, mean_bucket = sample_algorithmic_bytes(eng, reads, 2000, k)
+        mean_b, mean_bucket, probes = sample_algorithmic_bytes(eng, reads, 2000, k)
         log(f"algorithmic bytes/read = {mean_b:.0f} (reads + one 64-B bucket per distinct k-mer + result: {mean_bucket:.0f})")
         avg_ms = classify_ms / max(launches, 1)  # dominant kernel only: classify_kernel (HBM-bound probe inside)
         achieved = mean_b * args.launch_reads / (avg_ms * 1e-3) / 1e9
@@ -516,7 +522,7 @@ def main():
                          "algorithmic_bytes_per_read_bucket_only": mean_bucket,
                          "kernel": "classify_kernel<160,64,256,false,false,true>",
                          "kernel_avg_ms": avg_ms, "kernel_ms_per_2M_reads": avg_ms * 2e6 / args.launch_reads, "step_ms_per_launch": step_ms, "step_ms_per_2M_reads": step_ms * 2e6 / args.launch_reads, "tail_kernels_event_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.launch_reads,
-                         "random_64B_gather_ceiling_GBs": gather_gbs},
+                         "random_64B_gather_ceiling_GBs": gather_gbs, "probe_ends": probes},
         }
         if with_cands:
             c_avg = with_cands["classify_ms"] / max(with_cands["launches"], 1)

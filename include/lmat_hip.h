@@ -140,6 +140,12 @@ int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed
 int lmat_synth_db_build2(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes,
                          uint32_t genus_block_permille, uint32_t list_replicas);
 
+/* Measurement hook: where the lookups of these (forward-encoded) k-mers end in the compact table -- out5[0] found in the home
+ * bucket, [1] absent and the bucket never spilled (one 64-byte request in all), [2] found in the overflow table, [3] absent after
+ * the overflow table was asked too, [4] overflow buckets read.  bench.py reports the share of a read sample's lookups that need
+ * the second request (`overflow_probe_share`). */
+int lmat_debug_probe_stats(lmat_ctx* ctx, const uint64_t* kmers, uint64_t n, uint64_t* out5);
+
 /* Test hook for the synthetic database: what it must hold for the window of `species` (0-based) that starts at base `pos` of the
  * species ancestor -- the canonical k-mer and its taxid list (the strains that carry the window unmutated; with two or more
  * owners also their species, and the genus when they span species) -- computed on the HOST from the generator's functions, never

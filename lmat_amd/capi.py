@@ -125,6 +125,7 @@ def load_library(path: str | None = None):
         "lmat_db_clone": (i32, [vp, vp]),
         "lmat_debug_decide": (i32, [vp, vp, vp, vp, vp, u64, vp]),
         "lmat_synth_window": (i32, [vp, u32, u64, P(u64), vp, u32, P(u32)]),
+        "lmat_debug_probe_stats": (i32, [vp, vp, u64, vp]),
         "lmat_synth_read_windows": (i32, [vp, vp, u32, u64, u64, vp, vp, vp, u32, u32, P(u32), P(u32)]),
         "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
@@ -150,7 +151,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
-            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_synth_window", "lmat_synth_read_windows"]
+            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_synth_window", "lmat_synth_read_windows", "lmat_debug_probe_stats"]
 
 
 def _ptr(a):
@@ -551,6 +552,13 @@ class Engine:
         t = np.zeros(32, dtype=np.uint32)
         self._chk(self.lib.lmat_synth_window(self.ctx, species, int(pos), C.byref(km), _ptr(t), 32, C.byref(n)))
         return int(km.value), t[:n.value].tolist()
+
+    def probe_stats(self, kmers):
+        """-> dict: where the lookups of these k-mers end (home bucket / absent at once / overflow hit / overflow miss, overflow buckets read)."""
+        km = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros(5, dtype=np.uint64)
+        self._chk(self.lib.lmat_debug_probe_stats(self.ctx, _ptr(km), km.size, _ptr(out)))
+        return dict(zip(("home_hit", "absent_one_request", "overflow_hit", "overflow_miss", "overflow_buckets_read"), (int(x) for x in out)))
 
     def synth_read_windows(self, lengths, seed, r, cap=512, stride=32):
         """-> (kmers uint64[n], counts uint32[n], tids uint32[n, stride]) read r of synth_reads(lengths, seed) must find (host-derived)."""

@@ -460,6 +460,38 @@ __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmer
     for (uint32_t j = 0; j < nr && j < stride; ++j) tids[i * stride + j] = tb.conv[tb.arena[eoff + kListHdr + 2 * nk + j]];
 }
 
+// Where a lookup ends (measurement only): out[0] found in the home bucket, out[1] absent and the bucket never spilled (one
+// request), out[2] found in the overflow table, out[3] absent after the overflow table was asked as well; out[4] = overflow
+// buckets read in all.  One thread per k-mer; compact layout.
+__global__ void probe_stats_kernel(DeviceTables tb, const uint64_t* __restrict__ kmers, uint64_t n, unsigned long long* out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !tb.cpt.nb) return;
+    const uint64_t kmer = kmers[i], rc = revcomp_fwd(kmer, tb.cpt.k);
+    uint32_t b, tag;
+    cpt_address(tb.cpt, kmer < rc ? kmer : rc, kmer < rc ? rc : kmer, b, tag);
+    const uint32_t* bk = (const uint32_t*)tb.slots + (uint64_t)b * 16;
+    if (kmer <= rc)
+        for (int j = 0; j < kCptSlots; ++j)
+            if (((const uint16_t*)bk)[j] == (uint16_t)tag) { atomicAdd(&out[0], 1ull); return; }
+    if (!(bk[15] & kCptOvfFlag)) { atomicAdd(&out[1], 1ull); return; }
+    uint32_t ob = ovf_bucket_of(b, tag, tb.ovf_nbuckets);
+    unsigned long long reads = 0;
+    for (uint32_t tries = 0; tries < tb.ovf_nbuckets; ++tries) {
+        const uint64_t* s_ = tb.ovf_slots + (uint64_t)ob * kSlotsPerBucket;
+        ++reads;
+        bool empty = false;
+        for (int j = 0; j < kSlotsPerBucket; ++j) {
+            const uint64_t v = s_[j];
+            if (v == 0) empty = true;
+            else if ((v >> kPayloadBits) == kmer) { atomicAdd(&out[2], 1ull); atomicAdd(&out[4], reads); return; }
+        }
+        if (empty) break;
+        ob = ob + 1 == tb.ovf_nbuckets ? 0 : ob + 1;
+    }
+    atomicAdd(&out[3], 1ull);
+    atomicAdd(&out[4], reads);
+}
+
 // ------------------------------------------------------------------------------------------
 // Per-wave LDS layout of the classify kernel.
 //   U = capacity in distinct k-mers (a read of length L needs L-k+1 <= U), T = capacity in
@@ -1923,6 +1955,12 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         const int wsh = tb.cpt.wshift;
         uint32_t b, rho;
         if (wsh >= 0) { b = hi >> wsh; rho = hi & ((1u << wsh) - 1u); }
+        else if (wsh == -2) {  // fractional width (cpt_geometry): bucket = hi * nb >> 32, rho = floor((hi * nb mod 2^32) / nb) <= 3
+            const uint32_t nb32 = (uint32_t)tb.cpt.nb, lowp = hi * nb32;
+            const uint64_t nb64 = nb32;
+            b = __umulhi(hi, nb32);
+            rho = (lowp >= nb32 ? 1u : 0u) + ((uint64_t)lowp >= 2 * nb64 ? 1u : 0u) + ((uint64_t)lowp >= 3 * nb64 ? 1u : 0u);
+        }
         else { b = (uint32_t)(((double)hi + 0.5) * tb.cpt.invW); rho = hi - b * tb.cpt.W; }
         const int rs = 2 * (kCptW - 1 - (int)j);
         const uint32_t other = (uint32_t)((km >> (2 * cm + rs)) << rs) | ((uint32_t)km & ((1u << rs) - 1));
@@ -2188,25 +2226,48 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     // ---- probe, chunk by chunk
     uint32_t nov = 0;  // entries of olist
     auto ovf_pass = [&]() {  // looks the listed k-mers up in the overflow table: wide layout, linear probing, 4 lanes per bucket
-      for (uint32_t e0 = 0; e0 < nov; e0 += 16) {
-        const GAS u32x4* oq = (const GAS u32x4*)tb.ovf_slots;
-        const uint32_t en = e0 + ((uint32_t)lane >> 2);
-        const int q4 = lane & 3;
-        bool act = en < nov;
-        u32x4 e = {0u, 0u, 0u, 0u};
-        if (act) e = olist[en];
-        const uint64_t key1 = ((((uint64_t)e.y << 32) | e.x) << kPayloadBits) + 1;
-        uint32_t ob = act ? ovf_bucket_of(e.z, e.w & 0xFFFFu, tb.ovf_nbuckets) : 0u;
-        while (__ballot(act)) {
-            u32x4 v = {1u, 0u, 1u, 0u};
-            if (act) v = oq[(uint64_t)ob * 4 + q4];
-            const uint64_t t0 = (((uint64_t)v.y << 32) | v.x) - key1, t1 = (((uint64_t)v.w << 32) | v.z) - key1;
-            const bool m0 = act && t0 < 0xFFFFFFull, m1 = act && t1 < 0xFFFFFFull;
-            if (m0 || m1) upay[e.w >> 16] = (uint32_t)(m0 ? t0 : t1) + 1u;
-            // found, or a free last slot (slots fill front to back) ends the chain for all four lanes of the entry
-            const uint32_t done = (uint32_t)(__ballot(m0 || m1 || (q4 == 3 && (v.z | v.w) == 0u)) >> (lane & ~3)) & 0xFu;
-            if (done) act = false;
-            else ob = ob + 1 == tb.ovf_nbuckets ? 0 : ob + 1;
+      // OVL rounds of 16 entries with their first buckets all in flight before any is looked at: a near-capacity table displaces a
+      // quarter of its k-mers, a read then lists 30 .. 60 of them, and a round trip per 16 (the shape of this pass until round 4)
+      // was three or four dependent trips to memory per read.  The rare chain beyond the first bucket is walked round by round.
+      constexpr int OVL = 3;
+      const GAS u32x4* oq = (const GAS u32x4*)tb.ovf_slots;
+      const int q4 = lane & 3;
+      for (uint32_t e0 = 0; e0 < nov; e0 += 16 * OVL) {
+        u32x4 v[OVL];
+        uint32_t ob[OVL];
+#pragma unroll
+        for (int g = 0; g < OVL; ++g) {
+            const uint32_t en = e0 + 16u * g + ((uint32_t)lane >> 2);
+            v[g] = u32x4{1u, 0u, 1u, 0u};
+            ob[g] = 0;
+            if (en < nov) {
+                const u32x4 e = olist[en];
+                ob[g] = ovf_bucket_of(e.z, e.w & 0xFFFFu, tb.ovf_nbuckets);
+                v[g] = oq[(uint64_t)ob[g] * 4 + q4];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < OVL; ++g) {
+            if (e0 + 16u * g >= nov) break;
+            const uint32_t en = e0 + 16u * g + ((uint32_t)lane >> 2);
+            bool act = en < nov;
+            u32x4 e = {0u, 0u, 0u, 0u};
+            if (act) e = olist[en];
+            const uint64_t key1 = ((((uint64_t)e.y << 32) | e.x) << kPayloadBits) + 1;
+            u32x4 vv = v[g];
+            uint32_t obg = ob[g];
+            while (true) {
+                const uint64_t t0 = (((uint64_t)vv.y << 32) | vv.x) - key1, t1 = (((uint64_t)vv.w << 32) | vv.z) - key1;
+                const bool m0 = act && t0 < 0xFFFFFFull, m1 = act && t1 < 0xFFFFFFull;
+                if (m0 || m1) upay[e.w >> 16] = (uint32_t)(m0 ? t0 : t1) + 1u;
+                // found, or a free last slot (slots fill front to back) ends the chain for all four lanes of the entry
+                const uint32_t done = (uint32_t)(__ballot(m0 || m1 || (q4 == 3 && (vv.z | vv.w) == 0u)) >> (lane & ~3)) & 0xFu;
+                if (done) act = false;
+                if (!__ballot(act)) break;
+                obg = obg + 1 == tb.ovf_nbuckets ? 0 : obg + 1;
+                vv = u32x4{1u, 0u, 1u, 0u};
+                if (act) vv = oq[(uint64_t)obg * 4 + q4];
+            }
         }
       }
       nov = 0;
@@ -3503,6 +3564,11 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
     if (!n) return;
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tb, kmers, n, counts, tids,
                        stride);
+}
+
+void launch_probe_stats(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, unsigned long long* out, hipStream_t stream) {
+    if (!n) return;
+    probe_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(tb, kmers, n, out);
 }
 
 void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_probes, uint64_t seed,

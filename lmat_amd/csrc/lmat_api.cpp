@@ -334,8 +334,9 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int 
         uint64_t want = table_bytes ? table_bytes / 64 : (uint64_t)((double)n_kmers / 6.4) + 1;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = ~(size_t)0;
-        for (int attempt = 0; attempt < 8; ++attempt) {  // the bucket count is quantised: step down while table + overflow exceed the free memory
-            CptGeom g = cpt_geometry(k, want);
+        for (int attempt = 0; attempt < 24; ++attempt) {  // step down while table + overflow exceed the free memory
+            static const bool frac_ok = !getenv("LMAT_FRAC_W") || atoi(getenv("LMAT_FRAC_W")) != 0;  // (0: integer widths only, as before round 4 -- A/B runs)
+            CptGeom g = cpt_geometry(k, want, frac_ok);
             if (!g.nb) break;
             const double n_est = n_kmers ? (double)n_kmers : 6.4 * (double)g.nb;
             const double load = n_est / (double)g.nb;
@@ -345,8 +346,9 @@ static int alloc_table(lmat_ctx* c, uint64_t n_kmers, uint64_t table_bytes, int 
             if (const char* e = getenv("LMAT_OVERFLOW_SHARE")) share = atof(e);
             const uint64_t onb = (uint64_t)(n_est * share / (0.6 * kSlotsPerBucket)) + 1024;
             if (onb > 0xFFFFFFFFull) return set_err(c, LMAT_E_CAPACITY, "overflow table above 2^32 buckets");
-            if ((double)(g.nb + onb) * 64.0 + 6.0 * (double)(1ull << 30) > (double)free_b && g.W < (127u >> g.lowbits)) {
-                want = (1ull << (2 * g.m - g.lowbits)) / (g.W + 1);  // the next smaller table
+            if ((double)(g.nb + onb) * 64.0 + 6.0 * (double)(1ull << 30) > (double)free_b && (g.wshift == -2 || g.W < (127u >> g.lowbits))) {
+                want = g.wshift == -2 ? g.nb - g.nb / 16   // fractional widths: any size goes -- a sixteenth less
+                                      : (1ull << (2 * g.m - g.lowbits)) / (g.W + 1);  // the next smaller table
                 if (want < 1) break;
                 continue;
             }
@@ -650,6 +652,27 @@ int lmat_db_lookup(lmat_ctx* c, const uint64_t* kmers, uint64_t n, uint32_t* cou
     if (stride && tids) HIPCHK(c, hipMemcpyAsync(tids, d_t, n * stride * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(d_k); hipFree(d_c); hipFree(d_t);
+    return LMAT_OK;
+}
+
+// Measurement hook: where the lookups of these k-mers end -- out[0] home bucket, out[1] absent without a second request,
+// out[2] found in the overflow table, out[3] absent after asking it too, out[4] overflow buckets read.  Compact layout only.
+int lmat_debug_probe_stats(lmat_ctx* c, const uint64_t* kmers, uint64_t n, uint64_t* out5) {
+    if (!c || !out5 || (n && !kmers)) return LMAT_E_ARG;
+    if (!c->db_ready) return set_err(c, LMAT_E_ARG, "database not ready");
+    hipSetDevice(c->device);
+    for (int i = 0; i < 5; ++i) out5[i] = 0;
+    if (!n || !c->dev.cpt.nb) return LMAT_OK;
+    uint64_t* d_k = nullptr;
+    unsigned long long* d_o = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_k, n * 8));
+    HIPCHK(c, hipMalloc((void**)&d_o, 40));
+    HIPCHK(c, hipMemsetAsync(d_o, 0, 40, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_k, kmers, n * 8, hipMemcpyHostToDevice, c->stream));
+    launch_probe_stats(c->dev, d_k, n, d_o, c->stream);
+    HIPCHK(c, hipMemcpyAsync(out5, d_o, 40, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_k); hipFree(d_o);
     return LMAT_OK;
 }
 

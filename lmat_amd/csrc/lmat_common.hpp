@@ -84,7 +84,8 @@ struct CptGeom {
     uint32_t W = 0;        // bucket width in hi-space
     double invW = 0;       // 1.0 / W
     int k = 0, m = 0, lowbits = 0;
-    int wshift = -1;       // log2(W) when W is a power of two (the classify kernel then shifts instead of multiplying in double), else -1
+    int wshift = -1;       // log2(W) when W is a power of two (the classify kernel then shifts instead of multiplying in double), else -1;
+                           // -2: FRACTIONAL width -- nb is any number between 2^30 and 2^32 and bucket = hi * nb >> 32 (below)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -119,7 +120,7 @@ LM_HD uint64_t revcomp_fwd(uint64_t fwd, int k) {
 
 // geometry for a table of about want_buckets buckets; nb == 0 when the compact layout cannot hold this k / size
 // (then the caller uses the wide layout).  min_buckets: the smallest table the 16-bit tag allows for this k.
-LM_HD CptGeom cpt_geometry(int k, uint64_t want_buckets) {
+LM_HD CptGeom cpt_geometry(int k, uint64_t want_buckets, bool allow_fractional = true) {
     CptGeom g;
     if (k < 10 || k > 20) return g;
     const int m = k - (kCptW - 1), n = 2 * m;
@@ -131,7 +132,20 @@ LM_HD CptGeom cpt_geometry(int k, uint64_t want_buckets) {
     if (W < 1) W = 1;
     if (W > wmax) W = wmax;
     const uint64_t nb = (space + W - 1) / W;
-    g.nb = nb; g.W = (uint32_t)W; g.invW = 1.0 / (double)W; g.k = k; g.m = m; g.lowbits = lowbits;
+    g.k = k; g.m = m; g.lowbits = lowbits;
+    // An integer width quantises the large tables coarsely: between 2^31 and 2^32 buckets (128 and 256 GiB) there is nothing,
+    // and a 200 GB-class database landed on 2^31 buckets at a load of 8.7 of 12 slots with a quarter of its k-mers displaced.
+    // Where the integer width overshoots the request by more than 2 % (and hi-space is the full 32 bits: k >= 19), the table
+    // gets exactly the buckets asked for and a FRACTIONAL width: bucket = hi * nb >> 32, and rho = the place of hi among the
+    // (at most 4) values that share the bucket = floor((hi * nb mod 2^32) / nb).  (bucket, rho) <-> hi stays a bijection.
+    if (allow_fractional && n - lowbits == 32 && want_buckets > (1ull << 30) && want_buckets < (1ull << 32) && nb * 50 > want_buckets * 51) {
+        g.nb = want_buckets;
+        g.W = (uint32_t)((space + want_buckets - 1) / want_buckets);   // values of hi per bucket, at most (2 .. 4): bounds rho
+        g.invW = 1.0 / (double)g.W;
+        g.wshift = -2;
+        return g;
+    }
+    g.nb = nb; g.W = (uint32_t)W; g.invW = 1.0 / (double)W;
     g.wshift = (W & (W - 1)) == 0 ? 63 - __builtin_clzll(W) : -1;
     return g;
 }
@@ -154,9 +168,17 @@ LM_HD void cpt_address(const CptGeom& g, uint64_t c, uint64_t cr, uint32_t& buck
     const int j = (int)(best >> 1) & 3;
     const uint64_t sp = cpt_mix(best >> 3, m);
     const uint32_t hi = (uint32_t)(sp >> g.lowbits), low = (uint32_t)sp & ((1u << g.lowbits) - 1);
-    // hi / W, exact: (hi + 0.5) / W is never within 2^-8 of an integer and the double product is good to 2^-20
-    const uint32_t b = (uint32_t)(((double)hi + 0.5) * g.invW);
-    const uint32_t rho = hi - b * g.W;
+    uint32_t b, rho;
+    if (g.wshift == -2) {  // fractional width
+        const uint64_t prod = (uint64_t)hi * (uint64_t)(uint32_t)g.nb;
+        const uint64_t lowp = prod & 0xFFFFFFFFull, nb64 = g.nb;
+        b = (uint32_t)(prod >> 32);
+        rho = (lowp >= nb64 ? 1u : 0u) + (lowp >= 2 * nb64 ? 1u : 0u) + (lowp >= 3 * nb64 ? 1u : 0u);
+    } else {
+        // hi / W, exact: (hi + 0.5) / W is never within 2^-8 of an integer and the double product is good to 2^-20
+        b = (uint32_t)(((double)hi + 0.5) * g.invW);
+        rho = hi - b * g.W;
+    }
     const int rs = 2 * (kCptW - 1 - j);                            // bits of the k-mer right of the minimizer
     const uint32_t other = (uint32_t)((c >> (2 * m + rs)) << rs) | ((uint32_t)c & ((1u << rs) - 1));
     bucket = b;

@@ -34,7 +34,8 @@ def test_address_is_a_bijection_exhaustive_k10():
     assert len(set(seen.values())) == len(seen)
 
 
-@pytest.mark.parametrize("k,want", [(20, 1), (20, 1 << 30), (20, 3 << 29), (18, 1), (18, 1 << 27), (16, 1), (19, 1 << 28)])
+@pytest.mark.parametrize("k,want", [(20, 1), (20, 1 << 30), (20, 3 << 29), (20, 3 << 30), (20, 2_900_000_000), (20, 3_120_562_176), (19, 3 << 29),
+                                    (18, 1), (18, 1 << 27), (16, 1), (19, 1 << 28)])
 def test_address_sampled(k, want):
     """Neighbouring k-mers (one substitution apart, shifted by one base) are the near-collisions that matter."""
     lib = capi.load_library()
@@ -58,6 +59,31 @@ def test_address_sampled(k, want):
     h = np.bincount((np.array(buckets, dtype=np.float64) * 64 / nb).astype(int), minlength=64)
     chi2 = ((h - len(buckets) / 64.0) ** 2 / (len(buckets) / 64.0)).sum()
     assert chi2 < 130, chi2
+
+
+def test_fractional_width_is_a_bijection_small_model():
+    """The arithmetic of the fractional bucket width (cpt_geometry, wshift = -2), exhaustively on a 16-bit model of hi-space:
+    bucket = hi * nb >> 16, rho = floor((hi * nb mod 2^16) / nb) -- every hi gets its own (bucket, rho), rho stays below
+    ceil(2^16 / nb), and the buckets are filled evenly (floor or ceil of 2^16 / nb values each)."""
+    for nb in (16385, 20000, 24576, 30001, 32769, 40000, 49152, 65535):
+        hi = np.arange(1 << 16, dtype=np.uint64)
+        prod = hi * np.uint64(nb)
+        b = prod >> np.uint64(16)
+        rho = (prod & np.uint64(0xFFFF)) // np.uint64(nb)
+        assert int(b.max()) == nb - 1 and int(rho.max()) < -(-65536 // nb)
+        key = b * np.uint64(8) + rho
+        assert np.unique(key).size == 1 << 16
+        per = np.bincount(b.astype(np.int64), minlength=nb)
+        assert set(np.unique(per).tolist()) <= {65536 // nb, -(-65536 // nb)}
+
+
+def test_fractional_geometry_gives_the_buckets_asked_for():
+    lib = capi.load_library()
+    for want in (3_120_562_176, 2_900_000_000, 3 << 29):
+        nb, b, t = _addr(lib, 20, want, 0x123456789A)
+        assert nb == want
+    assert _addr(lib, 20, 1 << 31, 5)[0] == 1 << 31
+    assert _addr(lib, 20, 1 << 30, 5)[0] == 1 << 30   # powers of two keep their integer width (the shift path of the kernels)
 
 
 def test_no_compact_layout_for_short_kmers():
