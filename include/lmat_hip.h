@@ -115,6 +115,14 @@ int lmat_db_set_build_options(lmat_ctx* ctx, int tid_cutoff, const char* rank_ma
  * src/make_db_table.cpp:330-343,429): save between begin and finalize; load + finalize to use it. */
 int lmat_db_save_image(lmat_ctx* ctx, const char* fn);
 int lmat_db_load_image(lmat_ctx* ctx, const char* fn, uint64_t table_bytes);
+/* Two image formats, told apart by their first 8 bytes:
+ *   LMATIMG1  the ingest's view (sorted k-mers + canonical 16-bit lists; what make_db_image writes without a GPU): saved between
+ *             lmat_db_begin and lmat_db_finalize; loading it sizes a table and inserts every k-mer on the GPU.
+ *   LMATIMG2  the DEVICE layout itself (bucket array, overflow table, list arena, geometry): lmat_db_save_image on a FINALIZED
+ *             database streams it out of HBM, lmat_db_load_image streams it back in through pinned buffers -- the counterpart of
+ *             the reference mapping its database file (src/read_label.cpp:1477-1491); lmat_db_finalize is then a no-op.  Its list
+ *             records hold internal taxid indices built under the context's label modes: loading checks fingerprints of both
+ *             (LMAT_E_TAXONOMY / LMAT_E_ARG on a mismatch).  table_bytes is ignored for it. */
 /* A replica of src's finalized database in dst (another GPU of the node, or the same one): the k-mer table, its
  * overflow table and the list arena are copied device to device (hipMemcpyPeer: over xGMI between GPUs), instead of
  * every GPU parsing the files again.  dst must hold the same taxonomy and label modes as src and no database yet. */

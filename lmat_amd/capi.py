@@ -364,6 +364,10 @@ class Engine:
         self._chk(self.lib.lmat_db_load_image(self.ctx, path.encode(), table_bytes))
         self._chk(self.lib.lmat_db_finalize(self.ctx))
 
+    def save_device_image(self, path):
+        """The finalized database as it lies in HBM (LMATIMG2): load_image() of another context with the same taxonomy streams it back in."""
+        self._chk(self.lib.lmat_db_save_image(self.ctx, path.encode()))
+
     def set_label_modes(self, permissive=False, tid_cutoff=0, rank_map=None):
         """-s / -g N -m ranks; call before build_db / load_image."""
         self._chk(self.lib.lmat_set_label_modes(self.ctx, int(permissive), tid_cutoff, rank_map.encode() if rank_map else None))

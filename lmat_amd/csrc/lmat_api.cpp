@@ -7,6 +7,9 @@
 #include <chrono>
 #include <string>
 #include <thread>
+#include <atomic>
+#include <fcntl.h>
+#include <unistd.h>
 #include "kernels.hpp"
 #include "outfmt.hpp"
 
@@ -268,9 +271,176 @@ int lmat_db_add_taxhisto(lmat_ctx* c, const char* fn) {
     return LMAT_OK;
 }
 
+// ---- LMATIMG2: the database as it lies in HBM ------------------------------------------------------------------------------
+// The reference opens its database by mapping it (src/read_label.cpp:1477-1491, make_db_table.cpp:330-343): the file IS the
+// in-memory layout, and start-up costs what paging it in costs.  LMATIMG1 (dbbuild.cpp) is the ingest's view -- sorted k-mers
+// and canonical lists -- and loading it re-inserts every k-mer.  LMATIMG2 is the device layout itself: a 4 KiB header (geometry
+// of the compact table, list alignment, counts, and fingerprints of the taxonomy and the label modes the list records were
+// built under), then the bucket array, the overflow table and the list arena, each on a 4 KiB boundary.  Saving streams them
+// out of HBM, loading streams them in, through a few pinned buffers each with a stream and a thread of its own (file I/O of
+// one chunk beside the copies of the others): a database starts at the rate of the file system or the PCIe link.
+}  // extern "C"
+namespace {
+struct ImgHdr2 {
+    char magic[8];            // "LMATIMG2"
+    uint32_t version, k;
+    uint64_t nb;              // compact buckets (0: wide layout)
+    uint32_t W, lowbits, m; int32_t wshift;
+    uint32_t nbuckets, ovf_nbuckets, list_shift, n_ids;
+    uint64_t n_kmers, arena_words, n_lists;
+    uint64_t tax_fingerprint, mode_fingerprint;
+    uint64_t off_slots, bytes_slots, off_ovf, bytes_ovf, off_arena, bytes_arena;
+};
+static_assert(sizeof(ImgHdr2) <= 4096, "header page");
+uint64_t fnv(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001B3ull; }
+    return h;
+}
+template <class V> uint64_t fnv_vec(uint64_t h, const V& v) { return v.empty() ? h : fnv(h, v.data(), v.size() * sizeof(v[0])); }
+// the list records hold internal taxid indices and were filtered / sorted under the context's label modes: an image only fits
+// a context with the same taxonomy and the same modes
+uint64_t tax_fingerprint(const lmat_ctx* c) {
+    const HostTaxonomy& T = c->tax;
+    uint64_t h = 0xCBF29CE484222325ull;
+    h = fnv_vec(h, T.tid32); h = fnv_vec(h, T.fdepth); h = fnv_vec(h, T.flags); h = fnv_vec(h, T.paths); h = fnv_vec(h, T.path_len);
+    return h;
+}
+uint64_t mode_fingerprint(const lmat_ctx* c) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    const int32_t m[4] = {c->permissive, c->rt_tid_cut, c->rand_mode, c->gene_mode};
+    h = fnv(h, m, sizeof m);
+    std::vector<std::pair<uint32_t, uint32_t>> rm(c->rt_rank_map.begin(), c->rt_rank_map.end());
+    std::sort(rm.begin(), rm.end());
+    return fnv_vec(h, rm);
+}
+const uint64_t kImgChunk = 64ull << 20;
+const int kImgThreads = 4;
+// moves `bytes` between the device range and the file range in chunks, kImgThreads at a time (to_file: HBM -> file)
+bool img_stream(lmat_ctx* c, int fd, uint64_t file_off, char* dev, uint64_t bytes, bool to_file, std::string& err) {
+    if (!bytes) return true;
+    const uint64_t nchunks = (bytes + kImgChunk - 1) / kImgChunk;
+    const int nt = (int)std::min<uint64_t>(kImgThreads, nchunks);
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> failed{0};
+    std::vector<std::string> errs(nt);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t]() {
+            hipSetDevice(c->device);
+            void* buf = nullptr;
+            hipStream_t st = nullptr;
+            if (hipHostMalloc(&buf, kImgChunk, hipHostMallocDefault) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                errs[t] = "out of pinned memory for the image buffers"; failed = 1;
+                if (buf) hipHostFree(buf);
+                return;
+            }
+            for (uint64_t j; !failed && (j = next.fetch_add(1)) < nchunks;) {
+                const uint64_t o = j * kImgChunk, n = std::min(kImgChunk, bytes - o);
+                if (to_file) {
+                    if (hipMemcpyAsync(buf, dev + o, n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { errs[t] = "copy from the device failed"; failed = 1; break; }
+                    for (uint64_t w = 0; w < n;) {
+                        const ssize_t r = pwrite(fd, (char*)buf + w, n - w, (off_t)(file_off + o + w));
+                        if (r <= 0) { errs[t] = "write failed (disk full?)"; failed = 1; break; }
+                        w += (uint64_t)r;
+                    }
+                } else {
+                    for (uint64_t w = 0; w < n;) {
+                        const ssize_t r = pread(fd, (char*)buf + w, n - w, (off_t)(file_off + o + w));
+                        if (r <= 0) { errs[t] = "image truncated"; failed = 1; break; }
+                        w += (uint64_t)r;
+                    }
+                    if (failed) break;
+                    if (hipMemcpyAsync(dev + o, buf, n, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { errs[t] = "copy to the device failed"; failed = 1; break; }
+                }
+            }
+            hipStreamDestroy(st);
+            hipHostFree(buf);
+        });
+    for (auto& x : th) x.join();
+    for (auto& e : errs) if (!e.empty()) { err = e; return false; }
+    return !failed;
+}
+int save_device_image(lmat_ctx* c, const char* fn) {
+    if (c->gene_mode) return set_err(c, LMAT_E_ARG, "device images hold taxonomy databases: a gene database is built from its files");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const DeviceTables& D = c->dev;
+    ImgHdr2 h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "LMATIMG2", 8);
+    h.version = 1; h.k = (uint32_t)D.k;
+    h.nb = D.cpt.nb; h.W = D.cpt.W; h.lowbits = (uint32_t)D.cpt.lowbits; h.m = (uint32_t)D.cpt.m; h.wshift = D.cpt.wshift;
+    h.nbuckets = D.nbuckets; h.ovf_nbuckets = D.ovf_nbuckets; h.list_shift = D.list_shift; h.n_ids = D.n_ids;
+    h.n_kmers = c->n_kmers; h.arena_words = c->arena_words; h.n_lists = c->n_lists;
+    h.tax_fingerprint = tax_fingerprint(c); h.mode_fingerprint = mode_fingerprint(c);
+    auto up = [](uint64_t x) { return (x + 4095) / 4096 * 4096; };
+    h.bytes_slots = (D.cpt.nb ? D.cpt.nb : (uint64_t)D.nbuckets) * 64;
+    h.bytes_ovf = (uint64_t)D.ovf_nbuckets * 64;
+    h.bytes_arena = c->arena_words * 2;
+    h.off_slots = 4096; h.off_ovf = up(h.off_slots + h.bytes_slots); h.off_arena = up(h.off_ovf + h.bytes_ovf);
+    const int fd = open(fn, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return set_err(c, LMAT_E_IO, std::string("cannot write ") + fn);
+    std::vector<char> page(4096, 0);
+    memcpy(page.data(), &h, sizeof h);
+    std::string err;
+    bool ok = pwrite(fd, page.data(), 4096, 0) == 4096;
+    if (!ok) err = "write failed";
+    ok = ok && img_stream(c, fd, h.off_slots, (char*)D.slots, h.bytes_slots, true, err) &&
+         img_stream(c, fd, h.off_ovf, (char*)D.ovf_slots, h.bytes_ovf, true, err) &&
+         img_stream(c, fd, h.off_arena, (char*)D.arena, h.bytes_arena, true, err);
+    if (close(fd) != 0 && ok) { ok = false; err = "close failed"; }
+    if (!ok) { unlink(fn); return set_err(c, LMAT_E_IO, std::string("saving the device image ") + fn + ": " + err); }
+    return LMAT_OK;
+}
+int load_device_image(lmat_ctx* c, const char* fn) {
+    if (c->gene_mode) return set_err(c, LMAT_E_ARG, "device images hold taxonomy databases");
+    const int fd = open(fn, O_RDONLY);
+    if (fd < 0) return set_err(c, LMAT_E_IO, std::string("cannot read database image ") + fn);
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    std::vector<char> page(4096, 0);
+    ImgHdr2 h;
+    if (pread(fd, page.data(), 4096, 0) != 4096) return set_err(c, LMAT_E_IO, std::string("cannot read database image ") + fn);
+    memcpy(&h, page.data(), sizeof h);
+    if (memcmp(h.magic, "LMATIMG2", 8) != 0 || h.version != 1 || h.k < 1 || h.k > 20) return set_err(c, LMAT_E_IO, "not a device image of this engine version");
+    if (h.tax_fingerprint != tax_fingerprint(c) || h.n_ids != c->dev.n_ids)
+        return set_err(c, LMAT_E_TAXONOMY, "the image was saved under a different taxonomy (its list records hold that taxonomy's internal ids): load the files it was built with");
+    if (h.mode_fingerprint != mode_fingerprint(c))
+        return set_err(c, LMAT_E_ARG, "the image was saved under different label modes (-s / -g / -m shape the list records): set the same modes, or build from the tax_histo files");
+    const off_t fsz = lseek(fd, 0, SEEK_END);
+    if (fsz < 0 || (uint64_t)fsz < h.off_arena + h.bytes_arena || h.bytes_slots % 64 || h.bytes_ovf != (uint64_t)h.ovf_nbuckets * 64 ||
+        h.bytes_slots != (h.nb ? h.nb : (uint64_t)h.nbuckets) * 64 || h.bytes_arena != h.arena_words * 2)
+        return set_err(c, LMAT_E_IO, "database image truncated or inconsistent");
+    hipSetDevice(c->device);
+    DeviceTables& D = c->dev;
+    if (D.slots) { hipFree(D.slots); D.slots = nullptr; }
+    if (D.ovf_slots) { hipFree(D.ovf_slots); D.ovf_slots = nullptr; }
+    if (D.arena) { hipFree(D.arena); D.arena = nullptr; }
+    c->db_ready = false;
+    HIPCHK(c, hipMalloc((void**)&D.slots, std::max<uint64_t>(h.bytes_slots, 64)));
+    if (h.bytes_ovf) HIPCHK(c, hipMalloc((void**)&D.ovf_slots, h.bytes_ovf));
+    HIPCHK(c, hipMalloc((void**)&D.arena, h.bytes_arena + 64));   // (a record's first 16 bytes are one load: slack behind the last)
+    HIPCHK(c, hipMemset((char*)D.arena + h.bytes_arena, 0, 64));
+    std::string err;
+    if (!img_stream(c, fd, h.off_slots, (char*)D.slots, h.bytes_slots, false, err) ||
+        !img_stream(c, fd, h.off_ovf, (char*)D.ovf_slots, h.bytes_ovf, false, err) ||
+        !img_stream(c, fd, h.off_arena, (char*)D.arena, h.bytes_arena, false, err))
+        return set_err(c, LMAT_E_IO, std::string("loading the device image ") + fn + ": " + err);
+    D.cpt = CptGeom();
+    D.cpt.nb = h.nb; D.cpt.W = h.W; D.cpt.invW = h.W ? 1.0 / (double)h.W : 0.0; D.cpt.k = (int)h.k; D.cpt.m = (int)h.m; D.cpt.lowbits = (int)h.lowbits; D.cpt.wshift = h.wshift;
+    if (!h.nb) D.cpt = CptGeom();
+    D.nbuckets = h.nbuckets; D.ovf_nbuckets = h.ovf_nbuckets; D.list_shift = h.list_shift; D.k = (int)h.k;
+    c->n_kmers = h.n_kmers; c->arena_words = h.arena_words; c->n_lists = h.n_lists;
+    c->db_ready = true;
+    return LMAT_OK;
+}
+}  // namespace
+extern "C" {
+
 int lmat_db_save_image(lmat_ctx* c, const char* fn) {
     if (!c || !fn) return LMAT_E_ARG;
-    if (!c->ingest) return set_err(c, LMAT_E_ARG, "no open ingest: save the image between lmat_db_begin and lmat_db_finalize");
+    if (!c->ingest && c->db_ready) return save_device_image(c, fn);   // a finalized database: the device layout itself (LMATIMG2)
+    if (!c->ingest) return set_err(c, LMAT_E_ARG, "no database: save the ingest's image between lmat_db_begin and lmat_db_finalize, the device image after lmat_db_finalize");
     if (c->ingest->flush) return set_err(c, LMAT_E_ARG, "a streamed build (n_kmers_hint / table_bytes given) keeps no copy to save: use make_db_image");
     return c->ingest->save_image(fn) ? LMAT_OK : set_err(c, LMAT_E_IO, std::string("cannot write ") + fn);
 }
@@ -278,6 +448,18 @@ int lmat_db_save_image(lmat_ctx* c, const char* fn) {
 int lmat_db_load_image(lmat_ctx* c, const char* fn, uint64_t table_bytes) {
     if (!c || !fn) return LMAT_E_ARG;
     if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy before the k-mer database");
+    {   // a device image (LMATIMG2) is copied in as it is; lmat_db_finalize then has nothing left to do
+        char magic[8] = {0};
+        FILE* f = fopen(fn, "rb");
+        const bool img2 = f && fread(magic, 8, 1, f) == 1 && memcmp(magic, "LMATIMG2", 8) == 0;
+        if (f) fclose(f);
+        if (img2) {
+            delete c->ingest;
+            c->ingest = nullptr;
+            sb_free(c);
+            return load_device_image(c, fn);
+        }
+    }
     delete c->ingest;
     c->ingest = new Ingest();
     c->ingest_table_bytes = table_bytes;
@@ -562,6 +744,7 @@ static int build_device_db(lmat_ctx* c, Ingest& B, uint64_t table_bytes) {
 
 int lmat_db_finalize(lmat_ctx* c) {
     if (!c) return LMAT_E_ARG;
+    if (!c->ingest && c->db_ready) return LMAT_OK;   // a device image came in ready
     if (!c->ingest) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
     int rc;
     if (c->ingest->flush) {  // streamed build: the tail, then the list arena

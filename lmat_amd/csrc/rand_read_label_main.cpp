@@ -91,7 +91,7 @@ int main(int argc, char* argv[]) {
         size_t got = 0;
         { FILE* f = fopen(kmer_db_fn.c_str(), "rb"); if (f) { got = fread(hdr, 1, 20, f); fclose(f); } memcpy(magic, hdr, 8); }
         if (got < 20) { std::cerr << "Error: unable to open kmer db [" << kmer_db_fn << "]" << std::endl; return -1; }
-        if (memcmp(magic, "LMATIMG1", 8) == 0) {
+        if (memcmp(magic, "LMATIMG1", 8) == 0 || memcmp(magic, "LMATIMG2", 8) == 0) {
             if (lmat_db_load_image(ctx, kmer_db_fn.c_str(), 0) != LMAT_OK) return fail("k-mer DB image");
         } else {
             bool is_list = false;

@@ -68,7 +68,7 @@ static bool is_list_file(const std::string& fn) {
     unsigned char b[20];
     size_t n = fread(b, 1, 20, f);
     fclose(f);
-    if (n >= 8 && memcmp(b, "LMATIMG1", 8) == 0) return false;  // database image
+    if (n >= 8 && (memcmp(b, "LMATIMG1", 8) == 0 || memcmp(b, "LMATIMG2", 8) == 0)) return false;  // database image
     if (n < 20) return true;
     for (int i = 12; i < 20; ++i)
         if (b[i] != 0xff) return true;
@@ -321,7 +321,7 @@ int main(int argc, char* argv[]) {
     {
         FILE* f = fopen(files[0].c_str(), "rb");
         char magic[8] = {0};
-        if (f) { if (fread(magic, 1, 8, f) == 8 && memcmp(magic, "LMATIMG1", 8) == 0) is_image = true; fclose(f); }
+        if (f) { if (fread(magic, 1, 8, f) == 8 && (memcmp(magic, "LMATIMG1", 8) == 0 || memcmp(magic, "LMATIMG2", 8) == 0)) is_image = true; fclose(f); }
     }
     uint32_t klen = 0;
     uint64_t n_total = 0;  // k-mer counts of the headers size the table up front, so the files stream through
@@ -389,6 +389,10 @@ int main(int argc, char* argv[]) {
                         if (lmat_db_add_taxhisto(x, fn.c_str()) != LMAT_OK) return bad("k-mer DB");
                     if (lmat_db_finalize(x) != LMAT_OK) return bad("k-mer DB");
                 }
+                if (g == 0)   // LMAT_SAVE_DEVICE_IMAGE=<file>: leave the database as it now lies in HBM (LMATIMG2) -- the next run's -d, which then
+                              // starts by streaming the file in instead of parsing and inserting (the reference maps its .db the same way)
+                    if (const char* img = getenv("LMAT_SAVE_DEVICE_IMAGE"))
+                        if (*img && lmat_db_save_image(x, img) != LMAT_OK) return bad("device image");
                 if (g == 0) { sig.ok = true; sig.p->set_value(true); sig.p = nullptr; }
                 if (lmat_stream_create(x, kBatch, kBatchBases, cands_per_read, kSlots, &rings[g]) != LMAT_OK) return bad("batch ring");
             });

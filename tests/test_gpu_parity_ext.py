@@ -1029,3 +1029,72 @@ def test_without_tail_mode_gives_the_same_answers():
     for 150 bp reads."""
     _child_run("LMAT_TAIL", "0", ["test_gpu_parity_ext.py", "test_gpu_parity.py", "test_gpu_fuzz.py"],
                "config1_text_parity or out_text or full_size_sample or degenerate or random_configuration or past_a_chunk or example")
+
+
+# ---- LMATIMG2: the database as it lies in HBM (lmat_db_save_image on a finalized database) ------------------------------
+def test_device_image_round_trip(tmp_path, small_dataset):
+    """A finalized database is streamed out of HBM (LMATIMG2) and back into a fresh context: same lookups, byte-identical
+    .out text, from the API and through `read_label -d <image>`; a context with another taxonomy or other label modes is
+    refused (the list records hold internal ids built under both)."""
+    import subprocess
+    from lmat_amd import Engine, Params
+    from lmat_amd.capi import LmatError
+    ds = small_dataset
+    reads = ds["reads"][:300]
+
+    def text(e):
+        dr = e.upload_reads(reads)
+        res, cands = e.classify(dr)
+        bs = [r.encode() for r in reads]
+        off = np.zeros(len(bs) + 1, dtype=np.uint64)
+        np.cumsum([len(b) for b in bs], out=off[1:])
+        t = e.format_out(res, cands, (np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8), off))
+        dr.free()
+        return t
+
+    a = Engine(0, Params.run_rl())
+    a.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    a.build_db(ds["db"], k=20)
+    want = text(a)
+    img = str(tmp_path / "db.img2")
+    a.save_device_image(img)
+    assert open(img, "rb").read(8) == b"LMATIMG2" and os.path.getsize(img) >= a.table_bytes + a.arena_bytes
+    rng = np.random.default_rng(5)
+    kms = rng.integers(0, 1 << 40, 4000, dtype=np.uint64)
+    b = Engine(0, Params.run_rl())
+    b.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    b.load_image(img)
+    assert b.db_size == a.db_size and b.k == 20
+    assert text(b) == want
+    ca, ta = a.lookup(kms, stride=32)
+    cb, tb_ = b.lookup(kms, stride=32)
+    assert (ca == cb).all() and (ta == tb_).all()
+    b.close()
+    # other label modes / another taxonomy: refused, loudly
+    c = Engine(0, Params.run_rl())
+    c.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], ds["idmap"])
+    c.set_label_modes(permissive=True)
+    with pytest.raises(LmatError) as ei:
+        c.load_image(img)
+    assert "label modes" in str(ei.value)
+    c.close()
+    d = Engine(0, Params.run_rl())
+    d.load_taxonomy(_GDS["tree"], _GDS["depth"], _GDS["rank"], _GDS["idmap"])
+    with pytest.raises(LmatError) as ei:
+        d.load_image(img)
+    assert "taxonomy" in str(ei.value)
+    d.close()
+    a.close()
+    # the CLI writes such an image (LMAT_SAVE_DEVICE_IMAGE) and starts from it: the same files as from the tax_histo input
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lmat_amd", "csrc", "read_label")
+    base = [exe, "-f", ds["idmap"], "-u", ds["names"], "-w", ds["rank"], "-x", "0", "-j", "30", "-l", "0", "-b", "1.0",
+            "-e", ds["depth"], "-p", "-t", "1", "-i", ds["fasta"], "-c", ds["tree"]]
+    img_b = str(tmp_path / "cli.img2")
+    r1 = subprocess.run(base + ["-d", ds["db"], "-o", str(tmp_path / "o1")], env=dict(os.environ, LMAT_SAVE_DEVICE_IMAGE=img_b), capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stderr
+    assert open(img_b, "rb").read(8) == b"LMATIMG2"
+    r2 = subprocess.run(base + ["-d", img_b, "-o", str(tmp_path / "o2")], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    for suffix in ("0.out", ".0.30.fastsummary", ".0.30.nomatchsum"):
+        assert open(str(tmp_path / "o1") + suffix).read() == open(str(tmp_path / "o2") + suffix).read(), suffix
+    assert len(open(str(tmp_path / "o2") + "0.out").read()) > 1000
