@@ -335,6 +335,14 @@ int lmat_db_from_ingest(lmat_ctx* ctx, lmat_ingest* ing, uint64_t table_bytes);
  * records of the reference's own example run (tests/golden/example_records.json) are put to the GPU kernels directly. */
 int lmat_debug_decide(lmat_ctx* ctx, const uint32_t* tids, const float* scores, const uint64_t* off, const float* stdev,
                       uint64_t n, lmat_read_result* results);
+/* The same step on (taxid, COUNT) tables and a candidate k-mer count per table, through either decision path of the engine:
+ * on_the_wave = 0 the general path (k4_part1 / k4_part2: scores = count / cand, the statistics, std::sort(TCmp) replayed,
+ * findReadLabelVer2 -- the code lmat_debug_decide pins to the reference's printed records), on_the_wave = 1 k4_wave, the
+ * wave-parallel form the classify kernel runs for every read of the benchmark.  A table k4_wave declines (cand above 999, the
+ * heapsort turn of introsort, a lineage beyond 64 entries, two lineage entries of one depth ...) comes back with status 255.
+ * results[i]: status, match_type, cand_kmer_cnt, log_avg, stdev, call_tid, call_score. */
+int lmat_debug_decide_counts(lmat_ctx* ctx, const uint32_t* tids, const uint32_t* counts, const uint64_t* off, const uint32_t* cand,
+                             uint64_t n, int on_the_wave, lmat_read_result* results);
 
 /* ---- measurement aid ---------------------------------------------------------
  * Random 64-byte bucket gather over the loaded table with the probe kernel's access shape;

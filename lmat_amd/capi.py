@@ -124,6 +124,7 @@ def load_library(path: str | None = None):
         "lmat_comm_destroy": (None, [vp]),
         "lmat_db_clone": (i32, [vp, vp]),
         "lmat_debug_decide": (i32, [vp, vp, vp, vp, vp, u64, vp]),
+        "lmat_debug_decide_counts": (i32, [vp, vp, vp, vp, vp, u64, i32, vp]),
         "lmat_synth_window": (i32, [vp, u32, u64, P(u64), vp, u32, P(u32)]),
         "lmat_debug_probe_stats": (i32, [vp, vp, u64, vp]),
         "lmat_synth_read_windows": (i32, [vp, vp, u32, u64, u64, vp, vp, vp, u32, u32, P(u32), P(u32)]),
@@ -151,7 +152,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
-            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_synth_window", "lmat_synth_read_windows", "lmat_debug_probe_stats"]
+            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_debug_decide_counts", "lmat_synth_window", "lmat_synth_read_windows", "lmat_debug_probe_stats"]
 
 
 def _ptr(a):
@@ -584,6 +585,16 @@ class Engine:
         sd = np.ascontiguousarray(stdevs, dtype=np.float32)
         res = np.zeros(len(tables), dtype=READ_RESULT_DTYPE)
         self._chk(self.lib.lmat_debug_decide(self.ctx, _ptr(tids), _ptr(sc), _ptr(off), _ptr(sd), len(tables), _ptr(res)))
+        return res
+
+    def debug_decide_counts(self, tids, counts, off, cand, on_the_wave):
+        """tids / counts: flat uint32 arrays, off: uint64[n + 1], cand: uint32[n] -> results array of the chosen decision path."""
+        tids = np.ascontiguousarray(tids, dtype=np.uint32)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        cand = np.ascontiguousarray(cand, dtype=np.uint32)
+        res = np.zeros(cand.size, dtype=READ_RESULT_DTYPE)
+        self._chk(self.lib.lmat_debug_decide_counts(self.ctx, _ptr(tids), _ptr(counts), _ptr(off), _ptr(cand), cand.size, int(on_the_wave), _ptr(res)))
         return res
 
     def clone_db_from(self, src: "Engine"):

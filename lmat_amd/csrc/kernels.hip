@@ -15,6 +15,12 @@
 #include <type_traits>
 #include "kernels.hpp"
 
+#ifndef LMAT_LDS_SHIFT
+#define LMAT_LDS_SHIFT 0   // (-DLMAT_LDS_SHIFT=1: the lane shifts of the minimizer window and the repeat filter through LDS instead of DPP.
+                           //  Measured in round 4, same box: 24.57 against 24.29 ms per 8 M reads -- 60 vector instructions fewer per read,
+                           //  but two more LDS round trips with their waits in the front end of every read.  Off.)
+#endif
+
 namespace lmat {
 
 #define WSYNC()                                              \
@@ -1928,21 +1934,35 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     // with the minimum taken across lanes.  Among equal m-mers cpt_address takes the first in the CANONICAL k-mer's
     // direction, which is the last in the read's direction when the reverse strand is canonical: bits 2..3 of the
     // compared words count positions in that direction.
-    auto cpt_finish = [&](uint64_t km, uint64_t u, uint64_t un, uint64_t fcmask, uint32_t& b_out, uint32_t& t_out) {
+    // LSH (the 160-k-mer classes): the m-mer values of the next three positions come out of LDS -- every lane parks its own in an
+    // array over the (dead) packed record, then reads at +1, +2, +3 -- instead of three wave_shl steps: a DPP shift with its
+    // lane-63 patch is a v_readlane, a v_mov and a v_mov_dpp per half and step, 18 vector instructions a chunk, and the vector
+    // pipe is what this kernel runs out of; the LDS pipe has room.  Same for the five wave_shr steps of the repeat filter below.
+    constexpr bool LSH = LMAT_LDS_SHIFT && CACHE && CPT && 8 * (64 * CH + 4) <= WL<U, T, E, INK4, CPT>::XL_BLOOM;
+    auto cpt_finish = [&](int c, uint64_t km, uint64_t u, uint64_t un, uint64_t fcmask, uint32_t& b_out, uint32_t& t_out) {
         const uint32_t ulo = (uint32_t)u, uhi = (uint32_t)(u >> 32);
-        const int n0l = __builtin_amdgcn_readlane((int)(uint32_t)un, 0), n0h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 0);
-        const int n1l = __builtin_amdgcn_readlane((int)(uint32_t)un, 1), n1h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 1);
-        const int n2l = __builtin_amdgcn_readlane((int)(uint32_t)un, 2), n2h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 2);
-        // wave_shl:1 -- lane i takes lane i + 1, lane 63 the next chunk's value
-        const uint32_t u1l = (uint32_t)__builtin_amdgcn_update_dpp(n0l, (int)ulo, 0x130, 0xf, 0xf, false);
-        const uint32_t u1h = (uint32_t)__builtin_amdgcn_update_dpp(n0h, (int)uhi, 0x130, 0xf, 0xf, false);
-        const uint32_t u2l = (uint32_t)__builtin_amdgcn_update_dpp(n1l, (int)u1l, 0x130, 0xf, 0xf, false);
-        const uint32_t u2h = (uint32_t)__builtin_amdgcn_update_dpp(n1h, (int)u1h, 0x130, 0xf, 0xf, false);
-        const uint32_t u3l = (uint32_t)__builtin_amdgcn_update_dpp(n2l, (int)u2l, 0x130, 0xf, 0xf, false);
-        const uint32_t u3h = (uint32_t)__builtin_amdgcn_update_dpp(n2h, (int)u2h, 0x130, 0xf, 0xf, false);
+        uint32_t u1l, u1h, u2l, u2h, u3l, u3h;
+        if constexpr (LSH) {
+            const LAS uint64_t* up = (const LAS uint64_t*)xl + c * 64 + lane;
+            const uint64_t U1 = up[1], U2 = up[2], U3 = up[3];
+            u1l = (uint32_t)U1; u1h = (uint32_t)(U1 >> 32); u2l = (uint32_t)U2; u2h = (uint32_t)(U2 >> 32); u3l = (uint32_t)U3; u3h = (uint32_t)(U3 >> 32);
+        } else {
+            const int n0l = __builtin_amdgcn_readlane((int)(uint32_t)un, 0), n0h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 0);
+            const int n1l = __builtin_amdgcn_readlane((int)(uint32_t)un, 1), n1h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 1);
+            const int n2l = __builtin_amdgcn_readlane((int)(uint32_t)un, 2), n2h = __builtin_amdgcn_readlane((int)(uint32_t)(un >> 32), 2);
+            // wave_shl:1 -- lane i takes lane i + 1, lane 63 the next chunk's value
+            u1l = (uint32_t)__builtin_amdgcn_update_dpp(n0l, (int)ulo, 0x130, 0xf, 0xf, false);
+            u1h = (uint32_t)__builtin_amdgcn_update_dpp(n0h, (int)uhi, 0x130, 0xf, 0xf, false);
+            u2l = (uint32_t)__builtin_amdgcn_update_dpp(n1l, (int)u1l, 0x130, 0xf, 0xf, false);
+            u2h = (uint32_t)__builtin_amdgcn_update_dpp(n1h, (int)u1h, 0x130, 0xf, 0xf, false);
+            u3l = (uint32_t)__builtin_amdgcn_update_dpp(n2l, (int)u2l, 0x130, 0xf, 0xf, false);
+            u3h = (uint32_t)__builtin_amdgcn_update_dpp(n2h, (int)u2h, 0x130, 0xf, 0xf, false);
+        }
         const bool fc = lane_bit(fcmask);
-        const uint64_t a0 = ((uint64_t)uhi << 32) | (ulo | (fc ? 0u : 12u)), a1 = ((uint64_t)u1h << 32) | (u1l | (fc ? 4u : 8u));
-        const uint64_t a2 = ((uint64_t)u2h << 32) | (u2l | (fc ? 8u : 4u)), a3 = ((uint64_t)u3h << 32) | (u3l | (fc ? 12u : 0u));
+        // bits 2..3 (free in u): the m-mer's place in the canonical k-mer's direction, 4 i or 12 - 4 i = 4 i ^ 12 -- one xor-add each
+        const uint32_t dirm = fc ? 0u : 12u;
+        const uint64_t a0 = ((uint64_t)uhi << 32) | (ulo + dirm), a1 = ((uint64_t)u1h << 32) | (u1l + (dirm ^ 4u));
+        const uint64_t a2 = ((uint64_t)u2h << 32) | (u2l + (dirm ^ 8u)), a3 = ((uint64_t)u3h << 32) | (u3l + (dirm ^ 12u));
         const uint64_t m01 = a0 < a1 ? a0 : a1, m23 = a2 < a3 ? a2 : a3;
         const uint64_t best = m01 < m23 ? m01 : m23;
         const uint32_t j = ((uint32_t)best >> 2) & 3u, fl = (uint32_t)best & 3u;
@@ -1990,11 +2010,19 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c], okm[c], ureg[c], fcm[c]);
         }
         if (CPT) {
+            if constexpr (LSH) {  // every lane's m-mer value, parked for its three left neighbours (the packed record under it is through)
+                WSYNC();
+                LAS uint64_t* ush = (LAS uint64_t*)xl;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) ush[c * 64 + lane] = ureg[c];
+                if (lane < 4) ush[CH * 64 + lane] = 0ull;
+                WSYNC();
+            }
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if ((uint32_t)c * 64 >= P) break;
                 if (TAILOK && c == 2 && tail_mode()) continue;
-                cpt_finish(kreg[c], ureg[c], c + 1 < CH ? ureg[c + 1] : 0ull, fcm[c], hreg[c], treg[c]);
+                cpt_finish(c, kreg[c], ureg[c], c + 1 < CH ? ureg[c + 1] : 0ull, fcm[c], hreg[c], treg[c]);
             }
         }
     } else {
@@ -2150,6 +2178,24 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     if (CACHE) {
         uint32_t pb = 0, pq = 0, ps1 = 0, ps2 = 0, ps3 = 0;  // bucket / minimizer position / digests of the last lanes of the previous chunk
         uint64_t Vp = 0, seen = 0;                   // ... and its valid mask
+        // LSH: bucket, digest and minimizer position of every k-mer parked in LDS (three zero entries in front: nothing precedes
+        // the read), read back at -1, -2, -3
+        LAS uint32_t* barr = (LAS uint32_t*)xl;
+        LAS uint32_t* sarr = barr + (64 * CH + 4);
+        LAS uint16_t* qarr = (LAS uint16_t*)(sarr + (64 * CH + 4));
+        if constexpr (LSH) {
+            static_assert(10 * (64 * CH + 4) <= WL<U, T, E, INK4, CPT>::XL_BLOOM, "the parked values end below the repeat filter's bits");
+            WSYNC();  // (the m-mer values above are through)
+            if (lane < 3) { barr[lane] = 0u; sarr[lane] = 0u; qarr[lane] = 0; }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((uint32_t)c * 64 >= P) break;
+                barr[3 + c * 64 + lane] = hreg[c];
+                sarr[3 + c * 64 + lane] = (uint32_t)(kreg[c] ^ (kreg[c] >> 17));
+                qarr[3 + c * 64 + lane] = (uint16_t)((uint32_t)c * 64 + lane + (treg[c] >> 30));
+            }
+            WSYNC();
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= P) break;
@@ -2158,11 +2204,18 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             const uint32_t b = hreg[c];
             const uint32_t sig = (uint32_t)(kreg[c] ^ (kreg[c] >> 17));
             const uint32_t q = (uint32_t)c * 64 + lane + (treg[c] >> 30);  // where the k-mer's minimizer starts in the read
-            const uint32_t bprev = (uint32_t)__builtin_amdgcn_update_dpp((int)pb, (int)b, 0x138, 0xf, 0xf, false);  // wave_shr:1
-            const uint32_t qprev = (uint32_t)__builtin_amdgcn_update_dpp((int)pq, (int)q, 0x138, 0xf, 0xf, false);
-            const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps1, (int)sig, 0x138, 0xf, 0xf, false);
-            const uint32_t s2 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps2, (int)s1, 0x138, 0xf, 0xf, false);
-            const uint32_t s3 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps3, (int)s2, 0x138, 0xf, 0xf, false);
+            uint32_t bprev, qprev, s1, s2, s3;
+            if constexpr (LSH) {
+                bprev = barr[c * 64 + lane + 2];
+                qprev = qarr[c * 64 + lane + 2];
+                s1 = sarr[c * 64 + lane + 2]; s2 = sarr[c * 64 + lane + 1]; s3 = sarr[c * 64 + lane];
+            } else {
+                bprev = (uint32_t)__builtin_amdgcn_update_dpp((int)pb, (int)b, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                qprev = (uint32_t)__builtin_amdgcn_update_dpp((int)pq, (int)q, 0x138, 0xf, 0xf, false);
+                s1 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps1, (int)sig, 0x138, 0xf, 0xf, false);
+                s2 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps2, (int)s1, 0x138, 0xf, 0xf, false);
+                s3 = (uint32_t)__builtin_amdgcn_update_dpp((int)ps3, (int)s2, 0x138, 0xf, 0xf, false);
+            }
             // lane masks, combined on the scalar side: a ballot of `a && b` goes through a 0/1 register and a compare, a ballot of
             // one compare is the compare
             uint64_t hitm = V & ((V1 & __ballot(sig == s1)) | (V2 & __ballot(sig == s2)) | (V3 & __ballot(sig == s3)));
@@ -2176,11 +2229,13 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
             hitm |= __ballot(both != 0u);
             seen |= hitm;
-            pb = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
-            pq = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
-            ps1 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 63);
-            ps2 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 62);
-            ps3 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 61);
+            if constexpr (!LSH) {
+                pb = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+                pq = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+                ps1 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 63);
+                ps2 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 62);
+                ps3 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 61);
+            }
             Vp = V;
         }
         suspect = seen != 0;
@@ -2229,7 +2284,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
       // OVL rounds of 16 entries with their first buckets all in flight before any is looked at: a near-capacity table displaces a
       // quarter of its k-mers, a read then lists 30 .. 60 of them, and a round trip per 16 (the shape of this pass until round 4)
       // was three or four dependent trips to memory per read.  The rare chain beyond the first bucket is walked round by round.
-      constexpr int OVL = 3;
+      constexpr int OVL = (!INK4 && E <= kFastE && U <= 256) ? (U <= 160 ? 2 : 1) : 3;   // (the classes compiled for 8 waves per SIMD have 64 registers: two rounds fit, three spilled)
       const GAS u32x4* oq = (const GAS u32x4*)tb.ovf_slots;
       const int q4 = lane & 3;
       for (uint32_t e0 = 0; e0 < nov; e0 += 16 * OVL) {
@@ -3405,6 +3460,106 @@ __global__ __launch_bounds__(64) void k4_debug_kernel(ClassifyArgs A, const uint
     store_result((GAS uint64_t*)(A.results + i), res);
 }
 
+// lmat_debug_decide_counts, general path: k4_part1 / k4_part2 exactly as k4_kernel runs them for a read -- scores from counts,
+// statistics, std::sort(TCmp) replayed, findReadLabelVer2 -- on (taxid, count) tables given from outside.  One lane per table.
+__global__ __launch_bounds__(64) void k4_debug_counts_kernel(ClassifyArgs A, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ cnts,
+                                                             const uint64_t* __restrict__ off, const uint32_t* __restrict__ cands, uint64_t n) {
+    constexpr int TT = kK4T, LIN = kK4T + 72;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const GAS uint32_t* g_tid32 = (const GAS uint32_t*)A.tb.tid32;
+    const GAS uint64_t* g_paths8 = (const GAS uint64_t*)A.tb.paths8;
+    const GAS u32x4* g_facts16 = (const GAS u32x4*)A.tb.facts16;
+    uint16_t reg[TT], cnt[TT], dep[TT], tin[TT], tout[TT], ord[TT];
+    uint8_t sflags[TT];
+    float score[TT], score0[TT];
+    LinEnt lin[LIN];
+    K4Key keys[TT];
+    lmat_read_result res;
+    res.status = 255; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = 0; res.read_len = 0; res.log_avg = 0;
+    res.stdev = 0; res.call_tid = 0; res.call_score = 0; res.cand_off = 0; res.n_cand = 0; res.bin_sel = 0;
+    const int nT = (int)(off[i + 1] - off[i]);
+    const uint32_t cand = cands[i];
+    if (nT >= 1 && nT <= TT) {
+        for (int s = 0; s < nT; ++s) {
+            const uint32_t t = idx[off[i] + s];
+            const u32x4 f = g_facts16[t];
+            reg[s] = (uint16_t)t; cnt[s] = (uint16_t)cnts[off[i] + s];
+            dep[s] = (uint16_t)(f.w & 0xFFFFu); sflags[s] = (uint8_t)(f.w >> 16); tin[s] = (uint16_t)(f.z & 0xFFFFu); tout[s] = (uint16_t)(f.z >> 16);
+        }
+        K4State S;
+        k4_part1<LIN>(A.prm, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, nT, cand, false, nullptr, nullptr, A.nm, keys);
+        if (!S.done) {
+            int nlin = S.nlin;
+            const uint32_t high_tid = S.highest >= 0 ? reg[S.highest] : 0;
+            const bool have_add = S.highest_depth != 0 && high_tid != 0;
+            uint32_t high_tin = 0xFFFF, high_tout = 0xFFFF;
+            bool trunc = false;
+            if (have_add) {  // ancestors of the shallowest accepted node with their all_cand_set scores or -10000 (:326-343)
+                high_tin = tin[S.highest];
+                high_tout = tout[S.highest];
+                const u32x4 hf = g_facts16[high_tid];
+                const uint32_t alen = hf.y & 0xFFFFu, aoff = hf.x;
+                for (uint32_t j = 0; j < alen && !trunc; ++j) {
+                    if (nlin >= LIN) { trunc = true; break; }
+                    const uint64_t pe = g_paths8[aoff + j];
+                    const uint32_t a = (uint32_t)(pe & 0xFFFFu);
+                    int sl = -1;
+                    for (int s = 0; s < nT; ++s) if (reg[s] == a) sl = s;
+                    LinEnt en;
+                    en.tid = (uint16_t)a;
+                    en.score = sl >= 0 ? score0[sl] : -10000.0f;
+                    en.dep = (uint16_t)(pe >> 16); en.tin = (uint16_t)(pe >> 32); en.tout = (uint16_t)(pe >> 48);
+                    lin[nlin++] = en;
+                }
+            }
+            if (!trunc) {
+                uint32_t ncand = 0, call_idx = 0;
+                k4_part2<LIN>(A.prm, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, nT, have_add, high_tin, high_tout, nullptr, &ncand, &call_idx);
+            } else res.status = 255;
+        }
+    }
+    store_result((GAS uint64_t*)(A.results + i), res);
+}
+
+// ... and the path the benchmark runs: k4_wave, the decision step on the classify wave, on the same tables.  One wave per table,
+// set up as classify_one leaves a read: lane s = registration slot s with the id's fact record in its registers, the ids in the
+// wave's taxid hash.  A table k4_wave declines (its preconditions, the heapsort turn of introsort, a lineage beyond 64 lanes,
+// two lineage entries of one depth) comes back with status 255: the general path's job.
+__global__ __launch_bounds__(64) void k4_wave_debug_kernel(ClassifyArgs A, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ cnts,
+                                                           const uint64_t* __restrict__ off, const uint32_t* __restrict__ cands, uint64_t n) {
+    constexpr int THM = 255;
+    __shared__ __align__(16) unsigned int hent[THM + 1];
+    __shared__ __align__(16) uint32_t xch[384 + 64];
+    const int lane = threadIdx.x & 63;
+    for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t nT = (uint32_t)(off[i + 1] - off[i]);
+        GAS uint64_t* out = (GAS uint64_t*)(A.results + i);
+        bool done = false;
+        if (nT >= 1 && nT <= 64) {
+            for (int h = lane; h <= THM; h += 64) hent[h] = 0;
+            WSYNC();
+            const bool act = (uint32_t)lane < nT;
+            const uint32_t my_id = act ? idx[off[i] + lane] : 0u, my_cnt = act ? cnts[off[i] + lane] : 0u;
+            u32x4 fz = u32x4{0u, 0u, 0u, 0u};
+            if (act) {
+                fz = ((const GAS u32x4*)A.tb.facts16)[my_id];
+                const uint32_t h = tid_find_or_claim(hent, THM, my_id);
+                hent[h] = my_id | ((uint32_t)lane << 16);
+            }
+            WSYNC();
+            done = k4_wave<THM>((CArgsK4*)__builtin_amdgcn_kernarg_segment_ptr(), lane, nT, cands[i], fz, my_cnt, my_id, hent, xch, out, 0, 0u, 0);
+            WSYNC();
+        }
+        if (!done && lane == 0) {
+            lmat_read_result res;
+            res.status = 255; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = 0; res.valid_kmers = 0; res.read_len = 0; res.log_avg = 0;
+            res.stdev = 0; res.call_tid = 0; res.call_score = 0; res.cand_off = 0; res.n_cand = 0; res.bin_sel = 0;
+            store_result(out, res);
+        }
+    }
+}
+
 // Random 64-byte bucket gather with the probe's access shape (4 lanes x 16 B per bucket, 9 wave-loads = 144 buckets
 // in flight per wave): the practical ceiling of K2 on this table, and a known byte count to calibrate the
 // FETCH_SIZE counter against.
@@ -3685,6 +3840,15 @@ void launch_k4_debug(const ClassifyArgs& a, const uint32_t* idx, const float* sc
                      hipStream_t stream) {
     if (!n) return;
     k4_debug_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(a, idx, scores, off, stdevs, n);
+}
+
+void launch_k4_debug_counts(const ClassifyArgs& a, const uint32_t* idx, const uint32_t* cnts, const uint64_t* off, const uint32_t* cands, uint64_t n,
+                            bool on_the_wave, hipStream_t stream) {
+    if (!n) return;
+    if (on_the_wave) {
+        const uint64_t g = n < 256 * 32 ? n : 256 * 32;
+        k4_wave_debug_kernel<<<dim3((unsigned)g), dim3(64), 0, stream>>>(a, idx, cnts, off, cands, n);
+    } else k4_debug_counts_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(a, idx, cnts, off, cands, n);
 }
 
 void launch_tail(const ClassifyArgs& a, hipStream_t stream) {

@@ -87,6 +87,8 @@ void launch_k4_end(const ClassifyArgs& a, hipStream_t join_stream, hipStream_t s
                    hipEvent_t joined2, hipEvent_t joined3, hipEvent_t joined_small, hipEvent_t done);
 void launch_k4_debug(const ClassifyArgs& a, const uint32_t* idx, const float* scores, const uint64_t* off, const float* stdevs, uint64_t n,
                      hipStream_t stream);
+void launch_k4_debug_counts(const ClassifyArgs& a, const uint32_t* idx, const uint32_t* cnts, const uint64_t* off, const uint32_t* cands, uint64_t n,
+                            bool on_the_wave, hipStream_t stream);
 int classify_max_read_len();
 size_t classify_gmem_scratch_bytes();
 // issues ~n_probes random bucket reads (rounded up to 144 per wave x 4096 waves)

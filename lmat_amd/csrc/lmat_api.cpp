@@ -1833,6 +1833,55 @@ int lmat_debug_decide(lmat_ctx* c, const uint32_t* tids, const float* scores, co
     return LMAT_OK;
 }
 
+// The decision step on (taxid, count) tables: on_the_wave = 1 runs k4_wave -- the code the benchmarked path runs on the classify
+// wave --, 0 the general path (k4_part1 / k4_part2, the one lmat_debug_decide pins to the reference's printed records).
+int lmat_debug_decide_counts(lmat_ctx* c, const uint32_t* tids, const uint32_t* counts, const uint64_t* off, const uint32_t* cand, uint64_t n,
+                             int on_the_wave, lmat_read_result* results) {
+    if (!c || !tids || !counts || !off || !cand || !results) return LMAT_E_ARG;
+    if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy first");
+    if (!n) return LMAT_OK;
+    hipSetDevice(c->device);
+    const uint64_t total = off[n];
+    std::vector<uint32_t> idx(total);
+    for (uint64_t i = 0; i < total; ++i) {
+        auto it = c->tax.index_of.find(tids[i]);
+        if (it == c->tax.index_of.end()) return set_err(c, LMAT_E_TAXONOMY, "taxid " + std::to_string(tids[i]) + " is not in the taxonomy");
+        idx[i] = it->second;
+        if (counts[i] > 0xFFFFu) return set_err(c, LMAT_E_ARG, "a count above 65535");
+    }
+    uint32_t *d_idx = nullptr, *d_cn = nullptr, *d_cd = nullptr; uint64_t* d_off = nullptr; lmat_read_result* d_res = nullptr; void* d_tally = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_idx, std::max<uint64_t>(total, 1) * 4));
+    HIPCHK(c, hipMalloc((void**)&d_cn, std::max<uint64_t>(total, 1) * 4));
+    HIPCHK(c, hipMalloc((void**)&d_cd, n * 4));
+    HIPCHK(c, hipMalloc((void**)&d_off, (n + 1) * 8));
+    HIPCHK(c, hipMalloc((void**)&d_res, n * sizeof(lmat_read_result)));
+    HIPCHK(c, hipMalloc(&d_tally, c->counts_bytes));   // k4_wave tallies its calls: into a buffer nobody reads
+    HIPCHK(c, hipMemsetAsync(d_tally, 0, c->counts_bytes, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_idx, idx.data(), total * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_cn, counts, total * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_cd, cand, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_off, off, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, kCursorWords * 4, c->stream));
+    ClassifyArgs a;
+    a.tb = c->dev;
+    a.prm = kparams(c->params);
+    a.prm.stop_after = 0;
+    a.results = d_res;
+    a.cands = nullptr;
+    a.cand_cap = 0;
+    a.cursor = c->d_cursor;
+    a.err = c->d_err;
+    a.counts = d_tally;
+    auto it = c->tax.index_of.find(32630);
+    a.phix_call_idx = it == c->tax.index_of.end() ? 0 : it->second;
+    a.nm = NullModelDev();
+    launch_k4_debug_counts(a, d_idx, d_cn, d_off, d_cd, n, on_the_wave != 0, c->stream);
+    HIPCHK(c, hipMemcpyAsync(results, d_res, n * sizeof(lmat_read_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_idx); hipFree(d_cn); hipFree(d_cd); hipFree(d_off); hipFree(d_res); hipFree(d_tally);
+    return LMAT_OK;
+}
+
 int lmat_last_timing(const lmat_ctx* c, float* classify_ms, float* decide_ms, uint64_t* launches) {
     if (!c) return LMAT_E_ARG;
     if (classify_ms) *classify_ms = c->last_classify_ms;

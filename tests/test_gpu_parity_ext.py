@@ -1078,8 +1078,10 @@ def test_device_image_round_trip(tmp_path, small_dataset):
         c.load_image(img)
     assert "label modes" in str(ei.value)
     c.close()
+    from lmat_amd import synth
+    other = synth.write_aux_files(str(tmp_path / "other_tax"), synth.make_taxonomy((2, 2, 2, 3, 2, 2), specials=True))
     d = Engine(0, Params.run_rl())
-    d.load_taxonomy(_GDS["tree"], _GDS["depth"], _GDS["rank"], _GDS["idmap"])
+    d.load_taxonomy(other["tree"], other["depth"], other["rank"], other["idmap"])
     with pytest.raises(LmatError) as ei:
         d.load_image(img)
     assert "taxonomy" in str(ei.value)
