@@ -279,6 +279,8 @@ def main():
     ap.add_argument("--as-ranks", type=int, default=1, help="tests: ONE rank classifies the read sets of this many ranks one after the other (what an N-rank run must add up to)")
     ap.add_argument("--tally-out", default=None, help="tests: rank 0 writes the merged per-taxid tallies to this JSON file")
     ap.add_argument("--genome-len", type=int, default=0, help="bases per strain genome (default: sized so that the table holds ~6.4 k-mers per bucket)")
+    ap.add_argument("--list-tail", default="0,0,0", help="heavy tail of taxid lists: thousandths of every genome that are blocks conserved across a whole family, phylum, superkingdom (lists of 69 / 277 / 1109 taxids): e.g. 20,10,5")
+    ap.add_argument("--prune", type=int, default=0, help="run-time pruning -g N with a numeric rank map (-m): lists longer than N lose their lowest ranks first (TaxNodeStat.hpp:76-203)")
     ap.add_argument("--total-reads", type=int, default=0, help="STRONG scaling (BASELINE config 4: `50M reads sharded across 8`): this many reads in total, split evenly over the ranks and over --steps steps (overrides --batch; `scaling` becomes \"strong\")")
     ap.add_argument("--no-cands", action="store_true", help="skip the value_with_candidates leg (the same window with -p: candidate pairs written, as bin/run_rl.sh runs it)")
     ap.add_argument("--cands-per-read", type=int, default=32, help="capacity of the candidate buffer of the -p leg, pairs per read")
@@ -326,12 +328,25 @@ def main():
 
     eng = Engine(local_rank, Params.run_rl(prn_all=0))  # run_rl.sh flags, calls-only output
     eng.synth_taxonomy(BRANCHING)
+    tail = tuple(int(x) for x in args.list_tail.split(","))
+    if args.prune > 0:  # -g N -m <numeric ranks>: the rank value of a synthetic taxid is its level (strains 6: pruned first)
+        import tempfile as _tf
+        with _tf.NamedTemporaryFile("w", suffix=".ranks", delete=False) as f:
+            f.write("1 0\n")
+            dense, lv_n = 0, 1
+            for lv, b in enumerate(BRANCHING):
+                lv_n *= b
+                for _ in range(lv_n):
+                    dense += 1
+                    f.write(f"{1000 + 7 * dense} {lv + 1}\n")
+            rank_fn = f.name
+        eng.set_label_modes(False, args.prune, rank_fn)
     table_bytes = int(args.db_gb * (1 << 30)) // 64 * 64
     n_species, S = 768, 3
     pm = 1.0 - 0.99 ** k
     G = args.genome_len or int(0.8 * (table_bytes / 8) / (n_species * (1.0 + S * pm)))
     t0 = time.perf_counter()
-    eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes, genus_block_permille=args.genus_permille, list_replicas=args.list_replicas)
+    eng.synth_db(G, k=k, seed=2002, table_bytes=table_bytes, genus_block_permille=args.genus_permille, list_replicas=args.list_replicas, conserved_permille=tail)
     t_build = time.perf_counter() - t0
     log(f"db built: {eng.db_size} k-mers in {t_build:.2f}s, table {table_bytes / 2**30:.1f} GiB, G={G}")
     strong = plan_steps(args, world)
@@ -420,6 +435,7 @@ def main():
             run_step(rs, args.warmup + s)
     kernel_ms, launches = eng.sync()
     classify_ms, decide_ms, _ = eng.last_timing()
+    class_flow = eng.last_counters()   # reads the last launch passed from capacity class to capacity class
     from lmat_amd.shard import allreduce_tallies
     if rehearse and dist is not None:  # gloo: stage through host copies
         host = [x.cpu() for x in (t_cnt, t_sc, t_nm)]
@@ -513,7 +529,8 @@ def main():
                                    f"k-mer hash ({eng.db_size} 20-mers, replicated per GPU), run_rl.sh flags -x 0 -j 30 -l 0 -b 1, calls-only",
                        "total_reads": args.batch * args.steps * world * args.as_ranks, "reads_per_step_per_gpu": args.batch, "launches_per_step": lps, "reads_per_launch": args.launch_reads, "read_len": args.read_len, "db_gib": args.db_gb,
                        "db_kmers": eng.db_size, "k": k, "parallelism": f"reads sharded x{world}, DB replicated",
-                       "db_build_s": round(t_build, 2), "genus_block_permille": args.genus_permille, "list_replicas": args.list_replicas, "distinct_lists": eng.n_lists, "list_arena_mib": round(eng.arena_bytes / 2**20, 1), "reads_called": called, "nomatch": nomatch},
+                       "db_build_s": round(t_build, 2), "genus_block_permille": args.genus_permille, "list_tail_permille": list(tail), "prune_g": args.prune,
+                       "reads_past_each_class_last_launch": dict(class_flow, reads_per_launch=args.launch_reads), "list_replicas": args.list_replicas, "distinct_lists": eng.n_lists, "list_arena_mib": round(eng.arena_bytes / 2**20, 1), "reads_called": called, "nomatch": nomatch},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                          "frac_measured": frac_measured,

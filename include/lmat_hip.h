@@ -147,6 +147,17 @@ int lmat_synth_db_build(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed
  * over (1 = every list once; more make the arena as large as a real database's, beyond the caches). */
 int lmat_synth_db_build2(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes,
                          uint32_t genus_block_permille, uint32_t list_replicas);
+/* ... and with a HEAVY TAIL of taxid lists (real LMAT lists run to thousands of ids, doc/lmat-doc.txt:914-931): behind the genus
+ * block three conserved blocks of conserved_permille3[0..2] thousandths of every genome, shared -- without strain substitutions --
+ * by all species of a family, of a phylum, of a superkingdom: k-mers whose lists hold every strain, species and inner node of the
+ * group (69 / 277 / 1109 taxids in the bench taxonomy).  {0, 0, 0} is lmat_synth_db_build2. */
+int lmat_synth_db_build3(lmat_ctx* ctx, int k, uint64_t genome_len, uint64_t seed, uint64_t table_bytes,
+                         uint32_t genus_block_permille, uint32_t list_replicas, const uint32_t* conserved_permille3);
+
+/* Measurement hook: the 16 per-launch counters of the most recent launch, read after lmat_sync: [0] candidate cursor, [2] reads the
+ * fast classes passed on to the E = 512 class, [3] reads that class passed on to the middle tier (T = 256), [10] reads the middle
+ * tier passed on to the large LDS class (T = 1024), [7] reads that class passed on to the global-memory class. */
+int lmat_debug_last_counters(lmat_ctx* ctx, uint32_t* out16);
 
 /* Measurement hook: where the lookups of these (forward-encoded) k-mers end in the compact table -- out5[0] found in the home
  * bucket, [1] absent and the bucket never spilled (one 64-byte request in all), [2] found in the overflow table, [3] absent after

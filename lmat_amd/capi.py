@@ -89,6 +89,7 @@ def load_library(path: str | None = None):
         "lmat_synth_taxonomy": (i32, [vp, vp]),
         "lmat_synth_db_build": (i32, [vp, i32, u64, u64, u64]),
         "lmat_synth_db_build2": (i32, [vp, i32, u64, u64, u64, u32, u32]),
+        "lmat_synth_db_build3": (i32, [vp, i32, u64, u64, u64, u32, u32, vp]),
         "lmat_reads_upload": (i32, [vp, vp, vp, u64, P(vp)]),
         "lmat_reads_synth": (i32, [vp, u64, vp, u32, u64, P(vp)]),
         "lmat_reads_download_ascii": (i32, [vp, vp, u64, u64, vp, vp]),
@@ -126,6 +127,7 @@ def load_library(path: str | None = None):
         "lmat_debug_decide": (i32, [vp, vp, vp, vp, vp, u64, vp]),
         "lmat_debug_decide_counts": (i32, [vp, vp, vp, vp, vp, u64, i32, vp]),
         "lmat_synth_window": (i32, [vp, u32, u64, P(u64), vp, u32, P(u32)]),
+        "lmat_debug_last_counters": (i32, [vp, vp]),
         "lmat_debug_probe_stats": (i32, [vp, vp, u64, vp]),
         "lmat_synth_read_windows": (i32, [vp, vp, u32, u64, u64, vp, vp, vp, u32, u32, P(u32), P(u32)]),
         "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
@@ -146,13 +148,13 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_ingest_destroy", "lmat_ingest_error", "lmat_ingest_set_options", "lmat_ingest_add_taxhisto",
             "lmat_ingest_save_image", "lmat_ingest_load_image", "lmat_ingest_size", "lmat_ingest_kmer_length",
             "lmat_ingest_lookup", "lmat_db_from_ingest", "lmat_nullmodel_load", "lmat_nullmodel_clear", "lmat_set_label_modes",
-            "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_synth_db_build2", "lmat_reads_upload",
+            "lmat_db_table_bytes", "lmat_db_lookup", "lmat_synth_taxonomy", "lmat_synth_db_build", "lmat_synth_db_build2", "lmat_synth_db_build3", "lmat_reads_upload",
             "lmat_reads_synth", "lmat_reads_download_ascii", "lmat_reads_count", "lmat_reads_device_bytes",
             "lmat_reads_free", "lmat_classify", "lmat_classify_async", "lmat_classify_async_cands", "lmat_comm_available", "lmat_sync", "lmat_last_timing", "lmat_results_fetch",
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
-            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_debug_decide_counts", "lmat_synth_window", "lmat_synth_read_windows", "lmat_debug_probe_stats"]
+            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_debug_decide_counts", "lmat_synth_window", "lmat_synth_read_windows", "lmat_debug_probe_stats", "lmat_debug_last_counters"]
 
 
 def _ptr(a):
@@ -409,9 +411,12 @@ class Engine:
         b = np.asarray(branching, dtype=np.uint32)
         self._chk(self.lib.lmat_synth_taxonomy(self.ctx, _ptr(b)))
 
-    def synth_db(self, genome_len, k=20, seed=2002, table_bytes=0, genus_block_permille=100, list_replicas=1):
-        """Synthetic database on the device: a tenth of every genome is a block shared within its genus."""
-        self._chk(self.lib.lmat_synth_db_build2(self.ctx, k, int(genome_len), seed, int(table_bytes), genus_block_permille, list_replicas))
+    def synth_db(self, genome_len, k=20, seed=2002, table_bytes=0, genus_block_permille=100, list_replicas=1, conserved_permille=(0, 0, 0)):
+        """Synthetic database on the device (SURVEY 8d): a tenth of every genome is a block shared within its genus;
+        conserved_permille: the heavy tail -- blocks shared by a whole family / phylum / superkingdom (lists of 69 / 277 / 1109 taxids)."""
+        cp = np.asarray(conserved_permille, dtype=np.uint32)
+        assert cp.size == 3
+        self._chk(self.lib.lmat_synth_db_build3(self.ctx, k, int(genome_len), seed, int(table_bytes), genus_block_permille, list_replicas, _ptr(cp)))
 
     @property
     def k(self):
@@ -557,6 +562,12 @@ class Engine:
         t = np.zeros(32, dtype=np.uint32)
         self._chk(self.lib.lmat_synth_window(self.ctx, species, int(pos), C.byref(km), _ptr(t), 32, C.byref(n)))
         return int(km.value), t[:n.value].tolist()
+
+    def last_counters(self):
+        """Reads the last launch passed from class to class (after sync()): fast -> E=512 -> middle tier -> large LDS -> global memory."""
+        out = np.zeros(16, dtype=np.uint32)
+        self._chk(self.lib.lmat_debug_last_counters(self.ctx, _ptr(out)))
+        return {"past_fast": int(out[2]), "past_e512": int(out[3]), "past_middle": int(out[10]), "past_large": int(out[7])}
 
     def probe_stats(self, kmers):
         """-> dict: where the lookups of these k-mers end (home bucket / absent at once / overflow hit / overflow miss, overflow buckets read)."""

@@ -309,19 +309,33 @@ __global__ void cpt_merge_overflow_kernel(DeviceTables tb, unsigned long long* t
 // k-mers with many taxids); strain = ancestor with 1% substitutions.  All pure functions of (seed, species / strain,
 // position) so host code can reproduce any window.
 // ------------------------------------------------------------------------------------------
+// which conserved block holds base pos: 0 family, 1 phylum, 2 superkingdom, -1 none (SynthGeo)
+__host__ __device__ __forceinline__ int synth_cons_level(const SynthGeo& g, uint64_t pos) {
+    if (pos < g.blk || pos >= g.cend[2]) return -1;
+    return pos < g.cend[0] ? 0 : (pos < g.cend[1] ? 1 : 2);
+}
 __host__ __device__ __forceinline__ uint32_t synth_anc_base(const SynthGeo& g, uint32_t species, uint64_t pos) {
     if (pos < g.blk) return (uint32_t)(splitmix(g.seed ^ 0x47454E5553ull ^ ((uint64_t)(species / g.spg + 1) << 40) ^ pos) >> 13) & 3u;
+    const int lv = synth_cons_level(g, pos);
+    if (lv >= 0) return (uint32_t)(splitmix(g.seed ^ (0x434F4E5300ull + (uint64_t)lv) ^ ((uint64_t)(species / g.csz[lv] + 1) << 40) ^ pos) >> 13) & 3u;
     return (uint32_t)(splitmix(g.seed ^ ((uint64_t)(species + 1) << 40) ^ pos) >> 13) & 3u;
+}
+__host__ __device__ __forceinline__ bool synth_strain_mut(const SynthGeo& g, uint32_t strain_global, uint64_t pos) {
+    if (synth_cons_level(g, pos) >= 0) return false;   // conserved: every strain carries the group's bases
+    uint64_t h = splitmix((g.seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
+    return (h % 100) == 0;
 }
 __host__ __device__ __forceinline__ uint32_t synth_strain_base(const SynthGeo& g, uint32_t species, uint32_t strain_global, uint64_t pos) {
     uint32_t b = synth_anc_base(g, species, pos);
+    if (synth_cons_level(g, pos) >= 0) return b;
     uint64_t h = splitmix((g.seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
     if ((h % 100) == 0) b = (b + 1 + (uint32_t)((h >> 32) % 3)) & 3u;
     return b;
 }
-__host__ __device__ __forceinline__ bool synth_strain_mut(const SynthGeo& g, uint32_t strain_global, uint64_t pos) {
-    uint64_t h = splitmix((g.seed * 0x2545F4914F6CDD1Dull) ^ ((uint64_t)(strain_global + 1) << 40) ^ pos);
-    return (h % 100) == 0;
+// a window that lies inside ONE conserved block: its level, else -1
+__host__ __device__ __forceinline__ int synth_cons_window(const SynthGeo& g, uint64_t pos, int k) {
+    const int lv = synth_cons_level(g, pos);
+    return lv >= 0 && pos + k <= g.cend[lv] ? lv : -1;
 }
 __host__ __device__ __forceinline__ uint64_t canon_from_fwd(uint64_t fwd, int k) {
     const uint64_t x = revcomp_fwd(fwd, k);
@@ -348,6 +362,13 @@ __global__ void synth_db_kernel(DeviceTables tb, SynthGeo g, int k, const uint16
         if (inblk && sp % g.spg != 0) continue;
         uint64_t anc = 0;
         for (int j = 0; j < k; ++j) anc = (anc << 2) | synth_anc_base(g, sp, pos + j);
+        const int clv = synth_cons_window(g, pos, k);
+        if (clv >= 0) {  // conserved: one k-mer for the whole group, filed by its first species under the group's list
+            if (sp % g.csz[clv] != 0) continue;
+            if (!table_insert(tb, canon_from_fwd(anc, k), list_payload[g.coff[clv] + sp / g.csz[clv]])) atomicAdd(fail, 1u);
+            ++local;
+            continue;
+        }
         const uint32_t ns = inblk ? g.spg * g.S : g.S;   // strains that carry this window; they are numbered from sp * S
         uint32_t mask = 0;
         for (uint32_t s = 0; s < ns; ++s) {
@@ -3902,7 +3923,20 @@ uint32_t synth_strain_base_host(const SynthGeo& g, uint32_t species, uint32_t st
 }
 // what synth_db_kernel files for the ancestor window at (species, pos): the canonical k-mer, the first strain that may carry
 // it, and the mask of those strains (from first_strain on) whose copy of the window has no substitution
-void synth_window_host(const SynthGeo& g, int k, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* first_strain, uint32_t* mask, bool* inblk) {
+void synth_window_host(const SynthGeo& g, int k, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* first_strain, uint32_t* mask, bool* inblk,
+                       int* cons_level) {
+    const int clv = synth_cons_window(g, pos, k);
+    if (cons_level) *cons_level = clv;
+    if (clv >= 0) {  // every strain of the group carries it: first_strain = the group's first, mask unused
+        const uint32_t sp0 = species - species % g.csz[clv];
+        uint64_t anc = 0;
+        for (int j = 0; j < k; ++j) anc = (anc << 2) | synth_anc_base(g, sp0, pos + j);
+        *kmer = canon_from_fwd(anc, k);
+        *first_strain = sp0 * g.S;
+        *mask = 0;
+        *inblk = false;
+        return;
+    }
     const bool blk = pos + k <= g.blk;
     const uint32_t sp = blk ? species - species % g.spg : species;
     uint64_t anc = 0;

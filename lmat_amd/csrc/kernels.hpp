@@ -100,6 +100,7 @@ void launch_gather_bench(const uint64_t* slots, uint32_t nbuckets, uint64_t n_pr
 uint32_t synth_strain_base_host(const SynthGeo& g, uint32_t species, uint32_t strain_global, uint64_t pos);
 uint32_t synth_read_windows_host(const SynthGeo& g, const uint32_t* lengths, uint32_t n_lengths, uint64_t seed, uint64_t r, int k,
                                  uint32_t* len_out, uint32_t* strain_global, uint64_t* gpos, uint32_t* rpos, uint32_t cap);
-void synth_window_host(const SynthGeo& g, int k, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* first_strain, uint32_t* mask, bool* inblk);
+void synth_window_host(const SynthGeo& g, int k, uint32_t species, uint64_t pos, uint64_t* kmer, uint32_t* first_strain, uint32_t* mask, bool* inblk,
+                       int* cons_level = nullptr);
 
 }  // namespace lmat

@@ -925,7 +925,34 @@ int lmat_synth_db_build(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t 
 
 int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t table_bytes, uint32_t genus_block_permille,
                          uint32_t list_replicas) {
+    const uint32_t none[3] = {0, 0, 0};
+    return lmat_synth_db_build3(c, k, G, seed, table_bytes, genus_block_permille, list_replicas, none);
+}
+
+// the taxid list of conserved block `level` (0 family, 1 phylum, 2 superkingdom) of group `grp`, as tax_histo's LCA closure gives
+// it: every strain of the group, their species, and every inner node up to the group's own (src/kmerdb/TaxTree.hpp:160-260)
+static void cons_group_ids(const lmat_ctx* c, int level, uint32_t grp, std::vector<uint16_t>& internal) {
+    const HostTaxonomy& T = c->tax;
+    const SynthGeo& g = c->synth_geo;
+    const uint32_t gsz = g.csz[level], S = g.S, sp0 = grp * gsz;
+    internal.clear();
+    for (uint32_t s = 0; s < gsz * S; ++s) internal.push_back(c->synth_strain_idx[sp0 * S + s]);
+    std::vector<uint16_t> inner;
+    const uint32_t up = (uint32_t)level + 2;   // levels above the species that belong to the group: genus .. the group's root
+    for (uint32_t q = 0; q < gsz; ++q) {
+        const uint16_t sp = c->synth_species_idx[sp0 + q];
+        internal.push_back(sp);
+        for (uint32_t j = 0; j < up && j < T.path_len[sp]; ++j) inner.push_back(T.paths[T.path_off[sp] + j]);
+    }
+    std::sort(inner.begin(), inner.end());
+    inner.erase(std::unique(inner.begin(), inner.end()), inner.end());
+    internal.insert(internal.end(), inner.begin(), inner.end());
+}
+
+int lmat_synth_db_build3(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t table_bytes, uint32_t genus_block_permille,
+                         uint32_t list_replicas, const uint32_t* conserved_permille3) {
     if (!c || !c->tax.loaded || !c->synth_n_species) return set_err(c, LMAT_E_ARG, "lmat_synth_taxonomy first");
+    if (!conserved_permille3) return LMAT_E_ARG;
     if (k < 1 || k > 20 || G < (uint64_t)k) return set_err(c, LMAT_E_ARG, "bad k / genome length");
     if (genus_block_permille > 1000 || list_replicas < 1) return set_err(c, LMAT_E_ARG, "bad genus block share / replica count");
     hipSetDevice(c->device);
@@ -937,6 +964,19 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
     geo.seed = seed; geo.G = G; geo.n_species = NS; geo.S = S; geo.spg = spg;
     geo.blk = GB <= 12 && NS % spg == 0 ? G * genus_block_permille / 1000 : 0;  // the genus lists are a table over 2^GB strain subsets
     if (geo.blk < (uint64_t)k) geo.blk = 0;
+    {   // the heavy tail: conserved blocks behind the genus block (SynthGeo); group sizes follow the taxonomy's branching
+        uint64_t at = geo.blk;
+        uint32_t gsz = spg;
+        for (int l = 0; l < 3; ++l) {
+            gsz *= std::max<uint32_t>(c->synth_branching[3 - l], 1);   // genera per family, families per phylum, phyla per superkingdom
+            uint64_t len = conserved_permille3[l] > 1000 ? 0 : G * conserved_permille3[l] / 1000;
+            if (len < (uint64_t)k || NS % gsz != 0) len = 0;
+            at += len;
+            geo.cend[l] = at;
+            geo.csz[l] = gsz;
+        }
+        if (geo.cend[2] >= G) return set_err(c, LMAT_E_ARG, "the shared blocks leave no room for the species' own bases");
+    }
     const uint32_t NG = NS / spg;
     const HostTaxonomy& T = c->tax;
     auto id16 = [&](uint16_t internal) { return T.br.at(T.tid32[internal]); };
@@ -944,7 +984,11 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
     // genus block, per (genus, non-empty subset of its strains): owners + their species + the genus when the owners span
     // species -- what tax_histo's LCA closure yields (src/kmerdb/TaxTree.hpp:160-260).  Records are built on all host cores.
     const uint64_t g_off = (uint64_t)NS << S;
-    std::vector<uint32_t> list_payload(g_off + (geo.blk ? (uint64_t)NG << GB : 0), 0);
+    const uint64_t c_off0 = g_off + (geo.blk ? (uint64_t)NG << GB : 0);
+    uint64_t n_cons = 0;
+    for (int l = 0; l < 3; ++l) { geo.coff[l] = c_off0 + n_cons; n_cons += geo.cend[l] > (l ? geo.cend[l - 1] : geo.blk) ? NS / geo.csz[l] : 0; }
+    std::vector<uint32_t> list_payload(c_off0 + n_cons, 0);
+    c->synth_geo = geo;   // (cons_group_ids reads the group sizes)
     struct Made { uint64_t slot; std::vector<uint16_t> rec; };
     const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::vector<Made>> made(nthr);
@@ -981,6 +1025,17 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
         for (auto& x : th) x.join();
     }
     for (int b_ : bad) if (b_) return LMAT_E_TAXONOMY;
+    for (int l = 0; l < 3; ++l) {   // one list per conserved group
+        if (geo.cend[l] <= (l ? geo.cend[l - 1] : geo.blk)) continue;
+        std::vector<uint16_t> ids, raw, rec;
+        for (uint32_t grp = 0; grp < NS / geo.csz[l]; ++grp) {
+            cons_group_ids(c, l, grp, ids);
+            raw.clear();
+            for (uint16_t x : ids) raw.push_back(id16(x));
+            if (!build_list_record(c, raw, rec)) return LMAT_E_TAXONOMY;
+            made[0].push_back({geo.coff[l] + grp, rec});
+        }
+    }
     // records on the smallest alignment at which all copies fit the 24-bit payloads (16 bytes: 256 MB ... 256 bytes: 4 GB)
     std::vector<uint16_t> arena;
     uint64_t block_units = 0;
@@ -1026,7 +1081,13 @@ int lmat_synth_db_build2(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
     // expected distinct k-mers ~ windows * (1 + owners * P(window mutated)); size the table from that
     const double pm = 1.0 - std::pow(0.99, k);
     const double npos = (double)(G - k + 1), nblk = geo.blk ? (double)(geo.blk - k + 1) : 0.0;
-    const uint64_t est = (uint64_t)((double)NS * (npos - nblk) * (1.0 + S * pm) + (double)NG * nblk * (1.0 + GB * pm));
+    double ncons = 0, cons_kmers = 0;   // windows of the conserved blocks: one k-mer per group, no strain variants
+    for (int l = 0; l < 3; ++l) {
+        const double len = (double)(geo.cend[l] - (l ? geo.cend[l - 1] : geo.blk));
+        ncons += len;
+        cons_kmers += len * (double)(NS / geo.csz[l]);
+    }
+    const uint64_t est = (uint64_t)((double)NS * (npos - nblk - ncons) * (1.0 + S * pm) + (double)NG * nblk * (1.0 + GB * pm) + cons_kmers);
     if ((rc = alloc_table(c, est, table_bytes, k))) return rc;
     c->dev.k = k;
     uint32_t* d_fail = nullptr;
@@ -1065,8 +1126,16 @@ int lmat_synth_window(lmat_ctx* c, uint32_t species, uint64_t pos, uint64_t* kme
     if (species >= g.n_species || pos + k > g.G) return set_err(c, LMAT_E_ARG, "window outside the synthetic genomes");
     uint32_t first = 0, mask = 0;
     bool inblk = false;
-    synth_window_host(g, k, species, pos, kmer, &first, &mask, &inblk);
+    int clv = -1;
+    synth_window_host(g, k, species, pos, kmer, &first, &mask, &inblk, &clv);
     const HostTaxonomy& T = c->tax;
+    if (clv >= 0) {  // a conserved block: the whole group's list
+        std::vector<uint16_t> ids;
+        cons_group_ids(c, clv, species / g.csz[clv], ids);
+        *n = (uint32_t)ids.size();
+        for (uint32_t i = 0; i < ids.size() && i < cap; ++i) if (tids) tids[i] = T.tid32[ids[i]];
+        return LMAT_OK;
+    }
     std::vector<uint32_t> out;
     const uint32_t S = g.S, ns = inblk ? g.spg * S : S;
     uint32_t spmask = 0;
@@ -1106,11 +1175,16 @@ int lmat_synth_read_windows(lmat_ctx* c, const uint32_t* lengths, uint32_t n_len
         uint64_t km = 0;
         uint32_t first = 0, mask = 0;
         bool inblk = false;
-        synth_window_host(g, k, sp, gpos[w], &km, &first, &mask, &inblk);
+        int clv = -1;
+        synth_window_host(g, k, sp, gpos[w], &km, &first, &mask, &inblk, &clv);
         uint32_t* out = tids + (size_t)w * stride;
         uint32_t cnt = 0;
         auto put = [&](uint32_t t) { if (cnt < stride) out[cnt] = t; ++cnt; };
-        if (mask & (1u << (sg - first))) {  // the strain carries the ancestor's window: its owners' list
+        if (clv >= 0) {  // a conserved block: the whole group's list (longer than `stride` it is cut: counts[w] still says how long)
+            std::vector<uint16_t> ids;
+            cons_group_ids(c, clv, sp / g.csz[clv], ids);
+            for (uint16_t x : ids) put(T.tid32[x]);
+        } else if (mask & (1u << (sg - first))) {  // the strain carries the ancestor's window: its owners' list
             const uint32_t ns = inblk ? g.spg * S : S;
             uint32_t spmask = 0, owners = 0;
             for (uint32_t s_ = 0; s_ < ns; ++s_)
@@ -1879,6 +1953,16 @@ int lmat_debug_decide_counts(lmat_ctx* c, const uint32_t* tids, const uint32_t* 
     HIPCHK(c, hipMemcpyAsync(results, d_res, n * sizeof(lmat_read_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(d_idx); hipFree(d_cn); hipFree(d_cd); hipFree(d_off); hipFree(d_res); hipFree(d_tally);
+    return LMAT_OK;
+}
+
+// Measurement hook: the per-launch counter block of the most recent launch (after lmat_sync): [0] candidate cursor, [2] reads the
+// fast classes passed on, [3] reads the E = 512 class passed on, [10] the middle tier, [7] the large LDS class, [4] / [5] / [8] / [9]
+// reads handed to the general decision path by table size.
+int lmat_debug_last_counters(lmat_ctx* c, uint32_t* out16) {
+    if (!c || !out16) return LMAT_E_ARG;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpy(out16, c->d_cursor, kCursorWords * 4, hipMemcpyDeviceToHost));
     return LMAT_OK;
 }
 

@@ -76,6 +76,13 @@ struct NullModelDev {
 struct SynthGeo {
     uint64_t seed = 0, G = 0, blk = 0;   // genome length; the first blk bases are shared by the species of a genus
     uint32_t n_species = 0, S = 0, spg = 1;  // strains per species, species per genus
+    // Heavy tail (round 4): behind the genus block, three CONSERVED blocks -- [blk, cend[0]) shared by the csz[0] species of a
+    // family, [cend[0], cend[1]) by those of a phylum, [cend[1], cend[2]) by those of a superkingdom, without strain
+    // substitutions (think rRNA operons): k-mers whose taxid lists hold every strain, species and inner node of the group
+    // (69 / 277 / 1109 taxids in the bench taxonomy).  coff[l]: where level l's list payloads start in the generator's table.
+    uint64_t cend[3] = {0, 0, 0};
+    uint32_t csz[3] = {1, 1, 1};
+    uint64_t coff[3] = {0, 0, 0};
 };
 
 struct KernelParams {

@@ -96,6 +96,12 @@ def _random_count_tables(tax, n_tables, seed):
     levels = rng.integers(1, 6, n_tables)                    # distinct count values of a table
     cnt = (cand[tab] * (1 + rng.integers(0, levels[tab])) // (1 + levels[tab])).astype(np.int64)
     cnt = np.where(rng.random(tab.size) < 0.1, rng.integers(0, cand[tab] + 1), cnt)
+    # half of the tables the way reads make them: an ancestor counts at least what its descendants do (the lineage closure adds a
+    # position to every ancestor of its ids), so counts fall with depth and relatives of one depth tie
+    depth = np.array([tax.depth[t] for t in tax.ids], dtype=np.int64)
+    mono = (rng.random(n_tables) < 0.5)[tab]
+    cnt_m = np.minimum(cand[tab], cand[tab] * (9 - np.minimum(depth[pick], 8)) // 10 + rng.integers(0, 2, tab.size))
+    cnt = np.where(mono, cnt_m, cnt)
     return ids[pick].astype(np.uint32), cnt.astype(np.uint32), off, cand.astype(np.uint32)
 
 
@@ -133,5 +139,5 @@ def test_k4_wave_equals_the_general_decision_path_on_a_million_tables(tmp_path):
         declined_big += int((~took & (cand <= 999)).sum())
         kinds += np.bincount(gen["match_type"][took], minlength=8)[:8]
     assert total == 1_200_000 and taken > 0.9 * total
-    assert (kinds[:3] > 1000).all(), kinds     # direct, multi and partial matches all occur among the compared tables (LMAT_MT_*)
+    assert (kinds[:3] > 100).all(), kinds     # direct, multi and partial matches all occur among the compared tables (LMAT_MT_*)
     eng.close()

@@ -1100,3 +1100,86 @@ def test_device_image_round_trip(tmp_path, small_dataset):
     for suffix in ("0.out", ".0.30.fastsummary", ".0.30.nomatchsum"):
         assert open(str(tmp_path / "o1") + suffix).read() == open(str(tmp_path / "o2") + suffix).read(), suffix
     assert len(open(str(tmp_path / "o2") + "0.out").read()) > 1000
+
+
+# ---- heavy tail of taxid lists (lmat_synth_db_build3): every capacity tier of the classify kernels, against the oracle ------
+def test_heavy_tail_lists_parity(tmp_path):
+    """Real LMAT lists run to thousands of taxids (doc/lmat-doc.txt:914-931).  The synthetic database gets blocks conserved across a
+    whole family / phylum / superkingdom -- k-mers with lists of 69 / 277 / 1109 taxids -- and 3.5 % of the reads come from them:
+    more than 64 registered taxids (middle tier, T = 256), more than 256 (large LDS class, T = 1024), more than 1024 (global-memory
+    class, T = 4096).  Byte-identical .out text against the CPU oracle, whose lists are derived on the host; then the same reads
+    under run-time pruning (-g 64 -m ranks, TaxNodeStat.hpp:76-203), which keeps every read in the fast tiers."""
+    from lmat_amd import Engine, Params, synth
+    import oracle_py
+    br = (3, 4, 4, 4, 4, 3)
+    lens, n, seed = (150,), 6000, 3003
+    tax = synth.make_taxonomy(br, specials=False)
+    p = synth.write_aux_files(str(tmp_path), tax)
+    rank_fn = str(tmp_path / "numeric_ranks.txt")
+    with open(rank_fn, "w") as f:
+        for t in tax.ids:
+            f.write(f"{t} {tax.depth[t]}\n")
+    table_bytes = int(8.3 * (1 << 30))
+    Glen = int(0.8 * (table_bytes / 8) / (768 * (1.0 + 3 * (1 - 0.99 ** 20))))
+    for prune in (0, 64):
+        eng = Engine(0, Params.run_rl())
+        eng.synth_taxonomy(br)
+        if prune:
+            eng.set_label_modes(False, prune, rank_fn)
+        eng.synth_db(Glen, k=20, seed=2002, table_bytes=table_bytes, conserved_permille=(20, 10, 5))
+        reads = eng.synth_reads(n, lens, seed=seed)
+        res, cands = eng.classify(reads, cand_cap=1300 * n)
+        flow = eng.last_counters()
+        blob, off = reads.ascii(0, n)
+        orc = oracle_py.Oracle(p["tree"], p["depth"], p["rank"], p["idmap"])
+        orc.set_k(20)
+        orc.set_options()
+        if prune:
+            orc.set_label_modes(False, prune, rank_fn)
+        kms = np.unique(np.concatenate([orc.extract(bytes(blob[int(off[i]):int(off[i + 1])]), 20)[0] for i in range(n)]))
+        # host-derived lists (the two generators re-run on the host); long ones in a second pass with room for 1109 ids
+        hk, hc, ht, long_reads = [], [], [], []
+        for i in range(n):
+            a, b, c_ = eng.synth_read_windows(lens, seed, i)
+            if (b > 32).any():
+                long_reads.append(i)
+                keep = b <= 32
+                a, b, c_ = a[keep], b[keep], c_[keep]
+            hk.append(a); hc.append(b); ht.append(c_)
+        hk, hc, ht = np.concatenate(hk), np.concatenate(hc), np.concatenate(ht)
+        hk, ix = np.unique(hk, return_index=True)
+        hc, ht = hc[ix], ht[ix]
+        lk, lc, lt = [], [], []
+        for i in long_reads:
+            a, b, c_ = eng.synth_read_windows(lens, seed, i, stride=1152)
+            keep = b > 32
+            lk.append(a[keep]); lc.append(b[keep]); lt.append(c_[keep])
+        assert len(long_reads) > 0.02 * n
+        lk, lc, lt = np.concatenate(lk), np.concatenate(lc), np.concatenate(lt)
+        lk, ix = np.unique(lk, return_index=True)
+        lc, lt = lc[ix], lt[ix]
+        assert set(np.unique(lc).tolist()) == {69, 277, 1109}   # family, phylum and superkingdom lists all occur
+        # The oracle prunes raw lists itself, at lookup time (TaxNodeStat::begin), and the engine's records keep the raw list beside
+        # the pruned one (lookups return the raw one): with and without -g the oracle is fed the RAW lists -- host-derived where
+        # they can be, the table's own answers only for collisions and chance hits.
+        gc_, gt_ = eng.lookup(hk, stride=32)
+        same = (gc_ == hc) & (np.sort(gt_, axis=1) == np.sort(ht, axis=1)).all(axis=1)
+        assert same.mean() > 0.995
+        glc, glt = eng.lookup(lk, stride=1152)
+        assert (glc == lc).all() and (np.sort(glt, axis=1) == np.sort(lt, axis=1)).all()
+        rest = np.setdiff1d(kms, np.concatenate([hk, lk]))
+        rc_, rt_ = eng.lookup(rest, stride=32)
+        assert rc_.max() <= 32
+        orc.add_lists32(np.concatenate([hk, rest]), np.concatenate([np.where(same, hc, gc_), rc_]),
+                        np.concatenate([np.where(same[:, None], ht, gt_), rt_]))
+        orc.add_lists32(lk, lc, lt)
+        if not prune:
+            assert flow["past_fast"] > 0.02 * n and flow["past_e512"] > 0.02 * n and flow["past_middle"] > 0.008 * n and flow["past_large"] > 0.002 * n, flow
+        else:
+            assert flow["past_e512"] <= 2, flow   # pruned lists: nobody needs more than the fast tiers
+        want, _, _ = orc.classify(np.append(blob, np.uint8(0)), off, 20)
+        got = eng.format_out(res, cands, (np.append(blob, np.uint8(0)), off))
+        assert got == want
+        orc.close()
+        reads.free()
+        eng.close()
