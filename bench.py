@@ -484,8 +484,8 @@ def main():
         c_classify_ms, _, _ = eng.last_timing()
         barrier()
         c_dt = reduce_max(time.perf_counter() - t0)
-        tail = eng.fetch_results(0, min(args.launch_reads, 1_000_000))   # records of the last launch: pairs written per read
-        with_cands = {"dt": c_dt, "classify_ms": c_classify_ms, "launches": c_launches, "pairs_per_read": float(tail["n_cand"].mean())}
+        last_recs = eng.fetch_results(0, min(args.launch_reads, 1_000_000))   # records of the last launch: pairs written per read
+        with_cands = {"dt": c_dt, "classify_ms": c_classify_ms, "launches": c_launches, "pairs_per_read": float(last_recs["n_cand"].mean())}
         eng.set_params(Params.run_rl(prn_all=0))
     if rank == 0:
         counts, nomatch = merged

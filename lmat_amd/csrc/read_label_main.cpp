@@ -38,6 +38,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <deque>
 #include <queue>
 #include <thread>
 #include <vector>
@@ -173,6 +174,45 @@ static void parse_fasta_piece(const char* p, const char* end, Batch& b) {
         p = nl ? nl + 1 : end;
     }
     close();
+}
+
+// A piece of a FASTQ file between two synchronised cut points (below) -> one batch: FastxReader's state machine (fastx.hpp;
+// src/read_label.cpp:1651-1713) run over memory, with its quirks -- a record is pushed at its '+' / '-' line under the header of
+// the PREVIOUS record, exactly one quality line is skipped, a '>' line is both a header and sequence.  prev_hdr: the header in
+// force when the piece starts (the last '@' line before it); last: this piece ends the file (the machine's turn at end of input).
+static void parse_fastq_piece(const char* p, const char* end, const std::string& prev_hdr, bool last, Batch& b) {
+    b.clear();
+    std::string hdr = prev_hdr, last_hdr;
+    size_t rec0 = 0;   // where the open record's bases start
+    bool finished = false;
+    while (!finished) {
+        const char* line = p;
+        size_t len = 0;
+        if (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            len = (size_t)((nl ? nl : end) - p);
+            p = nl ? nl + 1 : end;
+        } else {
+            if (!last) break;
+            finished = true;
+        }
+        char c0 = len ? line[0] : '\0';
+        if (c0 == '>' || c0 == '@') { last_hdr = hdr; hdr.assign(line + 1, len - 1); }
+        if (c0 != '@' && c0 != '+' && c0 != '-') {
+            if (len && !b.add_bases(line, len)) return;
+            c0 = '\0';
+        }
+        if ((finished || c0 == '+' || c0 == '-') && b.nb > rec0) {
+            b.off.push_back(b.nb);
+            const std::string& h = finished ? hdr : last_hdr;
+            b.add_hdr(h.data(), h.size());
+            rec0 = b.nb;
+            if (p < end) {  // the quality line
+                const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+                p = nl ? nl + 1 : end;
+            }
+        }
+    }
 }
 
 // One batch on its way through the three stages: parse (reader thread) -> classify (main thread, GPU) ->
@@ -421,12 +461,54 @@ int main(int argc, char* argv[]) {
         in = &qf;
     }
     std::cout << "Classifing reads in parallel with " << n_threads << " processes in .out files..." << std::endl;
-    std::vector<std::ofstream> ofs(n_threads);
+    // The <o><t>.out shards are independent files (read_label.cpp:1642-1647): each has a writer thread of its own, fed in input
+    // order by the sequencer below -- one thread pushing every shard's text through one ofstream after the other was the
+    // pipeline's narrowest stage (round 3: 22 M reads/s with -p).
+    struct ShardOut {
+        int fd = -1;
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<std::string> q;
+        bool closed = false, bad = false;
+        double busy = 0;
+    };
+    std::vector<ShardOut> shard(n_threads);
     for (int t = 0; t < n_threads; ++t) {
         std::ostringstream nm;
         nm << ofbase << t << ".out";
-        ofs[t].open(nm.str().c_str());
+        shard[t].fd = open(nm.str().c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     }
+    std::vector<std::thread> shard_writers;
+    for (int t = 0; t < n_threads; ++t)
+        shard_writers.emplace_back([&shard, t]() {
+            ShardOut& so = shard[t];
+            for (;;) {
+                std::string s;
+                {
+                    std::unique_lock<std::mutex> l(so.m);
+                    so.cv.wait(l, [&] { return !so.q.empty() || so.closed; });
+                    if (so.q.empty()) break;
+                    s.swap(so.q.front());
+                    so.q.pop_front();
+                    so.cv.notify_all();
+                }
+                auto t0 = std::chrono::steady_clock::now();
+                for (size_t w = 0; w < s.size() && so.fd >= 0;) {
+                    const ssize_t r = write(so.fd, s.data() + w, s.size() - w);
+                    if (r <= 0) { so.bad = true; break; }
+                    w += (size_t)r;
+                }
+                so.busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+        });
+    auto shard_push = [&shard](int t, std::string&& s) {
+        if (s.empty()) return;
+        ShardOut& so = shard[t];
+        std::unique_lock<std::mutex> l(so.m);
+        so.cv.wait(l, [&] { return so.q.size() < 6 || so.closed; });
+        so.q.emplace_back(std::move(s));
+        so.cv.notify_all();
+    };
 
     std::map<uint32_t, int> merge_count;
     std::map<uint32_t, float> merge_score;
@@ -436,7 +518,7 @@ int main(int argc, char* argv[]) {
     size_t acc_mask = acc.size() - 1, acc_n = 0;
     int nm_acc[3] = {0, 0, 0};
     std::atomic<size_t> read_count(0);
-    double t_parse = 0, t_gpu = 0, t_fmt = 0, t_write = 0, t_tally = 0;  // LMAT_CLI_TIMING=1 prints the busy time of each stage
+    double t_parse = 0, t_gpu = 0, t_fmt = 0, t_write = 0, t_write_seq = 0, t_tally = 0;  // LMAT_CLI_TIMING=1 prints the busy time of each stage
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b_) { return std::chrono::duration<double>(b_ - a).count(); };
     WorkQueue parsed(4), classified(8);
@@ -448,7 +530,8 @@ int main(int argc, char* argv[]) {
     // line-order dependent).  Batches may reach the writer out of order; it puts them back.
     const char* map_base = nullptr;
     size_t map_size = 0;
-    if (!fastq && query_fn != "-") {
+    static const bool fastq_seq = getenv("LMAT_FASTQ_SEQUENTIAL") && atoi(getenv("LMAT_FASTQ_SEQUENTIAL")) != 0;  // (the one-thread reader, for A/B runs)
+    if ((!fastq || !fastq_seq) && query_fn != "-") {
         int fd = open(query_fn.c_str(), O_RDONLY);
         struct stat sb;
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
@@ -484,14 +567,56 @@ int main(int argc, char* argv[]) {
                         break;
                     }
                     if (at >= map_size) break;
-                    if (map_base[at] == '>') { c = at; break; }
-                    if (at - start + (64u << 10) >= kBatchBases) { c = at; break; }  // a record longer than a piece: cut between its lines
+                    if (fastq) {
+                        // A FASTQ piece starts where the sequential reader is provably between two records: at an '@' line that
+                        // follows [sequence line]['+' or '-' line][one more line = the quality line it skips].  (A quality line may
+                        // itself start with '@' or '+': then the lines in front of it do not fit, and the search moves on.)
+                        auto prev_line = [&](size_t ls) -> size_t {  // start of the line in front of the one that starts at ls
+                            if (ls <= start + 1) return (size_t)-1;
+                            const char* q = (const char*)memrchr(map_base + start, '\n', ls - 1 - start);
+                            return q ? (size_t)(q - map_base) + 1 : start;
+                        };
+                        if (map_base[at] == '@') {
+                            const size_t l1 = prev_line(at), l2 = l1 == (size_t)-1 ? l1 : prev_line(l1), l3 = l2 == (size_t)-1 ? l2 : prev_line(l2);
+                            if (l3 != (size_t)-1 && (map_base[l2] == '+' || map_base[l2] == '-') && l2 - l3 > 1 &&
+                                map_base[l3] != '@' && map_base[l3] != '+' && map_base[l3] != '-' && map_base[l3] != '>') { c = at; break; }
+                        }
+                    } else if (map_base[at] == '>') { c = at; break; }
+                    if (at - start + (64u << 10) >= kBatchBases) {  // a record longer than a piece: cut between its lines
+                        if (fastq) {   // (a FASTQ reader cut anywhere else than between records would lose its place: refuse)
+                            std::lock_guard<std::mutex> l(fail_m);
+                            if (!failed.exchange(true)) fail_msg = "input: no FASTQ record boundary within " + std::to_string(kBatchBases) + " bytes (LMAT_FASTQ_SEQUENTIAL=1 reads such a file with one thread)";
+                            cut_failed = true;
+                        }
+                        c = at;
+                        break;
+                    }
                     pos = at;
                 }
                 if (!cut_failed) cut.push_back(c);
             }
             if (cut_failed) { parsed.close(); return; }
             const size_t np = cut.size() - 1;
+            // FASTQ: the header in force at each cut = the last '@' line in front of it (the previous record's: sequence lines do
+            // not start with '@', and the line right before the cut is the skipped quality line, which may)
+            std::vector<std::string> cut_hdr(np);
+            if (fastq)
+                for (size_t j = 1; j < np; ++j) {
+                    size_t ls = cut[j];
+                    auto back = [&](size_t x) -> size_t {
+                        if (x == 0) return (size_t)-1;
+                        const char* q = x >= 2 ? (const char*)memrchr(map_base, '\n', x - 1) : nullptr;
+                        return q ? (size_t)(q - map_base) + 1 : 0;
+                    };
+                    ls = back(ls);                 // the quality line
+                    if (ls != (size_t)-1) ls = back(ls);   // the '+' line
+                    while (ls != (size_t)-1 && ls != 0 && map_base[ls] != '@') ls = back(ls);
+                    if (ls != (size_t)-1 && map_base[ls] == '@') {
+                        const char* nl = (const char*)memchr(map_base + ls, '\n', map_size - ls);
+                        const size_t le = nl ? (size_t)(nl - map_base) : map_size;
+                        cut_hdr[j].assign(map_base + ls + 1, le - ls - 1);
+                    }
+                }
             std::atomic<size_t> next_piece(0);
             std::vector<std::thread> th;
             for (unsigned t = 0; t < n_parse; ++t)
@@ -500,7 +625,8 @@ int main(int argc, char* argv[]) {
                         std::unique_ptr<Work> w(new Work());  // takes its base buffer BEFORE its piece: whoever holds piece i can always finish it
                         const size_t j = next_piece.fetch_add(1);
                         if (j >= np) break;
-                        parse_fasta_piece(map_base + cut[j], map_base + cut[j + 1], w->b);
+                        if (fastq) parse_fastq_piece(map_base + cut[j], map_base + cut[j + 1], cut_hdr[j], j + 1 == np, w->b);
+                        else parse_fasta_piece(map_base + cut[j], map_base + cut[j + 1], w->b);
                         if (w->b.overflow) {
                             std::lock_guard<std::mutex> l(fail_m);
                             if (!failed.exchange(true)) fail_msg = "input: a piece of the query file exceeds the batch buffer";
@@ -627,9 +753,9 @@ int main(int argc, char* argv[]) {
             }
             const std::vector<lmat_read_result>& res = w->res;
             const size_t n = w->b.n();
-            for (int t = 0; t < n_threads; ++t) ofs[t] << w->text[t];
+            for (int t = 0; t < n_threads; ++t) shard_push(t, std::move(w->text[t]));
             auto tp4 = now();
-            t_write += secs(tp3, tp4);
+            t_write_seq += secs(tp3, tp4);
             // tallies in read order (proc_line :1241-1276), float sums like a -t 1 run.  One thread sees every record, so the
             // per-taxid sums live in an open-addressing table (three std::map searches per read were the writer's largest
             // cost: 28 ns of its 37 per read) and go into the maps the summaries are made from when the run is over.
@@ -735,6 +861,16 @@ int main(int argc, char* argv[]) {
     reader.join();
     for (auto& x : formatters) x.join();
     writer.join();
+    for (auto& so : shard) { std::lock_guard<std::mutex> l(so.m); so.closed = true; so.cv.notify_all(); }
+    for (auto& x : shard_writers) x.join();
+    for (auto& so : shard) {
+        t_write = std::max(t_write, so.busy);
+        if (so.fd < 0 || so.bad || close(so.fd) != 0) {
+            std::lock_guard<std::mutex> l(fail_m);
+            if (!failed.exchange(true)) fail_msg = "cannot write an output shard (" + ofbase + "<t>.out)";
+        }
+        so.fd = -1;
+    }
     for (const Acc& a : acc)
         if (a.used) { merge_count[a.tid] = a.cnt; merge_score[a.tid] = a.score; }
     for (int j = 0; j < 3; ++j)
@@ -757,10 +893,9 @@ int main(int argc, char* argv[]) {
         for (int j = 0; same && j < 3; ++j) same = (uint64_t)(nomatch_merge.count(j) ? nomatch_merge[j] : 0) == nm3[j];
         if (!same) { std::cerr << "ERROR! the merged device tallies differ from the per-record tallies" << std::endl; destroy_all(); return -1; }
     }
-    for (auto& o : ofs) o.close();
     if (getenv("LMAT_CLI_TIMING"))
         std::cerr << "[read_label] stage busy time: parse " << t_parse << " s, GPU feed (copy into the pinned slots + waiting for results, busiest of "
-                  << n_gpu << " GPUs) " << t_gpu << " s, format (busiest of " << n_fmt << " workers) " << t_fmt << " s, write " << t_write << " s, tally " << t_tally << " s" << std::endl;
+                  << n_gpu << " GPUs) " << t_gpu << " s, format (busiest of " << n_fmt << " workers) " << t_fmt << " s, sequencer " << t_write_seq << " s, write (busiest shard) " << t_write << " s, tally " << t_tally << " s" << std::endl;
     const double t_pipeline = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     std::cout << "Finished classifing reads, doing final steps sequentially..." << std::endl;
 

@@ -151,6 +151,47 @@ def test_parallel_fasta_front_end_equals_the_sequential_reader(small_dataset, tm
         assert "unknown_hdr:" in outs[0] or name == "plain"
 
 
+def test_parallel_fastq_front_end_equals_the_sequential_reader(small_dataset, tmp_path):
+    """A FASTQ file is mapped and parsed in pieces too (round 4): pieces start where the sequential reader is provably between
+    two records, and run its state machine -- header of the PREVIOUS record, one quality line skipped (read_label.cpp:1651-1713).
+    Same files as the one-thread reader (LMAT_FASTQ_SEQUENTIAL=1) and as stdin, with pieces of a few hundred bytes, for the
+    plain file and for one full of traps: quality lines that start with '@', '+' and '-', '-' separators, a '>' line, blank
+    lines, CR LF, no final newline."""
+    ds = small_dataset
+    real = [l.rstrip("\n") for l in open(ds["fasta"]) if not l.startswith(">")]
+    tricky = str(tmp_path / "tricky.fq")
+    with open(tricky, "w") as f:
+        for i, s_ in enumerate(real[:240]):
+            q = "I" * len(s_)
+            if i % 7 == 1: q = "@" + q[1:]          # a quality line that looks like a header
+            if i % 7 == 2: q = "+" + q[1:]          # ... like a separator
+            if i % 7 == 3: q = "-" + q[1:]
+            sep = "-" if i % 5 == 4 else ("+r%d" % i if i % 5 == 3 else "+")
+            if i == 20: f.write(">stray fasta header\n")   # header AND sequence in -q mode
+            if i == 30: f.write("\n")
+            eol = "\r\n" if i % 11 == 5 else "\n"
+            f.write("@q%d some text\t%d%s%s%s%s%s%s" % (i, i, eol, s_, eol, sep, eol, q))
+            f.write(eol if i < 239 else "")
+    for name, query in (("plain", ds["fastq"]), ("tricky", tricky)):
+        for shards in (1,):
+            outs = []
+            for mode in ("sequential", "stdin", "pieces", "pieces_big"):
+                out = str(tmp_path / f"{name}_{shards}_{mode}")
+                args = [EXE, "-f", ds["idmap"], "-u", ds["names"], "-w", ds["rank"], "-x", "0", "-j", "30", "-l", "0", "-b", "1.0", "-q",
+                        "-e", ds["depth"], "-p", "-t", str(shards), "-i", "-" if mode == "stdin" else query, "-d", ds["db"], "-c", ds["tree"], "-o", out]
+                env = dict(os.environ)
+                if mode == "sequential": env["LMAT_FASTQ_SEQUENTIAL"] = "1"
+                if mode == "pieces": env["LMAT_FASTA_PIECE"] = "700"
+                r = subprocess.run(args, capture_output=True, text=True, env=env, stdin=open(query) if mode == "stdin" else None)
+                assert r.returncode == 0, r.stderr + r.stdout
+                # (shards cut every batch: with several shards the shard files depend on the batching, their sorted lines do not)
+                body = "".join(open(out + f"{t}.out").read() for t in range(shards))
+                outs.append((sorted(body.splitlines()) if shards > 1 else body, open(out + ".0.30.fastsummary").read()))
+            assert outs[0] == outs[1] == outs[2] == outs[3], (name, shards)
+            text = outs[0][0] if shards == 1 else "\n".join(outs[0][0])
+            assert "unknown_hdr:1\t" in text
+
+
 # ---- the contract with bin/run_rl.sh: its own argv, recorded from the script (tests/golden/make_run_rl_argv.py) ----------
 def _run_rl_cases():
     import json

@@ -139,5 +139,6 @@ def test_k4_wave_equals_the_general_decision_path_on_a_million_tables(tmp_path):
         declined_big += int((~took & (cand <= 999)).sum())
         kinds += np.bincount(gen["match_type"][took], minlength=8)[:8]
     assert total == 1_200_000 and taken > 0.9 * total
-    assert (kinds[:3] > 100).all(), kinds     # direct, multi and partial matches all occur among the compared tables (LMAT_MT_*)
+    assert (kinds[:2] > 1000).all(), kinds     # direct and multi matches both occur among the compared tables (a partial match needs max_val below
+                                               # the root's own score, which the max over the entries up to AND including the root never is, :386-404)
     eng.close()
