@@ -50,8 +50,8 @@ def main():
         rs.free()
         eng.close()
         n = a.reads
-        rec = np.empty((n, 10 + 151), dtype=np.uint8)      # ">r%08d\n" + 150 bases + "\n"
-        rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 10] = 10; rec[:, -1] = 10
+        rec = np.empty((n, 11 + 151), dtype=np.uint8)      # ">r%08d\n" (11 bytes) + 150 bases + "\n"
+        rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 10] = 10; rec[:, 161] = 10
         idx = np.arange(n)
         for j in range(8):
             rec[:, 9 - j] = 48 + (idx // 10 ** j) % 10
