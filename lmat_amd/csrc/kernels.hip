@@ -38,7 +38,9 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_wave_barrier();
 }
 static const int kGmemU = 32768;   // k-mer capacity of the global-memory class (reads up to 32787 bp)
-static const int kGmemGrid = 128;  // its workgroups (one per-read table set of ~1.2 MB each)
+static const int kGmemGrid = 2048; // its workgroups (one per-read table set of ~1.2 MB each: 2.4 GB of scratch).  Every step of a read in this class is a
+                                   // round trip to memory, so what it needs is waves: 128 of them (rounds 1-3) were 8 ms per read of the heavy-tail
+                                   // workload's superkingdom-wide lists (36 k such reads per 8 M: 2.2 s a launch)
 
 // Pointers that arrive inside a by-value struct are "generic" to the compiler, which then emits flat_load
 // (counted on lgkmcnt as well, so every LDS wait also waits for HBM).  The classify kernel therefore

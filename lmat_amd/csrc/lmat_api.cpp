@@ -38,17 +38,24 @@ int upload_taxonomy(lmat_ctx* c) {
     if ((rc = dev_upload(c, &c->dev.tid32, T.tid32))) return rc;
     if ((rc = dev_upload(c, &c->dev.fdepth, T.fdepth))) return rc;
     if ((rc = dev_upload(c, &c->dev.flags, T.flags))) return rc;
-    if ((rc = dev_upload(c, &c->dev.species_of, T.species_of))) return rc;
     if ((rc = dev_upload(c, &c->dev.path_off, T.path_off))) return rc;
     if ((rc = dev_upload(c, &c->dev.path_len, T.path_len))) return rc;
-    if ((rc = dev_upload(c, &c->dev.paths, T.paths))) return rc;
     if ((rc = dev_upload(c, &c->dev.conv, T.conv))) return rc;
-    if ((rc = dev_upload(c, &c->dev.tin, T.tin))) return rc;
-    if ((rc = dev_upload(c, &c->dev.tout, T.tout))) return rc;
-    {
+    c->dev.wide = T.wide ? 1u : 0u;
+    if (T.wide) {  // 32-bit ids and ticks as they are; the 16-bit packing does not exist for this taxonomy
+        if ((rc = dev_upload(c, &c->dev.species_of32, T.species_of))) return rc;
+        if ((rc = dev_upload(c, &c->dev.paths32, T.paths))) return rc;
+        if ((rc = dev_upload(c, &c->dev.tin32, T.tin))) return rc;
+        if ((rc = dev_upload(c, &c->dev.tout32, T.tout))) return rc;
+    } else {
+        auto narrow = [](const std::vector<uint32_t>& v) { return std::vector<uint16_t>(v.begin(), v.end()); };
+        if ((rc = dev_upload(c, &c->dev.species_of, narrow(T.species_of)))) return rc;
+        if ((rc = dev_upload(c, &c->dev.paths, narrow(T.paths)))) return rc;
+        if ((rc = dev_upload(c, &c->dev.tin, narrow(T.tin)))) return rc;
+        if ((rc = dev_upload(c, &c->dev.tout, narrow(T.tout)))) return rc;
         std::vector<uint64_t> p8(T.paths.size());
         for (size_t i = 0; i < T.paths.size(); ++i) {
-            const uint16_t a = T.paths[i];
+            const uint32_t a = T.paths[i];
             p8[i] = (uint64_t)a | ((uint64_t)T.fdepth[a] << 16) | ((uint64_t)T.tin[a] << 32) | ((uint64_t)T.tout[a] << 48);
         }
         std::vector<uint32_t> f16((size_t)(T.n + 1) * 4);
@@ -130,7 +137,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
-                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->d_results, c->d_cands, c->d_cursor,
+                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->dev.paths32, c->dev.tin32, c->dev.tout32, c->dev.species_of32, c->d_results, c->d_cands, c->d_cursor,
                     c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_ovf4, c->parked.d_ovf4, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_tail, c->parked.d_tail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc,
                     c->d_err, c->parked.d_results, c->parked.d_cands, c->parked.d_cursor, c->parked.d_ovf, c->parked.d_ovf2, c->parked.d_ovf3, c->parked.d_k4buf, c->parked.d_k4small,
                     c->parked.d_k4large, c->parked.d_k4bail};
@@ -894,7 +901,7 @@ int lmat_synth_taxonomy(lmat_ctx* c, const uint32_t* br) {
     for (uint32_t i = 0; i < T.n; ++i) {
         const uint32_t ix = i + 1;
         T.tid32[ix] = ids[i];
-        T.index_of[ids[i]] = (uint16_t)ix;
+        T.index_of[ids[i]] = ix;
         T.fdepth[ix] = (uint16_t)depth[i];
         if (level_of[i] == 6) T.flags[ix] |= kFlagStrain;
         const uint16_t t16 = (uint16_t)(i == 0 ? 1 : i + 1);
@@ -902,9 +909,9 @@ int lmat_synth_taxonomy(lmat_ctx* c, const uint32_t* br) {
         T.br[ids[i]] = t16;
         T.path_off[ix] = (uint32_t)T.paths.size();
         uint32_t cur = i;
-        while (parent[cur] != cur) { cur = parent[cur]; T.paths.push_back((uint16_t)(cur + 1)); }
+        while (parent[cur] != cur) { cur = parent[cur]; T.paths.push_back(cur + 1); }
         T.path_len[ix] = (uint16_t)(T.paths.size() - T.path_off[ix]);
-        if (level_of[i] == 6) T.species_of[ix] = (uint16_t)(parent[i] + 1);
+        if (level_of[i] == 6) T.species_of[ix] = parent[i] + 1;
     }
     T.loaded = true;
     build_euler_intervals(T);
@@ -942,7 +949,7 @@ static void cons_group_ids(const lmat_ctx* c, int level, uint32_t grp, std::vect
     for (uint32_t q = 0; q < gsz; ++q) {
         const uint16_t sp = c->synth_species_idx[sp0 + q];
         internal.push_back(sp);
-        for (uint32_t j = 0; j < up && j < T.path_len[sp]; ++j) inner.push_back(T.paths[T.path_off[sp] + j]);
+        for (uint32_t j = 0; j < up && j < T.path_len[sp]; ++j) inner.push_back((uint16_t)T.paths[T.path_off[sp] + j]);
     }
     std::sort(inner.begin(), inner.end());
     inner.erase(std::unique(inner.begin(), inner.end()), inner.end());
@@ -2116,7 +2123,7 @@ int lmat_stream_create(lmat_ctx* c, uint64_t max_reads, uint64_t max_bases, uint
     const uint64_t max_words = max_bases / 16 + max_bases / 32 + 3 * max_reads + 16;  // rec_words summed, rounded up per read
     for (auto& sl : st->slots) {
         if (!ok) break;
-        sl.cand_cap = (uint64_t)cands_per_read * max_reads;
+        sl.cand_cap = cands_per_read ? (uint64_t)cands_per_read * max_reads + (uint64_t)kCandSubs * 2048 : 0;  // (+ what the sub-cursors may leave unused: kernels.hpp)
         ok = hipHostMalloc((void**)&sl.h_bases, max_bases + 16, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&sl.h_off, (max_reads + 1) * 8, hipHostMallocDefault) == hipSuccess &&
              hipHostMalloc((void**)&sl.h_rec_off, (max_reads + 1) * 8, hipHostMallocDefault) == hipSuccess &&

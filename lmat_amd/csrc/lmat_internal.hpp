@@ -20,16 +20,21 @@ struct HostTaxonomy {
     std::vector<uint32_t> tid32;      // [n+1]
     std::vector<uint16_t> fdepth;     // [n+1] depth from the -e file (read_label.cpp:1579-1582)
     std::vector<uint8_t> flags;       // [n+1] kFlag*
-    std::vector<uint16_t> species_of; // [n+1] for strain-ranked ids: first ancestor ranked "species"
+    std::vector<uint32_t> species_of; // [n+1] for strain-ranked ids: first ancestor ranked "species"
     std::vector<uint32_t> path_off;   // [n+1] into paths
     std::vector<uint16_t> path_len;   // [n+1] number of ancestors (tree depth)
-    std::vector<uint16_t> paths;      // ancestors parent..root as internal indices (TaxTree.hpp:60-91)
-    std::vector<uint16_t> tin, tout;  // [n+1] Euler-tour interval: a is a proper ancestor of b iff tin[a] < tin[b] && tout[b] <= tout[a]
-    std::unordered_map<uint32_t, uint16_t> index_of;  // tid32 -> internal
+    std::vector<uint32_t> paths;      // ancestors parent..root as internal indices (TaxTree.hpp:60-91)
+    std::vector<uint32_t> tin, tout;  // [n+1] Euler-tour interval: a is a proper ancestor of b iff tin[a] < tin[b] && tout[b] <= tout[a]
+    std::unordered_map<uint32_t, uint32_t> index_of;  // tid32 -> internal
     std::unordered_map<uint32_t, uint16_t> br;        // 32 -> 16 (make_db_table.cpp:259-273)
     std::vector<uint32_t> conv;                       // [65536] 16 -> 32 (read_label.cpp:1593-1598), 0 = unmapped
-    uint16_t human_idx = 0;                           // internal index of 9606
+    uint32_t human_idx = 0;                           // internal index of 9606
     bool loaded = false;
+    // More than 65534 ids (the closure of a database of 32-bit taxids: upstream's TID_SIZE=32 build, CMakeLists.txt:92-105):
+    // internal ids and Euler ticks do not fit 16 bits.  The host keeps 32-bit tables either way; the device gets the 16-bit
+    // packing of rounds 1-3 for a taxonomy that fits it (the fast classes are built on it) and the WIDE tables otherwise, which
+    // the wide classes of the classify kernel read (kernels.hip: WIDE).  A wide database stores its lists as 32-bit taxids.
+    bool wide = false;
 };
 
 struct DeviceTables {
@@ -51,6 +56,12 @@ struct DeviceTables {
     // packed copies for the classify kernels: one load instead of several gathers per id
     uint64_t* paths8 = nullptr;   // parallel to paths: id | fdepth << 16 | tin << 32 | tout << 48
     uint32_t* facts16 = nullptr;  // [n+1][4]: path_off | path_len, species_of << 16 | tin, tout << 16 | fdepth, flags << 16
+    // wide taxonomies (HostTaxonomy::wide): 32-bit ids and ticks; the 16-bit arrays above stay null
+    uint32_t wide = 0;
+    uint32_t* paths32 = nullptr;      // parallel to paths
+    uint32_t* tin32 = nullptr;        // [n+1]
+    uint32_t* tout32 = nullptr;
+    uint32_t* species_of32 = nullptr;
     uint32_t* conv = nullptr;  // [65536] 16 -> 32, lookup API only
     uint32_t n_ids = 0;
     int k = 0;
@@ -233,5 +244,7 @@ int load_null_models(lmat_ctx* c, const char* list_fn);
 void free_null_models(lmat_ctx* c);
 // compute the arena record of one raw list; returns false (err set) on invalid ids
 bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec);
+// the same for a wide database: raw = the stored 32-bit taxids as (low, high) pairs of u16 (Ingest::raw32); the record holds pairs too
+bool build_list_record_wide(lmat_ctx* c, const std::vector<uint16_t>& raw_pairs, std::vector<uint16_t>& rec);
 void comm_free(lmat_ctx* c);
 }  // namespace lmat

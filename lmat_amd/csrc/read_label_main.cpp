@@ -388,7 +388,8 @@ int main(int argc, char* argv[]) {
     const size_t kBatch = 1u << 20;                                   // reads per GPU batch ...
     const size_t kBatchBases = std::max<size_t>(kPiece, 1u << 20) + (1u << 20);  // ... and bases: one piece (+ the tail of its last record)
     const int kSlots = 3;
-    const uint32_t cands_per_read = prm.prn_all ? 16 : 8;  // a slot grows itself when a batch prints more
+    const uint32_t cands_per_read = prm.prn_all ? 24 : 8;  // a slot grows itself when a batch prints more (a re-run and 0.5 s of re-pinning: the
+                                                           // 64 GiB bench table prints 14.3 pairs a read, and 16 a read was one growth per slot)
     int n_fmt_plan = std::max<int>(1, (int)std::min<unsigned>(n_cpu > 6 ? n_cpu - n_parse - 2 : n_cpu, 32u));
     if (const char* e = getenv("LMAT_FORMAT_THREADS")) n_fmt_plan = std::max(1, atoi(e));
     std::vector<lmat_stream*> rings(n_gpu, nullptr);
