@@ -36,7 +36,7 @@ bool Ingest::load_idmap(const char* fn) {
     return true;
 }
 
-bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string& err) {
+bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string& err, bool any_size) {
     FILE* f = fopen(tree_fn, "r");
     if (!f) { err = std::string("failed to open ") + tree_fn + " for reading"; return false; }
     // two comment lines, one count line, then "id nchild child.. parent" / name line pairs (TaxTree.hpp:24-57)
@@ -54,7 +54,7 @@ bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string&
     fclose(f);
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-    if (ids.size() > 65534) {
+    if (ids.size() > 65534 && !any_size) {
         err = "the taxonomy has " + std::to_string(ids.size()) + " nodes; without a 32->16 map (-f) the engine takes at most 65534 (make_db_image -t <tree> -M <map> makes one from the database itself)";
         return false;
     }

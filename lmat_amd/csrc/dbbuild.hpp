@@ -21,7 +21,7 @@
 namespace lmat {
 
 // canonical payload: 1..65535 = the 16-bit DB taxid of a one-element list; 65536 + i = lists[i]
-bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string& err);  // sorted, unique, <= 65534
+bool tree_node_ids(const char* tree_fn, std::vector<uint32_t>& ids, std::string& err, bool any_size = false);  // sorted, unique, <= 65534
 
 // The 32->16 map of a database made from its own content, for taxonomies of more than 65534 nodes (a TID_SIZE=32 build of the
 // reference needs no map; this engine's ids are 16 bits wide): every taxid the tax_histo files hold, 1 / 9606 / the adaptor

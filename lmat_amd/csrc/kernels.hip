@@ -533,6 +533,12 @@ struct LinEnt {  // candidate-lineage entry (read_label.cpp:225-262, 327-351), 1
     float score;
 };
 static const uint16_t kLinNoGood = 0x8000;
+struct LinEntW {  // the same for a wide taxonomy (32-bit ids and Euler ticks), 20 bytes
+    uint32_t tid;
+    uint16_t dep, pad_;
+    uint32_t tin, tout;
+    float score;
+};
 // K4 in LDS, three table sizes (registered taxids of a read): per-lane block = 6 x u16[T], u8[T], f32[T], LinEnt[LIN], an
 // odd number of dwords apart (conflict-free).  The lineage holds the candidates plus the appended ancestors: a read whose
 // chain is longer is passed on to the scratch kernel.
@@ -553,8 +559,11 @@ static_assert(K4Lds<16>::STRIDE == 125, "small tier: 31.25 KB per wave");
 // Regions are reused across phases (see classify_one).
 constexpr int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <int U, int T, int E, bool INK4, bool CPT = false>
+template <int U, int T, int E, bool INK4, bool CPT = false, bool WIDE = false>
 struct WL {
+    static constexpr int IDB = WIDE ? 4 : 2;   // bytes of a taxid / an Euler tick in the per-read tables (WIDE: the wide classes, INK4 only)
+    static constexpr int HB = WIDE ? 8 : 4;    // ... and of a taxid-hash entry (id | slot)
+    static_assert(!WIDE || INK4, "wide ids run in the classes that keep their tables in memory and decide in-kernel");
     static constexpr int H = pow2_ceil(U * 3 / 2);  // k-mer / payload hash slots
     static constexpr int D = INK4 ? U : 64;  // distinct payloads (taxid lists) per read; the fast classes hand a read with more to a larger class
     static constexpr int TH = 4 * T;   // taxid hash slots: <= T registered + <= T unregistered species keys
@@ -563,17 +572,17 @@ struct WL {
     static constexpr int R1_HASH = 8 * H;                              // u64 hv[H]
     // reg, stamp, cnt, leaf (u16) | hent, best (u32) | in-kernel K4: dep, ord, tin, tout (u16), score (f32), sflags (u8),
     // score0, nm_rp (f32), nm_cl (u8)
-    static constexpr int R1_TID = 8 * T + 8 * TH + (INK4 ? 8 * T + 4 * T + T + 4 * T + 4 * T + T : 0);
+    static constexpr int R1_TID = (IDB + 6) * T + 2 * HB * TH + (INK4 ? (4 + 2 * IDB) * T + 4 * T + T + 4 * T + 4 * T + T : 0);
     // The k-mer hash of the compact path (reads whose repeat filter fires) is through before the probe writes anything: in the
     // classes that overlay the probe's block on their tables it may run on over R2 / R3 and the payload array behind R1.
     static constexpr bool HASH_OVER = CPT && U <= 512 && !INK4;
     static constexpr int R1 = HASH_OVER ? R1_TID : (R1_HASH > R1_TID ? R1_HASH : R1_TID);
     static constexpr int R2_K = CPT ? 0 : 8 * U + 4 * U;               // ukmer, ubucket (wide layout only)
     static constexpr int R2_D = 4 * D + 2 * D + 2 * D + 2 * D + D;     // dpay, dmult, dn, dstart, dfl
-    static constexpr int R2_L = INK4 ? 12 * LIN : 0;                   // lineage (K4, after the d-arrays die)
+    static constexpr int R2_L = INK4 ? (WIDE ? 20 : 12) * LIN : 0;     // lineage (K4, after the d-arrays die)
     static constexpr int R2 = R2_K > R2_D ? (R2_K > R2_L ? R2_K : R2_L) : (R2_D > R2_L ? R2_D : R2_L);
     static constexpr int R3_P = 4 * U;                                 // upay
-    static constexpr int R3_E = (INK4 ? 16 : 7) * E;                   // element staging (slots map to lanes: the per-id facts stay in registers)
+    static constexpr int R3_E = (INK4 ? (WIDE ? 24 : 16) : 7) * E;     // element staging (slots map to lanes: the per-id facts stay in registers)
     static constexpr int R3 = R3_P > R3_E ? R3_P : R3_E;
     static constexpr int OFF_RD = 0;
     // The packed record is read by K1 only.  Where a class keeps the k-mers of a read in registers (U <= 512) and addresses
@@ -653,6 +662,36 @@ __device__ __forceinline__ int tid_slot(const unsigned int* hent, int thmask, ui
     const uint32_t s = hent[h] >> 16;
     return s >= 0x8000u ? -1 : (int)s;
 }
+// ... and the same hash for the wide classes: 64-bit entries, low 32 bits = taxid index (0 = empty), high 32 bits = registration slot
+// (< 0x80000000), 0x80000000 | lane while a chunk decides who registers it, 0xFFFFFFFF = known key, not registered
+__device__ __forceinline__ uint32_t tid_hash_w(uint32_t t, int thmask) { return ((t * 0x9E3779B1u) >> 12) & thmask; }
+__device__ __forceinline__ uint32_t tid_find_or_claim(unsigned long long* hent, int thmask, uint32_t t) {
+    uint32_t h = tid_hash_w(t, thmask);
+    while (true) {
+        unsigned long long cur = hent[h];
+        if ((uint32_t)cur == t) return h;
+        if (cur == 0) {
+            unsigned long long prev = atomicCAS(&hent[h], 0ull, (unsigned long long)t | 0xFFFFFFFF00000000ull);
+            if (prev == 0 || (uint32_t)prev == t) return h;
+        }
+        h = (h + 1) & thmask;
+    }
+}
+__device__ __forceinline__ int tid_find(const unsigned long long* hent, int thmask, uint32_t t) {
+    uint32_t h = tid_hash_w(t, thmask);
+    while (true) {
+        unsigned long long cur = hent[h];
+        if ((uint32_t)cur == t) return (int)h;
+        if (cur == 0) return -1;
+        h = (h + 1) & thmask;
+    }
+}
+__device__ __forceinline__ int tid_slot(const unsigned long long* hent, int thmask, uint32_t t) {
+    const int h = tid_find(hent, thmask, t);
+    if (h < 0) return -1;
+    const uint32_t s = (uint32_t)(hent[h] >> 32);
+    return s >= 0x80000000u ? -1 : (int)s;
+}
 // u16 counters packed two per dword so LDS atomics can add to them (sums stay below 65536)
 __device__ __forceinline__ void add_u16(uint16_t* arr, uint32_t idx, uint32_t v) {
     atomicAdd((unsigned int*)arr + (idx >> 1), (idx & 1) ? (v << 16) : v);
@@ -674,7 +713,7 @@ struct TCmpDev {  // TCmp, read_label.cpp:475-485
     }
 };
 struct CmpDepthDev {  // CmpDepth, read_label.cpp:159-167
-    __device__ bool operator()(const LinEnt& a, const LinEnt& b) const { return (int)(a.dep & 0x7FFF) > (int)(b.dep & 0x7FFF); }
+    template <class LE> __device__ bool operator()(const LE& a, const LE& b) const { return (int)(a.dep & 0x7FFF) > (int)(b.dep & 0x7FFF); }
 };
 
 // glibc's logf (sysdeps/ieee754/flt-32/e_logf.c, the ARM optimized-routines algorithm): 16-entry table on the
@@ -741,10 +780,10 @@ struct K4State {
 
 // K4 part 1 (lane 0): scores, running sums, PhiX screen, mean/stdev, human bias, TCmp sort, lineage
 // building loop of findReadLabelVer2.  read_label.cpp:748-764, 803-893, 295-325.
-template <int LIN>
+template <int LIN, class TID = uint16_t, class LE = LinEnt>   // (TID: taxids and Euler ticks -- u16, or u32 with LinEntW in the wide classes)
 __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& S, const uint16_t* cnt, float* score, float* score0,
-                         const uint16_t* dep, const uint8_t* sflags, const uint16_t* tin, const uint16_t* tout,
-                         const uint16_t* reg, uint16_t* ord, LinEnt* lin, int nT, uint32_t cand, bool use_nm,
+                         const uint16_t* dep, const uint8_t* sflags, const TID* tin, const TID* tout,
+                         const TID* reg, uint16_t* ord, LE* lin, int nT, uint32_t cand, bool use_nm,
                          const float* nm_rp, const uint8_t* nm_cl, const NullModelDev& ND, K4Key* keys = nullptr,
                          const float* preset_stdev = nullptr) {
     if (preset_stdev) {  // lmat_debug_decide: score[] and the standard deviation are given (a record of a reference run):
@@ -874,8 +913,8 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
                 lidx = i;
                 lin_done = true;
             } else {
-                LinEnt e;
-                e.tid = reg[s]; e.score = score[s]; e.dep = (uint16_t)cd; e.tin = (uint16_t)ti; e.tout = (uint16_t)to;
+                LE e;
+                e.tid = reg[s]; e.score = score[s]; e.dep = (uint16_t)cd; e.tin = (TID)ti; e.tout = (TID)to;
                 lin[nlin++] = e;
                 if (cd > lowest_depth || i == nT - 1) { lowest = s; lowest_depth = cd; }
                 if (cd < highest_depth || i == nT - 1) { highest = s; highest_depth = cd; }
@@ -887,10 +926,10 @@ __device__ void k4_part1(const KernelParams& P, lmat_read_result& res, K4State& 
 }
 
 // K4 part 2 (lane 0): lineage sort, competitor scan, call, candidate list.  read_label.cpp:344-419, 898-937.
-template <int LIN>
+template <int LIN, class TID = uint16_t, class LE = LinEnt>
 __device__ void k4_part2(const KernelParams& P, const GAS uint32_t* tid32, lmat_read_result& res, const K4State& S,
-                         const float* score, const uint16_t* tin, const uint16_t* tout, const uint16_t* reg,
-                         const uint16_t* ord, LinEnt* lin, int nlin, int nT,
+                         const float* score, const TID* tin, const TID* tout, const TID* reg,
+                         const uint16_t* ord, LE* lin, int nlin, int nT,
                          bool have_add, uint32_t high_tin, uint32_t high_tout, GAS lmat_cand* cand_out,
                          uint32_t* n_cand_out, uint32_t* call_idx_out) {
     const int nlin_total = nlin;
@@ -1313,7 +1352,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
             uint32_t coff = 0;
             if (lane == 0) {
                 if (chunk) {  // from this workgroup's sub-cursor; an exhausted one takes the next chunk off the bump cursor (kernels.hpp)
-                    GAS unsigned long long* sub = (GAS unsigned long long*)(g_cursor + kCursorWords) + 8u * (__builtin_amdgcn_workgroup_id_x() & (uint32_t)(kCandSubs - 1));
+                    GAS unsigned long long* sub = (GAS unsigned long long*)(g_cursor + kCursorWords) + 8u * (__builtin_amdgcn_workgroup_id_x() & Ap->cand_sub_mask);
                     const unsigned long long v = __hip_atomic_fetch_add(sub, (unsigned long long)reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     coff = (uint32_t)v;
                     if ((v & 0xFFFFFFFFull) + reserve > (v >> 32)) {
@@ -1722,11 +1761,19 @@ __global__ __launch_bounds__(256) void tail_kernel(ClassifyArgs A) {
 }
 
 typedef const ClassifyArgs __attribute__((address_space(4))) CArgs;
-template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
+template <int U, int T, int E, bool INK4, bool PERM, bool CPT, bool WIDE = false>
 __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned char* lds, LAS unsigned char* xl, int lane,
                                              const uint32_t* wcur, uint32_t (&nmacc)[2]) {
-    using L = WL<U, T, E, INK4, CPT>;
+    using L = WL<U, T, E, INK4, CPT, WIDE>;
     constexpr int THM = L::TH - 1;
+    // WIDE (a taxonomy of more than 65534 ids, HostTaxonomy::wide): taxids and Euler ticks are 32 bits wide in the per-read tables,
+    // hash entries 64; the classes with in-kernel decision only.  Everything below that says tid_t / ent_t is the same code for both.
+    using tid_t = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
+    using ent_t = typename std::conditional<WIDE, unsigned long long, unsigned int>::type;
+    using lin_t = typename std::conditional<WIDE, LinEntW, LinEnt>::type;
+    constexpr int ESH = WIDE ? 32 : 16;                       // where the slot sits in a hash entry
+    constexpr ent_t EIDM = WIDE ? (ent_t)0xFFFFFFFFull : (ent_t)0xFFFFu;   // id part of an entry; also "slot = none"
+    constexpr uint32_t EPEND = WIDE ? 0x80000000u : 0x8000u;  // slot field while a chunk decides
     // RELANE: values derived from the lane id (LDS addresses, masks) are cheap; re-deriving them per phase keeps the
     // register allocator from carrying (and spilling) them across the probe phase, where 34 VGPRs hold loads in flight
 #define RELANE() do { asm volatile("" : "+v"(lane)); asm volatile("" : "+s"(Ap)); } while (0)
@@ -1739,17 +1786,17 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     // R1, hash phases
     unsigned long long* hv = (unsigned long long*)(lds + L::OFF_R1);
     // R1, taxid phase
-    uint16_t* reg = (uint16_t*)(lds + L::OFF_R1);
-    uint16_t* stamp = reg + T;
+    tid_t* reg = (tid_t*)(lds + L::OFF_R1);
+    uint16_t* stamp = (uint16_t*)(reg + T);
     uint16_t* cnt = stamp + T;
     uint16_t* leaf = cnt + T;
-    unsigned int* hent = (unsigned int*)(leaf + T);
-    unsigned int* best = hent + L::TH;
+    ent_t* hent = (ent_t*)(leaf + T);
+    ent_t* best = hent + L::TH;
     // in-kernel K4 only (large-capacity kernel)
     uint16_t* dep = (uint16_t*)(best + L::TH);
     uint16_t* ord = dep + T;
-    uint16_t* tin = ord + T;
-    uint16_t* tout = tin + T;
+    tid_t* tin = (tid_t*)(ord + T);
+    tid_t* tout = tin + T;
     float* score = (float*)(tout + T);
     uint8_t* sflags = (uint8_t*)(score + T);
     float* score0 = (float*)(sflags + T);
@@ -1763,7 +1810,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     uint16_t* dn = dmult + L::D;
     uint16_t* dstart = dn + L::D;
     uint8_t* dfl = (uint8_t*)(dstart + L::D);
-    LinEnt* lin = (LinEnt*)(lds + L::OFF_R2);
+    lin_t* lin = (lin_t*)(lds + L::OFF_R2);
     // R3: payload per distinct k-mer, then the staged kept-list elements
     uint32_t* upay = (uint32_t*)(lds + (CPT ? L::OFF_UPAY_C : L::OFF_R3));
     // large classes (16 B per element): poff u32 | t | ta | d | sp | plen u16 | fl u8.
@@ -1771,12 +1818,13 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     // registers of the lane that is its registration slot.
     using eld_t = typename std::conditional<INK4, uint16_t, uint8_t>::type;
     uint32_t* el_poff = (uint32_t*)(lds + L::OFF_R3);
-    uint16_t* el_t = INK4 ? (uint16_t*)(el_poff + E) : (uint16_t*)(lds + L::OFF_R3);   // kept id, registration order
-    uint16_t* el_ta = el_t + E;                  // kept id, ascending order (closure order)
-    eld_t* el_d = (eld_t*)(el_ta + (INK4 ? E : 2 * E));  // owning distinct-payload index
-    uint16_t* el_off = el_ta + E;                // T <= 64: offset of the id's chain in the item list of the closure
-    uint16_t* el_sp = (uint16_t*)el_d + E;       // large classes: species_of[ta]
-    uint16_t* el_plen = el_sp + E;               // path_len[ta]
+    tid_t* el_t = INK4 ? (tid_t*)(el_poff + E) : (tid_t*)(lds + L::OFF_R3);   // kept id, registration order
+    tid_t* el_ta = el_t + E;                     // kept id, ascending order (closure order)
+    tid_t* el_sp = el_ta + E;                    // large classes: species_of[ta] (wide layout: the three id arrays first, then the u16 ones)
+    eld_t* el_d = WIDE ? (eld_t*)(el_sp + E) : (eld_t*)(el_ta + (INK4 ? E : 2 * E));  // owning distinct-payload index
+    uint16_t* el_off = (uint16_t*)(el_ta + E);   // T <= 64: offset of the id's chain in the item list of the closure
+    if constexpr (!WIDE) el_sp = (tid_t*)((uint16_t*)el_d + E);
+    uint16_t* el_plen = WIDE ? (uint16_t*)el_d + E : (uint16_t*)el_sp + E;   // path_len[ta]
     uint8_t* el_fl = (uint8_t*)(el_plen + E);    // flags[ta]
 
     const int k = tb.k;
@@ -1787,9 +1835,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     const GAS uint8_t* g_flags = (const GAS uint8_t*)tb.flags;
     const GAS uint32_t* g_path_off = (const GAS uint32_t*)tb.path_off;
     const GAS uint16_t* g_path_len = (const GAS uint16_t*)tb.path_len;
-    const GAS uint16_t* g_paths = (const GAS uint16_t*)tb.paths;
-    const GAS uint16_t* g_tin = (const GAS uint16_t*)tb.tin;
-    const GAS uint16_t* g_tout = (const GAS uint16_t*)tb.tout;
+    const GAS tid_t* g_paths = (const GAS tid_t*)(WIDE ? (const void*)tb.paths32 : (const void*)tb.paths);
+    const GAS tid_t* g_tin = (const GAS tid_t*)(WIDE ? (const void*)tb.tin32 : (const void*)tb.tin);
+    const GAS tid_t* g_tout = (const GAS tid_t*)(WIDE ? (const void*)tb.tout32 : (const void*)tb.tout);
+    const GAS tid_t* g_species_of = (const GAS tid_t*)(WIDE ? (const void*)tb.species_of32 : (const void*)tb.species_of);
     const GAS uint64_t* g_paths8 = (const GAS uint64_t*)tb.paths8;
     const GAS u32x4* g_facts16 = (const GAS u32x4*)tb.facts16;
     GAS uint32_t* g_cursor = (GAS uint32_t*)A.cursor;
@@ -2679,7 +2728,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 const u32x4 ch = *(const GAS u32x4*)(arena + LMAT_LIST_OFF(pay, tb.list_shift));  // [flags][n_kept][n_raw][ids...]
                 fl = ch.x & 0xFFFFu;
                 n = ch.x >> 16;
-                w3 = ch.y >> 16; w4 = ch.z & 0xFFFFu; w5 = ch.z >> 16; w6 = ch.w & 0xFFFFu;
+                if constexpr (WIDE) {  // ids are (low, high) pairs: the first kept id and the first ascending one fit the 16 bytes
+                    w3 = (ch.y >> 16) | (ch.z << 16);
+                    w4 = (ch.z >> 16) | (ch.w << 16);
+                } else { w3 = ch.y >> 16; w4 = ch.z & 0xFFFFu; w5 = ch.z >> 16; w6 = ch.w & 0xFFFFu; }
             }
         }
         // inclusive scan of n over the wave
@@ -2691,14 +2743,14 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             dstart[d] = (uint16_t)s0;
             if (s0 + n <= (uint32_t)E) {  // owner index of every element; ids of the short lists
                 for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (eld_t)d;
-                if (n == 1) { el_t[s0] = (uint16_t)w3; el_ta[s0] = (uint16_t)w4; }
-                else if (n == 2) {
-                    el_t[s0] = (uint16_t)w3; el_t[s0 + 1] = (uint16_t)w4;
-                    el_ta[s0] = (uint16_t)w5; el_ta[s0 + 1] = (uint16_t)w6;
+                if (n == 1) { el_t[s0] = (tid_t)w3; el_ta[s0] = (tid_t)w4; }
+                else if (!WIDE && n == 2) {
+                    el_t[s0] = (tid_t)w3; el_t[s0 + 1] = (tid_t)w4;
+                    el_ta[s0] = (tid_t)w5; el_ta[s0 + 1] = (tid_t)w6;
                 }
             }
         }
-        any_long |= __ballot(n > 2) != 0;
+        any_long |= __ballot(n > (WIDE ? 1u : 2u)) != 0;
         // label_vec.first < 0 positions leave the candidate count (quirk Q4); positions with a
         // non-empty set count as found (construct_labels :722-725)
         const uint32_t both = wave_sum(((fl & kListNegFirst) ? m : 0u) | ((n ? m : 0u) << 16));  // each sum is at most the k-mer capacity
@@ -2726,11 +2778,16 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             const uint32_t e = e0 + lane;
             if (e < nel) {
                 const uint32_t d = el_d[e], n = dn[d];
-                if (n > 2) {
+                if (n > (WIDE ? 1u : 2u)) {
                     const size_t eoff = LMAT_LIST_OFF(dpay[d], tb.list_shift) + kListHdr;
                     const uint32_t j = e - dstart[d];
-                    el_t[e] = arena[eoff + j];
-                    el_ta[e] = arena[eoff + n + j];
+                    if constexpr (WIDE) {
+                        el_t[e] = (tid_t)((uint32_t)arena[eoff + 2 * j] | ((uint32_t)arena[eoff + 2 * j + 1] << 16));
+                        el_ta[e] = (tid_t)((uint32_t)arena[eoff + 2 * (n + j)] | ((uint32_t)arena[eoff + 2 * (n + j) + 1] << 16));
+                    } else {
+                        el_t[e] = arena[eoff + j];
+                        el_ta[e] = arena[eoff + n + j];
+                    }
                 }
             }
         }
@@ -2740,11 +2797,19 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
             const uint32_t e = e0 + lane;
             if (e < nel) {
-                const u32x4 f = g_facts16[el_ta[e]];
-                el_poff[e] = f.x;
-                el_plen[e] = (uint16_t)(f.y & 0xFFFFu);
-                el_sp[e] = (uint16_t)(f.y >> 16);
-                el_fl[e] = (uint8_t)(f.w >> 16);
+                if constexpr (WIDE) {
+                    const uint32_t t = el_ta[e];
+                    el_poff[e] = g_path_off[t];
+                    el_plen[e] = g_path_len[t];
+                    el_sp[e] = g_species_of[t];
+                    el_fl[e] = g_flags[t];
+                } else {
+                    const u32x4 f = g_facts16[el_ta[e]];
+                    el_poff[e] = f.x;
+                    el_plen[e] = (uint16_t)(f.y & 0xFFFFu);
+                    el_sp[e] = (tid_t)(f.y >> 16);
+                    el_fl[e] = (uint8_t)(f.w >> 16);
+                }
             }
         }
         WSYNC();
@@ -2764,21 +2829,21 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         uint32_t h = 0;
         if (act) {
             h = tid_find_or_claim(hent, THM, t);
-            atomicMin(&hent[h], t | ((0x8000u | (uint32_t)lane) << 16));
+            atomicMin(&hent[h], (ent_t)t | ((ent_t)(EPEND | (uint32_t)lane) << ESH));
         }
         WSYNC();
-        const uint64_t nm_ = __ballot(e < nel) & __ballot((hent[h] >> 16) == (0x8000u | (uint32_t)lane));  // (idle lanes read entry 0: harmless)
+        const uint64_t nm_ = __ballot(e < nel) & __ballot((uint32_t)(hent[h] >> ESH) == (EPEND | (uint32_t)lane));  // (idle lanes read entry 0: harmless)
         const uint32_t newcnt = popc64(nm_);
         if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
         if (lane_bit(nm_)) {
             const uint32_t s = nT + prefix_count(nm_);
-            hent[h] = t | (s << 16);
-            reg[s] = (uint16_t)t; stamp[s] = 0xFFFF;
+            hent[h] = (ent_t)t | ((ent_t)s << ESH);
+            reg[s] = (tid_t)t; stamp[s] = 0xFFFF;
         }
         nT += newcnt;
         WSYNC();
         if (act) {
-            const uint32_t s = hent[h] >> 16;
+            const uint32_t s = (uint32_t)(hent[h] >> ESH);
             const uint32_t m = dmult[el_d[e]];
             add_u16(leaf, s, m);
             add_u16(cnt, s, m);
@@ -2806,9 +2871,9 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             const uint32_t e = e0 + lane;
             if (e < nel && (el_fl[e] & kFlagStrain) && el_sp[e]) {
                 const uint32_t u = el_ta[e];
-                const uint32_t lf = leaf[hent[tid_find(hent, THM, u)] >> 16];
+                const uint32_t lf = leaf[(uint32_t)(hent[tid_find(hent, THM, u)] >> ESH)];
                 const uint32_t h = tid_find_or_claim(hent, THM, el_sp[e]);
-                atomicMax(&best[h], (lf << 16) | (0xFFFFu - u));
+                atomicMax(&best[h], ((ent_t)lf << ESH) | (EIDM - (ent_t)u));
             }
         }
         WSYNC();
@@ -2824,7 +2889,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         const uint32_t sp = el_sp[e];
         if (!sp) return false;
         const int h = tid_find(hent, THM, sp);
-        return h >= 0 && best[h] != 0 && (best[h] & 0xFFFFu) == (0xFFFFu - (uint32_t)el_ta[e]);
+        return h >= 0 && best[h] != 0 && (best[h] & EIDM) == (EIDM - (ent_t)el_ta[e]);
     };
     if constexpr (INK4) {
             // next eligible element at or after e (uniform scan)
@@ -2846,7 +2911,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 if ((int)d != cur_d) {  // entering a new position set: its kept ids are members already
                     cur_d = (int)d;
                     const uint32_t s0 = dstart[d], n = dn[d];
-                    for (uint32_t j = lane; j < n; j += 64) stamp[hent[tid_find(hent, THM, el_t[s0 + j])] >> 16] = (uint16_t)d;
+                    for (uint32_t j = lane; j < n; j += 64) stamp[(uint32_t)(hent[tid_find(hent, THM, el_t[s0 + j])] >> ESH)] = (uint16_t)d;
                     WSYNC();
                 }
                 uint32_t a_cur = a_next;
@@ -2860,19 +2925,19 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     if (act) {
                         h = tid_find_or_claim(hent, THM, a);
                     }
-                    const bool unreg = act && (hent[h] >> 16) == 0xFFFFu;
+                    const bool unreg = act && (uint32_t)(hent[h] >> ESH) == (uint32_t)EIDM;
                     const uint64_t nm_ = __ballot(unreg);
                     const uint32_t newcnt = popc64(nm_);
                     if (nT + newcnt > (uint32_t)T) { overflow = true; break; }
                     if (unreg) {
                         const uint32_t s = nT + prefix_count(nm_);
-                        hent[h] = a | (s << 16);
-                        reg[s] = (uint16_t)a; stamp[s] = 0xFFFF;
+                        hent[h] = (ent_t)a | ((ent_t)s << ESH);
+                        reg[s] = (tid_t)a; stamp[s] = 0xFFFF;
                     }
                     nT += newcnt;
                     WSYNC();
                     if (act) {
-                        const uint32_t s = hent[h] >> 16;
+                        const uint32_t s = (uint32_t)(hent[h] >> ESH);
                         if (stamp[s] != (uint16_t)d) { stamp[s] = (uint16_t)d; cnt[s] += (uint16_t)m; }
                     }
                     WSYNC();
@@ -3129,7 +3194,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     K4State S;
     S.done = false; S.nlin = 0; S.highest = -1; S.highest_depth = 0; S.lidx = -1; S.lowest = -1; S.plasmid_slot = -1;
     S.top_score = 0; S.diff_thresh = 0;
-    if (lane == 0) k4_part1<L::LIN>(prm_g, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, (int)nT, cand, nmt >= 0, nm_rp, nm_cl, nm_g);
+    if (lane == 0) k4_part1<L::LIN, tid_t, lin_t>(prm_g, res, S, cnt, score, score0, dep, sflags, tin, tout, reg, ord, lin, (int)nT, cand, nmt >= 0, nm_rp, nm_cl, nm_g);
     const int done = __builtin_amdgcn_readfirstlane((int)S.done);
     int nlin = __builtin_amdgcn_readfirstlane(S.nlin);
     const int highest = __builtin_amdgcn_readfirstlane(S.highest);
@@ -3155,8 +3220,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 if (j < take) {
                     const uint32_t a = g_paths[aoff + j];
                     const int s = tid_slot(hent, THM, a);
-                    LinEnt en;
-                    en.tid = (uint16_t)a;
+                    lin_t en;
+                    en.tid = (tid_t)a;
                     en.score = s >= 0 ? score0[s] : -10000.0f;
                     en.dep = g_fdepth[a]; en.tin = g_tin[a]; en.tout = g_tout[a];
                     lin[nlin + j] = en;
@@ -3176,7 +3241,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 if ((uint64_t)coff + reserve <= A.cand_cap) cout_ = (GAS lmat_cand*)A.cands + coff;
                 else G_OR(g_err, (uint32_t)kErrCandOverflow);
             }
-            k4_part2<L::LIN>(prm_g, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
+            k4_part2<L::LIN, tid_t, lin_t>(prm_g, g_tid32, res, S, score, tin, tout, reg, ord, lin, nlin, (int)nT, have_add, high_tin,
                      high_tout, cout_, &ncand, &call_idx);
         } else {
             call_idx = A.phix_call_idx;
@@ -3617,20 +3682,20 @@ __global__ __launch_bounds__(64) void gather_bench_kernel(const uint64_t* __rest
 #define LMAT_FAST_WAVES 8   // (A/B builds: -DLMAT_FAST_WAVES=7 compiles the fast classes for 7 waves per SIMD, 72 registers)
 #endif
 constexpr int classify_waves(int U, int E, bool INK4, bool CPT) { return INK4 ? 1 : (E > kFastE ? (U <= 160 ? 5 : 2) : (U <= 160 ? (CPT ? LMAT_FAST_WAVES : 5) : (U <= 256 ? (CPT ? LMAT_FAST_WAVES : 5) : (U <= 320 ? (CPT ? 5 : 3) : (CPT ? 4 : 3))))); }
-template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
+template <int U, int T, int E, bool INK4, bool PERM, bool CPT, bool WIDE = false>
 __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_kernel(ClassifyArgs A) {
     extern __shared__ __align__(16) unsigned char lds_smem[];
     // U > 2048: the per-read tables of this workgroup live in global memory
-    unsigned char* smem = U > 2048 ? A.gscratch + (size_t)blockIdx.x * WL<U, T, E, INK4, false>::BYTES : lds_smem;
+    unsigned char* smem = U > 2048 ? A.gscratch + (size_t)blockIdx.x * WL<U, T, E, INK4, false, WIDE>::BYTES : lds_smem;
     // scratch block of the compact-layout probe: always real LDS
-    LAS unsigned char* xl = (LAS unsigned char*)(U > 2048 ? lds_smem : lds_smem + WL<U, T, E, INK4, CPT>::OFF_XL);
+    LAS unsigned char* xl = (LAS unsigned char*)(U > 2048 ? lds_smem : lds_smem + WL<U, T, E, INK4, CPT, WIDE>::OFF_XL);
     const int lane = threadIdx.x & 63;
     // Software pipeline over the reads of this wave: the record offset is fetched two reads ahead and the
     // record words one read ahead, so a read never starts with a chain of dependent HBM round trips.
     // What the loop needs from the kernel arguments (read count, list and record pointers) is read again in every trip -- scalar
     // loads from the argument segment -- instead of being carried across classify_one, where every carried scalar is one more
     // value spilled to a lane of a vector register around the decision step (the kernel has 78 scalar registers).
-    constexpr int NW = (WL<U, T, E, INK4, CPT>::RD_WORDS + 1 + 63) / 64;
+    constexpr int NW = (WL<U, T, E, INK4, CPT, WIDE>::RD_WORDS + 1 + 63) / 64;
     const uint32_t G = gridDim.x;
     uint32_t it = blockIdx.x;
     uint32_t wcur[NW], wnext[NW];
@@ -3660,7 +3725,7 @@ __global__ __launch_bounds__(64, classify_waves(U, E, INK4, CPT)) void classify_
         const bool more = (uint64_t)it + G < count;
 #pragma unroll
         for (int j = 0; j < NW; ++j) wnext[j] = more ? words[off1 + lane + 64 * j] : 0u;
-        classify_one<U, T, E, INK4, PERM, CPT>(Ap, r_of(it), smem, xl, lane, wcur, nmacc);
+        classify_one<U, T, E, INK4, PERM, CPT, WIDE>(Ap, r_of(it), smem, xl, lane, wcur, nmacc);
         WSYNC();
 #pragma unroll
         for (int j = 0; j < NW; ++j) wcur[j] = wnext[j];
@@ -3833,19 +3898,19 @@ void launch_k4_end(const ClassifyArgs& a, hipStream_t join_stream, hipStream_t s
     hipEventRecord(done, join_stream);
 }
 
-template <int U, int T, int E, bool INK4, bool PERM, bool CPT>
+template <int U, int T, int E, bool INK4, bool PERM, bool CPT, bool WIDE = false>
 static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
-    using L = WL<U, T, E, INK4, CPT>;
+    using L = WL<U, T, E, INK4, CPT, WIDE>;
     if (U > 2048) {  // tables in global memory: few workgroups; LDS only for the compact probe's scratch block
         int grid = kGmemGrid;
         if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)(a.count ? a.count : 1);
-        classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), CPT ? L::XL_BYTES : 0, stream>>>(a);
+        classify_kernel<U, T, E, INK4, PERM, CPT, WIDE><<<dim3(grid), dim3(64), CPT ? L::XL_BYTES : 0, stream>>>(a);
         return;
     }
     static const int lds_pad = getenv("LMAT_LDS_PAD") ? atoi(getenv("LMAT_LDS_PAD")) : 0;  // experiments: fewer resident waves
     const int lds_bytes = L::BYTES + lds_pad;
     static PerDeviceOnce attr_once;
-    attr_once([lds_bytes] { hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM, CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
+    attr_once([lds_bytes] { hipFuncSetAttribute((const void*)classify_kernel<U, T, E, INK4, PERM, CPT, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); });
     // one single-wave workgroup per read slot; enough groups to fill every CU's LDS several times over
     const int per_cu = 160 * 1024 / lds_bytes;
     // Reads differ in cost (one over genus-shared k-mers takes 3-4 times the usual), and a block keeps its share of the batch:
@@ -3856,7 +3921,7 @@ static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
     if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)a.count;
     if (a.count_ptr && INK4 && grid > 256 * (per_cu < 2 ? 2 : per_cu)) grid = 256 * (per_cu < 2 ? 2 : per_cu);  // the lists of the large classes are short (the E = 512 class may get a tenth of a batch): a block per wave the LDS holds
     if (grid < 1) grid = 1;
-    classify_kernel<U, T, E, INK4, PERM, CPT><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
+    classify_kernel<U, T, E, INK4, PERM, CPT, WIDE><<<dim3(grid), dim3(64), lds_bytes, stream>>>(a);
 }
 
 void launch_k4_debug(const ClassifyArgs& a, const uint32_t* idx, const float* scores, const uint64_t* off, const float* stdevs, uint64_t n,
@@ -3884,15 +3949,27 @@ void launch_tail(const ClassifyArgs& a, hipStream_t stream) {
 }
 
 int classify_max_read_len() { return kGmemU + 19; }
-size_t classify_gmem_scratch_bytes() { return (size_t)kGmemGrid * WL<kGmemU, 4096, 16384, true>::BYTES; }
+size_t classify_gmem_scratch_bytes() { return (size_t)kGmemGrid * WL<kGmemU, 4096, 16384, true, false, true>::BYTES; }   // (the wide layout: the larger of the two)
 
 // permissive match (-s) is a compile-time variant: a run-time test of it inside the closure loops cost 22%
 #define LC(U, T, E, K)                                                                                                   \
     (a.tb.cpt.nb ? (a.prm.permissive ? launch_classify_t<U, T, E, K, true, true>(a, stream) : launch_classify_t<U, T, E, K, false, true>(a, stream)) \
                  : (a.prm.permissive ? launch_classify_t<U, T, E, K, true, false>(a, stream) : launch_classify_t<U, T, E, K, false, false>(a, stream)))
+// wide taxonomies (more than 65534 ids): 32-bit ids in the per-read tables, the classes that decide in-kernel only, compact layout
+#define LCW(U, T, E) (a.prm.permissive ? launch_classify_t<U, T, E, true, true, true, true>(a, stream) : launch_classify_t<U, T, E, true, false, true, true>(a, stream))
 bool launch_classify(const ClassifyArgs& a, uint32_t max_read_len, int tcap_class, hipStream_t stream) {
     const int k = a.tb.k;
     const uint32_t P = max_read_len >= (uint32_t)k ? max_read_len - k + 1 : 0;
+    if (a.tb.wide) {
+        // tcap_class 4: the first wide tier (128 taxids / 512 list elements: 30 KB of LDS, five waves per CU); 5: the second (512 /
+        // 2048, one per CU); 1: tables in global memory (4096 / 16384).  Reads beyond 531 bp start in the second tier.
+        if (!a.tb.cpt.nb) return false;
+        if (tcap_class == 4) { if (P > 512) return false; LCW(512, 128, 512); }
+        else if (tcap_class == 5) { if (P <= 512) LCW(512, 512, 2048); else if (P <= 2048) LCW(2048, 512, 2048); else return false; }
+        else if (P <= (uint32_t)kGmemU && a.gscratch) LCW(kGmemU, 4096, 16384);
+        else return false;
+        return true;
+    }
     if (tcap_class == 2) {  // reads whose kept lists add up to more than kFastE elements (many strains per k-mer): 512 of them
         if (P <= 160) LC(160, 64, 512, false); else LC(512, 64, 512, false);
     } else if (tcap_class == 3) {

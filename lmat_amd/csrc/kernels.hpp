@@ -18,6 +18,7 @@ struct ClassifyArgs {
     uint64_t cand_cap;
     uint32_t* cursor;          // per-batch counters: [0] candidate bump cursor, [2..] list lengths; behind the 16 words: kCandSubs sub-cursors (64 B apart)
     uint32_t cand_chunk = 0;   // pairs a sub-cursor takes from the bump cursor at a time (0: every read bumps the cursor itself)
+    uint32_t cand_sub_mask = 0; // sub-cursors in use - 1 (a power of two, at most kCandSubs: fewer for smaller batches, whose slack would otherwise outweigh their pairs)
     uint32_t* err;             // sticky error flags: launches only OR into the word
     void* counts;              // u64 count[n_ids] | f64 score[n_ids] | u64 nomatch[3]
     uint32_t phix_call_idx;    // internal index of 32630

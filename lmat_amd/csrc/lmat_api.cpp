@@ -245,6 +245,8 @@ int lmat_db_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_byte
     c->ingest = new Ingest();
     c->ingest->k = k;
     c->ingest->br = c->tax.br;
+    // a wide taxonomy without a 16-bit map: the database holds 32-bit taxids, stored as they come (upstream's TID_SIZE=32 build)
+    if (c->tax.wide && c->tax.br.empty() && !c->gene_mode) c->ingest->raw32 = true;
     c->ingest_table_bytes = table_bytes;
     c->db_ready = false;
     sb_free(c);
@@ -645,7 +647,7 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
                         rec[0] = 0x8000;
                         rec[1] = (uint16_t)(l.size() / 2);
                         rec.insert(rec.end(), l.begin(), l.end());
-                    } else if (!build_list_record(c, B.lists[p - kListBase], rec)) return LMAT_E_TAXONOMY;
+                    } else if (!(B.raw32 ? build_list_record_wide(c, B.lists[p - kListBase], rec) : build_list_record(c, B.lists[p - kListBase], rec))) return LMAT_E_TAXONOMY;
                     lp = arena_append(S.arena, rec, S.shift);
                 }
                 dp = lp;
@@ -660,7 +662,7 @@ static int sb_push(lmat_ctx* c, Ingest& B) {
                     const uint32_t t32 = T.conv[p];
                     const bool special = c->permissive || t32 == 0 || t32 == 63221 || t32 == 741158 || t32 == 20999999 || t32 == 12721 || t32 == 693660;
                     auto it = T.index_of.find(t32);
-                    if (!special && it != T.index_of.end()) {
+                    if (!special && it != T.index_of.end() && it->second < kListBase) {   // (a plain payload is an internal index below 65536)
                         sp = it->second;
                     } else {
                         one[0] = (uint16_t)p;
@@ -1399,13 +1401,21 @@ static ClassifyArgs make_args(lmat_ctx* c, const lmat_reads* reads, uint64_t fir
     // Large candidate buffers are handed out through sub-cursors, a chunk at a time (kernels.hpp): at most kCandSubs chunks lie
     // partly unused at the end of a launch, an eighth of the buffer in the worst case.  Small ones -- few reads, no contention --
     // are bumped read by read as before.  (LMAT_CAND_CHUNK=0 turns the sub-cursors off.)
+    // Batches of up to 128 K reads bump the cursor read by read (no contention to speak of, and no slack: the CLI's batches are
+    // 50 K reads of an 8 MB piece); larger ones use one sub-cursor per 4096 reads, 2048 pairs a chunk: the slack -- chunks partly
+    // used when the launch ends -- stays below half a pair per read.  (LMAT_CAND_CHUNK=0 turns the sub-cursors off.)
     a.cand_chunk = 0;
-    if (want_cands && cand_cap <= 0x7FFFFFFFull) {   // (a sub-cursor's two halves are 32 bits wide each)
+    a.cand_sub_mask = 0;
+    if (want_cands && cand_cap <= 0x7FFFFFFFull && count > (128u << 10)) {   // (a sub-cursor's two halves are 32 bits wide each)
         static const int forced = getenv("LMAT_CAND_CHUNK") ? atoi(getenv("LMAT_CAND_CHUNK")) : -1;
-        uint64_t ch = cand_cap / (8 * (uint64_t)kCandSubs);
-        ch = ch >= 2048 ? 2048 : (ch >= 1024 ? 1024 : (ch >= 512 ? 512 : (ch >= 256 ? 256 : 0)));
+        uint32_t subs = 32;
+        while (subs < (uint32_t)kCandSubs && (uint64_t)subs * 4096 < count) subs *= 2;
+        uint64_t ch = 2048;
+        while (ch > 256 && ch * subs * 4 > cand_cap) ch /= 2;   // a tight buffer: smaller chunks rather than a quarter of it as slack
+        if (ch * subs * 4 > cand_cap) ch = 0;
         if (forced >= 0) ch = forced >= 64 ? (uint64_t)forced : 0;
         a.cand_chunk = (uint32_t)ch;
+        a.cand_sub_mask = subs - 1;
     }
     a.cursor = c->d_cursor;
     a.err = c->batch_err ? c->d_cursor + 15 : c->d_err;  // a streamed batch keeps its own flags (word 15 of the per-batch counter block)

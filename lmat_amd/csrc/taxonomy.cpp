@@ -71,6 +71,7 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
         while (in >> t >> r) rank.insert(std::make_pair(t, r));
     }
     // --- 32 -> 16 map; later lines overwrite (operator[])
+    std::vector<uint32_t> wide_ids;   // no map and a tree beyond 65534 nodes: all its ids
     T.conv.assign(65536, 0);
     if (idmap_fn && *idmap_fn) {
         FILE* f = fopen(idmap_fn, "r");
@@ -87,11 +88,17 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
         // ranks of the tree's node ids, the same rule the ingest uses (dbbuild.cpp:idmap_from_tree).
         std::vector<uint32_t> ids;
         std::string e;
-        if (!tree_node_ids(tree_fn, ids, e)) return set_err(c, ids.size() > 65534 ? LMAT_E_CAPACITY : LMAT_E_IO, e);
-        for (size_t i = 0; i < ids.size(); ++i) {
-            T.conv[i + 1] = ids[i];
-            T.br[ids[i]] = (uint16_t)(i + 1);
-        }
+        if (!tree_node_ids(tree_fn, ids, e, true)) return set_err(c, LMAT_E_IO, e);
+        if (ids.size() > 65534) {
+            // more nodes than 16-bit codes: the database stores its taxids as they are (32 bits), every node of the tree is an
+            // id the engine may meet, and the classify kernels' WIDE classes take the reads (HostTaxonomy::wide)
+            T.wide = true;
+            wide_ids.swap(ids);
+        } else
+            for (size_t i = 0; i < ids.size(); ++i) {
+                T.conv[i + 1] = ids[i];
+                T.br[ids[i]] = (uint16_t)(i + 1);
+            }
     }
     std::unordered_set<uint32_t> low_plasmid;
     if (plasmid_fn && *plasmid_fn) {
@@ -111,10 +118,12 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
             if (is_human32(t)) any_human = true;
         }
     }
+    for (uint32_t t : wide_ids) { S.insert(t); if (is_human32(t)) any_human = true; }
     if (any_human) S.insert(9606);
     // the PhiX short-circuit reports ART_SEQ_TID 32630 (read_label.cpp:842): give it a tally slot
     for (uint32_t t16 = 0; t16 < 65536; ++t16)
         if (T.conv[t16] && is_phix32(T.conv[t16])) { S.insert(32630); break; }
+    for (uint32_t t : wide_ids) if (is_phix32(t)) { S.insert(32630); break; }
     std::vector<uint32_t> work(S.begin(), S.end());
     for (size_t i = 0; i < work.size(); ++i) {
         uint32_t cur = work[i];
@@ -133,8 +142,7 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
             if (++guard > 10000) return set_err(c, LMAT_E_TAXONOMY, "cycle in taxonomy above " + std::to_string(work[i]));
         }
     }
-    if (S.size() > 65535)
-        return set_err(c, LMAT_E_CAPACITY, "taxonomy closure has " + std::to_string(S.size()) + " ids; engine limit is 65535");
+    if (S.size() > 65534) T.wide = true;   // (also a 16-bit map whose ids, with their ancestors, pass 65534: 32-bit internal ids)
     std::vector<uint32_t> ids(S.begin(), S.end());
     std::sort(ids.begin(), ids.end());
     T.n = (uint32_t)ids.size();
@@ -146,7 +154,7 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
     T.path_len.assign(T.n + 1, 0);
     for (uint32_t i = 0; i < T.n; ++i) {
         T.tid32[i + 1] = ids[i];
-        T.index_of[ids[i]] = (uint16_t)(i + 1);
+        T.index_of[ids[i]] = i + 1;
     }
     for (uint32_t i = 1; i <= T.n; ++i) {
         const uint32_t t = T.tid32[i];
@@ -180,7 +188,7 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
     for (uint32_t i = 1; i <= T.n; ++i) {
         if (!(T.flags[i] & kFlagStrain)) continue;
         for (uint32_t p = 0; p < T.path_len[i]; ++p) {
-            uint16_t a = T.paths[T.path_off[i] + p];
+            const uint32_t a = T.paths[T.path_off[i] + p];
             auto r = rank.find(T.tid32[a]);
             if (r != rank.end() && r->second == "species") {
                 T.species_of[i] = a;
@@ -191,7 +199,6 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
     auto h = T.index_of.find(9606);
     T.human_idx = h == T.index_of.end() ? 0 : h->second;
     T.loaded = true;
-    if (T.n > 65534) return set_err(c, LMAT_E_CAPACITY, "taxonomy closure above 65534 ids");
     build_euler_intervals(T);
     return upload_taxonomy(c);
 }
@@ -202,32 +209,32 @@ int load_taxonomy_files(lmat_ctx* c, const char* tree_fn, const char* depth_fn, 
 // numbered behind the real trees (every tin is unique; k4_wave's "related = the intervals intersect" relies on that).
 void build_euler_intervals(HostTaxonomy& T) {
     const uint32_t n = T.n;
-    T.tin.assign(n + 1, 0xFFFF);
-    T.tout.assign(n + 1, 0xFFFF);
-    std::vector<std::vector<uint16_t>> children(n + 1);
+    T.tin.assign(n + 1, T.wide ? 0xFFFFFFFFu : 0xFFFFu);
+    T.tout.assign(n + 1, T.wide ? 0xFFFFFFFFu : 0xFFFFu);
+    std::vector<std::vector<uint32_t>> children(n + 1);
     std::vector<uint8_t> is_child(n + 1, 0), has_child(n + 1, 0);
     for (uint32_t i = 1; i <= n; ++i)
         if (T.path_len[i]) {
-            const uint16_t par = T.paths[T.path_off[i]];
-            children[par].push_back((uint16_t)i);
+            const uint32_t par = T.paths[T.path_off[i]];
+            children[par].push_back(i);
             is_child[i] = 1;
             has_child[par] = 1;
         }
     uint32_t clock = 0;
-    std::vector<std::pair<uint16_t, size_t>> st;
+    std::vector<std::pair<uint32_t, size_t>> st;
     for (uint32_t r = 1; r <= n; ++r) {
         if (is_child[r]) continue;
         if (!has_child[r]) continue;  // roots that own a subtree (lone nodes are numbered behind them, below)
-        st.push_back(std::make_pair((uint16_t)r, (size_t)0));
-        T.tin[r] = (uint16_t)clock++;
+        st.push_back(std::make_pair(r, (size_t)0));
+        T.tin[r] = clock++;
         while (!st.empty()) {
             auto& top = st.back();
             if (top.second < children[top.first].size()) {
-                const uint16_t ch = children[top.first][top.second++];
-                T.tin[ch] = (uint16_t)clock++;
+                const uint32_t ch = children[top.first][top.second++];
+                T.tin[ch] = clock++;
                 st.push_back(std::make_pair(ch, (size_t)0));
             } else {
-                T.tout[top.first] = (uint16_t)(clock - 1);
+                T.tout[top.first] = clock - 1;
                 st.pop_back();
             }
         }
@@ -235,7 +242,7 @@ void build_euler_intervals(HostTaxonomy& T) {
     // a node without parent and children is a tree of its own: an interval of one tick that nothing else touches (every node's
     // tin is then unique, and "related" is "the intervals intersect" without exceptions -- the decision step on the wave leans on it)
     for (uint32_t r = 1; r <= n; ++r)
-        if (!is_child[r] && !has_child[r]) { T.tin[r] = T.tout[r] = (uint16_t)clock; ++clock; }
+        if (!is_child[r] && !has_child[r]) { T.tin[r] = T.tout[r] = clock; ++clock; }
 }
 
 // One raw DB list -> arena record.  Restates the per-k-mer part of retrieve_kmer_labels
@@ -251,21 +258,15 @@ struct RankPair {  // MyPair, src/kmerdb/SortedDb.hpp:129-139
 };
 }  // namespace
 
-bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec) {
+// seq32: the list's taxids as the reference's cursor hands them out (stored order, 32 bits); raw_units: how the stored list
+// is kept behind the record for lookups (16-bit codes, or (low, high) pairs of a wide database); wide: ids in the record are pairs
+static bool build_list_record_core(lmat_ctx* c, std::vector<uint32_t>& seq, const std::vector<uint16_t>& raw_units, size_t n_raw,
+                                   bool wide, std::vector<uint16_t>& rec) {
     const HostTaxonomy& T = c->tax;
     // what TaxNodeStat::begin / next hand to the caller (TaxNodeStat.hpp:60-256): the stored ids converted
     // 16 -> 32, or, with run-time pruning (-g N [-m ranks]) on a list longer than N, the survivors of the
     // rank-priority queue in pop order (or just the first stored id when no rank map was given)
-    std::vector<uint32_t> seq;
-    uint32_t count = (uint32_t)raw.size();
-    for (size_t i = 0; i < raw.size(); ++i) {
-        const uint32_t tid = T.conv[raw[i]];
-        if (tid == 0) {  // TaxNodeStat.hpp:235-238: "bad taxid" assert
-            set_err(c, LMAT_E_TAXONOMY, "bad taxid: 16-bit id " + std::to_string(raw[i]) + " has no 32-bit mapping");
-            return false;
-        }
-        seq.push_back(tid);
-    }
+    uint32_t count = (uint32_t)seq.size();
     if (c->rt_tid_cut > 0 && (int)count > c->rt_tid_cut) {
         if (c->rt_rank_map.empty()) {
             seq.resize(1);
@@ -286,7 +287,7 @@ bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vecto
             for (uint32_t j = 0; j < count; ++j) { seq.push_back(q.top().second); q.pop(); }
         }
     }
-    std::vector<uint16_t> obs;
+    std::vector<uint32_t> obs;
     bool seen_human = false, neg_first = false;
     unsigned dcnt = 0;
     for (size_t i = 0; i < seq.size(); ++i) {  // read_label.cpp:1031-1066
@@ -306,26 +307,26 @@ bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vecto
         obs.push_back(it->second);
         dcnt++;
     }
-    std::vector<uint16_t> kept;
-    auto add_unique = [&kept](uint16_t t) { if (std::find(kept.begin(), kept.end(), t) == kept.end()) kept.push_back(t); };
+    std::vector<uint32_t> kept;
+    auto add_unique = [&kept](uint32_t t) { if (std::find(kept.begin(), kept.end(), t) == kept.end()) kept.push_back(t); };
     if (c->permissive) {
         // -s (read_label.cpp:1050-1058,1075-1102): every accepted id joins the position set in list order, then,
         // walking the depth-sorted ids until one of depth 0, all their ancestors do; no leaf-most filter
-        for (uint16_t t : obs) add_unique(t);
-        std::vector<uint16_t> sorted(obs);
-        std::sort(sorted.begin(), sorted.end(), [&T](uint16_t a, uint16_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
-        for (uint16_t t : sorted) {
+        for (uint32_t t : obs) add_unique(t);
+        std::vector<uint32_t> sorted(obs);
+        std::sort(sorted.begin(), sorted.end(), [&T](uint32_t a, uint32_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
+        for (uint32_t t : sorted) {
             if (T.fdepth[t] == 0) break;
             for (uint32_t p = 0; p < T.path_len[t]; ++p) add_unique(T.paths[T.path_off[t] + p]);
         }
     } else {
         // CmpDepth1 (read_label.cpp:169-177) through the same std::sort the reference calls, then the leaf-most filter
-        std::sort(obs.begin(), obs.end(), [&T](uint16_t a, uint16_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
-        std::unordered_set<uint16_t> non_leaf;
+        std::sort(obs.begin(), obs.end(), [&T](uint32_t a, uint32_t b) { return (int)T.fdepth[a] > (int)T.fdepth[b]; });
+        std::unordered_set<uint32_t> non_leaf, have;
         for (size_t i = 0; i < obs.size(); ++i) {
-            const uint16_t t = obs[i];
+            const uint32_t t = obs[i];
             if (non_leaf.count(t)) continue;
-            if (std::find(kept.begin(), kept.end(), t) != kept.end()) {
+            if (!have.insert(t).second) {
                 set_err(c, LMAT_E_IO, "taxid list holds taxid " + std::to_string(T.tid32[t]) + " twice");
                 return false;
             }
@@ -333,21 +334,46 @@ bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vecto
             for (uint32_t p = 0; p < T.path_len[t]; ++p) non_leaf.insert(T.paths[T.path_off[t] + p]);
         }
     }
-    if (kept.size() > 65535 || raw.size() > 65535) {
+    if (kept.size() > 65535 || n_raw > 65535) {
         set_err(c, LMAT_E_CAPACITY, "taxid list too long");
         return false;
     }
-    std::vector<uint16_t> asc(kept);
+    std::vector<uint32_t> asc(kept);
     std::sort(asc.begin(), asc.end());  // internal index order == 32-bit taxid order
     rec.clear();
     rec.push_back(neg_first ? kListNegFirst : 0);
     rec.push_back((uint16_t)kept.size());
-    rec.push_back((uint16_t)raw.size());
-    rec.insert(rec.end(), kept.begin(), kept.end());
-    rec.insert(rec.end(), asc.begin(), asc.end());
-    rec.insert(rec.end(), raw.begin(), raw.end());
+    rec.push_back((uint16_t)n_raw);
+    auto put = [&](uint32_t t) { rec.push_back((uint16_t)t); if (wide) rec.push_back((uint16_t)(t >> 16)); };
+    for (uint32_t t : kept) put(t);
+    for (uint32_t t : asc) put(t);
+    rec.insert(rec.end(), raw_units.begin(), raw_units.end());
     if (rec.size() & 1) rec.push_back(0);
     return true;
+}
+
+bool build_list_record(lmat_ctx* c, const std::vector<uint16_t>& raw, std::vector<uint16_t>& rec) {
+    const HostTaxonomy& T = c->tax;
+    std::vector<uint32_t> seq;
+    for (size_t i = 0; i < raw.size(); ++i) {
+        const uint32_t tid = T.conv[raw[i]];
+        if (tid == 0) {  // TaxNodeStat.hpp:235-238: "bad taxid" assert
+            set_err(c, LMAT_E_TAXONOMY, "bad taxid: 16-bit id " + std::to_string(raw[i]) + " has no 32-bit mapping");
+            return false;
+        }
+        seq.push_back(tid);
+    }
+    if (!T.wide) return build_list_record_core(c, seq, raw, raw.size(), false, rec);
+    // a 16-bit map under a taxonomy whose closure is wide: the record's ids are pairs, and so is the stored list kept behind it
+    std::vector<uint16_t> pairs;
+    for (uint32_t t : seq) { pairs.push_back((uint16_t)t); pairs.push_back((uint16_t)(t >> 16)); }
+    return build_list_record_core(c, seq, pairs, seq.size(), true, rec);
+}
+
+bool build_list_record_wide(lmat_ctx* c, const std::vector<uint16_t>& raw_pairs, std::vector<uint16_t>& rec) {
+    std::vector<uint32_t> seq;
+    for (size_t i = 0; i + 1 < raw_pairs.size(); i += 2) seq.push_back((uint32_t)raw_pairs[i] | ((uint32_t)raw_pairs[i + 1] << 16));
+    return build_list_record_core(c, seq, raw_pairs, seq.size(), true, rec);
 }
 
 }  // namespace lmat
