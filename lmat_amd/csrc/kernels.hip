@@ -486,6 +486,11 @@ __global__ void lookup_kernel(DeviceTables tb, const uint64_t* __restrict__ kmer
     }
     const uint32_t nk = tb.arena[eoff + 1], nr = tb.arena[eoff + 2];
     counts[i] = nr;
+    if (tb.wide) {  // ids and the stored list are (low, high) pairs of 32-bit taxids
+        const size_t raw = eoff + kListHdr + 4 * (size_t)nk;
+        for (uint32_t j = 0; j < nr && j < stride; ++j) tids[i * stride + j] = (uint32_t)tb.arena[raw + 2 * j] | ((uint32_t)tb.arena[raw + 2 * j + 1] << 16);
+        return;
+    }
     for (uint32_t j = 0; j < nr && j < stride; ++j) tids[i * stride + j] = tb.conv[tb.arena[eoff + kListHdr + 2 * nk + j]];
 }
 

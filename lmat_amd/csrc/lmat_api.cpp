@@ -264,6 +264,8 @@ int lmat_db_begin(lmat_ctx* c, int k, uint64_t n_kmers_hint, uint64_t table_byte
 int lmat_db_set_build_options(lmat_ctx* c, int tid_cutoff, const char* rank_map_fn, const char* human_kmers_fn,
                               const char* adaptor_kmers_fn, uint32_t adaptor_tid) {
     if (!c || !c->ingest) return set_err(c, LMAT_E_ARG, "lmat_db_begin first");
+    if (c->ingest->raw32 && !c->gene_mode && (tid_cutoff > 0 || (human_kmers_fn && *human_kmers_fn) || (adaptor_kmers_fn && *adaptor_kmers_fn)))
+        return set_err(c, LMAT_E_ARG, "build-time pruning and the human / adaptor k-mer feeds work on 16-bit codes: a database of 32-bit taxids under a taxonomy beyond 65534 ids is taken as it is (run-time pruning, -g, applies)");
     if (!c->ingest->set_options(tid_cutoff, rank_map_fn, human_kmers_fn, adaptor_kmers_fn, adaptor_tid))
         return set_err(c, LMAT_E_IO, c->ingest->err);
     return LMAT_OK;
@@ -317,7 +319,7 @@ uint64_t tax_fingerprint(const lmat_ctx* c) {
 }
 uint64_t mode_fingerprint(const lmat_ctx* c) {
     uint64_t h = 0xCBF29CE484222325ull;
-    const int32_t m[4] = {c->permissive, c->rt_tid_cut, c->rand_mode, c->gene_mode};
+    const int32_t m[5] = {c->permissive, c->rt_tid_cut, c->rand_mode, c->gene_mode, c->tax.wide ? 1 : 0};
     h = fnv(h, m, sizeof m);
     std::vector<std::pair<uint32_t, uint32_t>> rm(c->rt_rank_map.begin(), c->rt_rank_map.end());
     std::sort(rm.begin(), rm.end());
@@ -1535,6 +1537,42 @@ static int run_classify(lmat_ctx* c, const lmat_reads* reads, uint64_t first, ui
         if (timed && !started) hipEventRecord(e0, c->stream);
         started = true;
     };
+    if (c->dev.wide) {
+        // A wide taxonomy (more than 65534 ids): the classes with 32-bit ids in their tables, which decide in-kernel -- a first
+        // tier of 128 taxids / 512 list elements (five waves per CU), a second of 512 / 2048, then tables in global memory.  The
+        // 16-bit fast classes do not apply; this path is built for correctness on databases of 32-bit taxids, not for the headline.
+        if (!c->dev.cpt.nb) return set_err(c, LMAT_E_ARG, "a wide taxonomy needs the compact table layout (k >= 10)");
+        const uint32_t kk = (uint32_t)c->dev.k;
+        mark_start();
+        ClassifyArgs w = a;
+        w.gscratch = c->d_gscratch;
+        bool ok = true;
+        if (reads->max_len <= 512 + kk - 1) {
+            w.ovf_list = c->d_ovf; w.ovf_slot = 2;
+            ok = launch_classify(w, reads->max_len, 4, c->stream);
+            w.index = c->d_ovf; w.count_ptr = c->d_cursor + 2; w.count = 0;
+        }
+        if (ok && reads->max_len <= 2048 + kk - 1) {
+            w.ovf_list = c->d_ovf2; w.ovf_slot = 3;
+            ok = launch_classify(w, reads->max_len, 5, c->stream);
+            w.index = c->d_ovf2; w.count_ptr = c->d_cursor + 3; w.count = 0;
+        }
+        w.ovf_list = nullptr; w.ovf_slot = 7;
+        if (ok) ok = launch_classify(w, reads->max_len, 1, c->stream);
+        if (!ok) return set_err(c, LMAT_E_CAPACITY, "read longer than " + std::to_string(classify_max_read_len()) + " bases");
+        if (timed) { HIPCHK(c, hipEventRecord(e1, c->stream)); HIPCHK(c, hipEventRecord(e2, c->stream)); }
+        c->join_stream = c->stream;
+        HIPCHK(c, hipEventRecord(c->ev_done, c->stream));
+        c->set_in_flight = true;
+        if (timed) {
+            HIPCHK(c, hipEventRecord(e3, c->stream));
+            c->pending_events.push_back(std::make_pair(e0, e1));
+            c->pending_events2.push_back(std::make_pair(e2, e3));
+            e0 = e1 = e2 = e3 = nullptr;
+        }
+        HIPCHK(c, hipGetLastError());
+        return LMAT_OK;
+    }
     // Each read runs in the smallest fast class that holds it (160 / 256 / 512 k-mers; 512 = 531 bp at k = 20); longer
     // reads ride the overflow list to the wave-per-read classes behind it.  A batch of one class is one plain launch.
     {
@@ -1890,6 +1928,7 @@ int lmat_debug_decide(lmat_ctx* c, const uint32_t* tids, const float* scores, co
                       lmat_read_result* results) {
     if (!c || !tids || !scores || !off || !stdev || !results) return LMAT_E_ARG;
     if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy first");
+    if (c->tax.wide) return set_err(c, LMAT_E_ARG, "the debug entries of the decision step take taxonomies of up to 65534 ids");
     if (!n) return LMAT_OK;
     hipSetDevice(c->device);
     const uint64_t total = off[n];
@@ -1930,6 +1969,7 @@ int lmat_debug_decide_counts(lmat_ctx* c, const uint32_t* tids, const uint32_t* 
                              int on_the_wave, lmat_read_result* results) {
     if (!c || !tids || !counts || !off || !cand || !results) return LMAT_E_ARG;
     if (!c->tax.loaded) return set_err(c, LMAT_E_ARG, "load the taxonomy first");
+    if (c->tax.wide) return set_err(c, LMAT_E_ARG, "the debug entries of the decision step take taxonomies of up to 65534 ids");
     if (!n) return LMAT_OK;
     hipSetDevice(c->device);
     const uint64_t total = off[n];
