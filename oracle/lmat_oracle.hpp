@@ -96,8 +96,11 @@ struct Taxonomy {
     std::unordered_map<tid_t, tid_t> parent;        // tree node -> parent id
     std::map<tid_t, tid_t> depth;                   // -e file (sopt._imap)
     std::map<tid_t, std::string> rank;              // -w file (gRank_table)
-    std::unordered_map<uint16_t, uint32_t> conv;    // -f file: 16 -> 32 (conv_map)
-    std::unordered_map<uint32_t, uint16_t> br;      // -f file: 32 -> 16 (make_db_table.cpp:259-273)
+    // storage codes: the 16-bit ids of the -f map (a TID_SIZE=16 build), or, without a map, the rank of an id among the tree's
+    // node ids -- a bijective code no result depends on; kept 32 bits wide so that a tree beyond 65534 nodes (TID_SIZE=32) fits
+    typedef uint32_t code_t;
+    std::unordered_map<code_t, uint32_t> conv;      // -f file: 16 -> 32 (conv_map)
+    std::unordered_map<uint32_t, code_t> br;        // -f file: 32 -> 16 (make_db_table.cpp:259-273)
     std::unordered_set<int> low_plasmid;            // -r file (gLowNumPlasmid)
 
     // TaxTree(const char*) : two comment lines, one count line, then per node
@@ -133,8 +136,7 @@ struct Taxonomy {
         std::vector<tid_t> ids;
         for (auto& kv : parent) ids.push_back(kv.first);
         std::sort(ids.begin(), ids.end());
-        if (ids.size() > 65534) return false;
-        for (size_t i = 0; i < ids.size(); ++i) { br[ids[i]] = (uint16_t)(i + 1); conv[(uint16_t)(i + 1)] = ids[i]; }
+        for (size_t i = 0; i < ids.size(); ++i) { br[ids[i]] = (code_t)(i + 1); conv[(code_t)(i + 1)] = ids[i]; }
         return true;
     }
     bool load_depth(const std::string& fn) {  // read_label.cpp:1574-1582
@@ -220,7 +222,8 @@ struct Taxonomy {
 // ---------------------------------------------------------------------------
 struct KmerDb {
     int k = 0;
-    std::unordered_map<kmer_t, std::vector<uint16_t>> table;
+    typedef Taxonomy::code_t code_t;
+    std::unordered_map<kmer_t, std::vector<code_t>> table;
     kmer_t last_kmer = 0;  // add_data's static last_kmer: ordering is checked across files
     // make_db_table options that change the stored lists (src/make_db_table.cpp:150-213,303-313)
     int tid_cutoff = 0;                                   // -g
@@ -296,9 +299,9 @@ struct KmerDb {
             fclose(f);
             have_adaptors = true;
         }
-        auto map16 = [&](uint32_t tid, uint16_t& out) -> bool {  // SortedDb.cpp:503-511,678-690
+        auto map16 = [&](uint32_t tid, code_t& out) -> bool {  // SortedDb.cpp:503-511,678-690
             auto b = tax.br.find(tid);
-            uint16_t t16 = b == tax.br.end() ? 0 : b->second;
+            code_t t16 = b == tax.br.end() ? 0 : b->second;
             if (t16 == 0 || t16 > tax.br.size() + 1) {
                 if (err) { std::ostringstream o; o << "bad read: " << tid << " " << t16; *err = o.str(); }
                 return false;
@@ -306,7 +309,7 @@ struct KmerDb {
             out = t16;
             return true;
         };
-        uint16_t HUMAN_16 = 0, ADAPTOR_16 = 0;
+        code_t HUMAN_16 = 0, ADAPTOR_16 = 0;
         { auto h = tax.br.find(9606); if (h != tax.br.end()) HUMAN_16 = h->second; }
         { auto a = tax.br.find(adaptor_tid); if (a != tax.br.end()) ADAPTOR_16 = a->second; }
         for (uint64_t i = 0; i < kmer_count; ++i) {
@@ -321,8 +324,8 @@ struct KmerDb {
             }
             while (last_human < kmer) {  // SortedDb.cpp:170-222: human k-mers the stream does not contain
                 const bool ad = have_adaptors && adaptor_set.count(last_human);
-                table[last_human] = std::vector<uint16_t>(1, ad ? (ADAPTOR_16 ? ADAPTOR_16 : (uint16_t)adaptor_tid)
-                                                                 : (HUMAN_16 ? HUMAN_16 : (uint16_t)9606));
+                table[last_human] = std::vector<code_t>(1, ad ? (ADAPTOR_16 ? ADAPTOR_16 : (code_t)(uint16_t)adaptor_tid)
+                                                                : (HUMAN_16 ? HUMAN_16 : (code_t)(uint16_t)9606));
                 last_human = read_encode(human_fp);
             }
             bool add_human = false;
@@ -331,11 +334,11 @@ struct KmerDb {
             std::vector<uint32_t> tids(tid_count);
             for (uint16_t j = 0; j < tid_count; ++j)
                 if (fread(&tids[j], 4, 1, in) != 1) { if (err) *err = "truncated taxid list"; fclose(in); return false; }
-            std::vector<uint16_t>& lst = table[kmer];
+            std::vector<code_t>& lst = table[kmer];
             lst.clear();
-            uint16_t t16 = 0;
+            code_t t16 = 0;
             if (have_adaptors && adaptor_set.count(kmer)) {  // :275-292
-                lst.push_back(ADAPTOR_16 ? ADAPTOR_16 : (uint16_t)adaptor_tid);
+                lst.push_back(ADAPTOR_16 ? ADAPTOR_16 : (code_t)(uint16_t)adaptor_tid);
             } else {
                 uint16_t tmp = tid_count;
                 std::priority_queue<MyPair> q;
@@ -390,8 +393,8 @@ struct KmerDb {
         fclose(in);
         return true;
     }
-    void add_list(kmer_t kmer, const std::vector<uint16_t>& l) { table[kmer] = l; }
-    const std::vector<uint16_t>* lookup(kmer_t kmer) const {
+    void add_list(kmer_t kmer, const std::vector<code_t>& l) { table[kmer] = l; }
+    const std::vector<code_t>* lookup(kmer_t kmer) const {
         auto it = table.find(kmer);
         return it == table.end() ? nullptr : &it->second;
     }
@@ -708,7 +711,7 @@ struct Classifier {
 
     // TaxNodeStat::begin (5-argument form, TaxNodeStat.hpp:60-205) + next()/taxid()/taxidCount() (:208-264):
     // the taxid sequence and count the caller sees for one k-mer, run-time pruning (-g/-m) included
-    void taxnodestat_sequence(const std::vector<uint16_t>* lst, kmer_t kmer_id, std::vector<tid_t>& seq,
+    void taxnodestat_sequence(const std::vector<KmerDb::code_t>* lst, kmer_t kmer_id, std::vector<tid_t>& seq,
                               uint16_t& taxid_count) const {
         seq.clear();
         taxid_count = lst ? (uint16_t)lst->size() : 0;
@@ -778,7 +781,7 @@ struct Classifier {
                 no_dups.insert(kmer_id);
                 if (tr) { tr->uniq_kmers.push_back(kmer_id); tr->uniq_pos.push_back(pos); }
 
-                const std::vector<uint16_t>* lst = db.lookup(kmer_id);
+                const std::vector<KmerDb::code_t>* lst = db.lookup(kmer_id);
                 std::vector<tid_t> seq;
                 uint16_t taxid_count = 0;
                 taxnodestat_sequence(lst, kmer_id, seq, taxid_count);

@@ -99,7 +99,7 @@ uint64_t orc_db_size(orc_ctx* c) { return c->db.table.size(); }
 // DB entries supplied directly as 32-bit ids in stored order (used when the lists
 // come from another lookup source); ids are mapped 32->16 like add_data would.
 int orc_add_list32(orc_ctx* c, uint64_t kmer, const uint32_t* tids, int n) {
-    std::vector<uint16_t> l;
+    std::vector<KmerDb::code_t> l;
     for (int i = 0; i < n; ++i) {
         auto b = c->tax.br.find(tids[i]);
         if (b == c->tax.br.end() || b->second == 0) { c->err = "tid not in 32->16 map"; return -1; }
@@ -111,7 +111,7 @@ int orc_add_list32(orc_ctx* c, uint64_t kmer, const uint32_t* tids, int n) {
 
 // lookup: returns taxidCount, writes up to cap converted 32-bit ids in stored order; -1 = miss
 int orc_lookup(orc_ctx* c, uint64_t kmer, uint32_t* out, int cap) {
-    const std::vector<uint16_t>* l = c->db.lookup(kmer);
+    const std::vector<KmerDb::code_t>* l = c->db.lookup(kmer);
     if (!l) return -1;
     for (int i = 0; i < (int)l->size() && i < cap; ++i) {
         auto cv = c->tax.conv.find((*l)[i]);
@@ -122,7 +122,7 @@ int orc_lookup(orc_ctx* c, uint64_t kmer, uint32_t* out, int cap) {
 
 // the sequence TaxNodeStat hands out under the current label modes (run-time pruning); -1 = miss
 int orc_lookup_rt(orc_ctx* c, uint64_t kmer, uint32_t* out, int cap) {
-    const std::vector<uint16_t>* l = c->db.lookup(kmer);
+    const std::vector<KmerDb::code_t>* l = c->db.lookup(kmer);
     if (!l) return -1;
     Classifier cls(c->tax, c->db, c->opt);
     std::vector<tid_t> seq;

@@ -99,3 +99,45 @@ def test_wide_taxonomy_cli_and_image(wide_dataset, tmp_path):
         assert open(str(tmp_path / o) + "0.out").read() == want
         assert open(str(tmp_path / o) + ".0.30.fastsummary").read() == fs
         assert open(str(tmp_path / o) + ".0.30.nomatchsum").read() == nm
+
+
+@pytest.mark.parametrize("mode", ["permissive", "prune", "null_bias"])
+def test_wide_taxonomy_label_modes(wide_dataset, tmp_path, mode):
+    """The same parity under -s (permissive match), under run-time pruning (-g 6 -m ranks) and with -l 3 / no -p: the wide
+    classes are the classes of the general path, so every mode the 16-bit build has is there."""
+    import oracle_py
+    from lmat_amd import Engine, Params
+    ds = wide_dataset
+    reads = ds["reads"][:700]
+    bs = [r.encode() for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    blob = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8)
+    rank_fn = str(tmp_path / "numeric_ranks.txt")
+    with open(rank_fn, "w") as f:
+        for line in open(ds["depth"]):
+            f.write(line)
+    prm = Params.run_rl(prn_all=0) if mode == "null_bias" else Params.run_rl()
+    if mode == "null_bias":
+        prm.hbias = 3.0
+    eng = Engine(0, prm)
+    eng.load_taxonomy(ds["tree"], ds["depth"], ds["rank"], None)
+    orc = oracle_py.Oracle(ds["tree"], ds["depth"], ds["rank"], None)
+    if mode == "permissive":
+        eng.set_label_modes(permissive=True)
+        orc.set_label_modes(True, 0, None)
+    elif mode == "prune":
+        eng.set_label_modes(False, 6, rank_fn)
+        orc.set_label_modes(False, 6, rank_fn)
+    eng.build_db(ds["db"], k=20)
+    orc.add_taxhisto(ds["db"])
+    orc.set_options(hbias=3.0, prn_all=0) if mode == "null_bias" else orc.set_options()
+    dr = eng.upload_reads((blob, off))
+    res, cands = eng.classify(dr, cand_cap=400 * len(reads))
+    got = eng.format_out(res, cands, (blob, off))
+    want, _, _ = orc.classify(blob, off, 20)
+    assert got == want
+    assert (res["status"] == 0).sum() > 0.4 * len(reads)
+    orc.close()
+    dr.free()
+    eng.close()
