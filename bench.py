@@ -537,7 +537,7 @@ def main():
                          "frac_step": mean_b * args.launch_reads / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "frac_bucket_only": mean_bucket * args.launch_reads / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_read_bucket_only": mean_bucket,
-                         "kernel": "classify_kernel<160,64,256,false,false,true>",
+                         "kernel": "classify_kernel<160,64,256,false,false,true,false>",
                          "kernel_avg_ms": avg_ms, "kernel_ms_per_2M_reads": avg_ms * 2e6 / args.launch_reads, "step_ms_per_launch": step_ms, "step_ms_per_2M_reads": step_ms * 2e6 / args.launch_reads, "tail_kernels_event_ms": decide_ms / max(launches, 1), "algorithmic_bytes_per_read": mean_b, "reads_per_launch": args.launch_reads,
                          "random_64B_gather_ceiling_GBs": gather_gbs, "probe_ends": probes},
         }
