@@ -15,6 +15,9 @@
 #include <type_traits>
 #include "kernels.hpp"
 
+#ifndef LMAT_CLOSURE_FAST
+#define LMAT_CLOSURE_FAST 1   // (A/B builds: -DLMAT_CLOSURE_FAST=0)
+#endif
 #ifndef LMAT_LDS_SHIFT
 #define LMAT_LDS_SHIFT 0   // (-DLMAT_LDS_SHIFT=1: the lane shifts of the minimizer window and the repeat filter through LDS instead of DPP.
                            //  Measured in round 4, same box: 24.57 against 24.29 ms per 8 M reads -- 60 vector instructions fewer per read,
@@ -3005,20 +3008,29 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
         }
         WSYNC();
+        // the slots with an eligible element.  One such slot in the whole read (the usual case: strains of one species, the
+        // representative one eligible): its chain is the only one to walk -- no offsets to scan, no search per item.
+        const uint64_t todo0 = __ballot(first[lane] != 0xFFFFFFFFu);
+        const bool one = LMAT_CLOSURE_FAST && todo0 != 0 && (todo0 & (todo0 - 1)) == 0;
+        const int sx0 = one ? __builtin_ctzll(todo0) : 0;
+        if (one) {
+            W = (uint32_t)__builtin_amdgcn_readlane((int)f_plen, sx0);
+        } else {
 #pragma unroll
-        for (int ch = 0; ch < EC; ++ch) {
-            if ((uint32_t)ch * 64 < nel) {
-                const uint32_t e = (uint32_t)ch * 64 + lane;
-                const uint32_t sl = sreg[ch] & 0xFFu;
-                const uint32_t plen = (uint32_t)__shfl((int)f_plen, (int)sl);
-                const bool walk = e < nel && first[sl] == e;
-                const uint32_t w = walk ? plen : 0u;
-                const uint32_t incl = wave_scan_incl(w);
-                if (e < nel) el_off[e] = (uint16_t)(W + incl - w);
-                W += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            for (int ch = 0; ch < EC; ++ch) {
+                if ((uint32_t)ch * 64 < nel) {
+                    const uint32_t e = (uint32_t)ch * 64 + lane;
+                    const uint32_t sl = sreg[ch] & 0xFFu;
+                    const uint32_t plen = (uint32_t)__shfl((int)f_plen, (int)sl);
+                    const bool walk = e < nel && first[sl] == e;
+                    const uint32_t w = walk ? plen : 0u;
+                    const uint32_t incl = wave_scan_incl(w);
+                    if (e < nel) el_off[e] = (uint16_t)(W + incl - w);
+                    W += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
             }
+            WSYNC();
         }
-        WSYNC();
         if (W > 65535u) overflow = true;  // item offsets are u16; such a read goes to the large-capacity kernel
         for (uint32_t i0 = 0; i0 < W && !overflow; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -3026,7 +3038,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             uint32_t a = 0, h = 0;
             uint64_t pe = 0;
             uint32_t sl_i = 0, rel = 0;
-            if (act) {
+            if (one) {
+                sl_i = (uint32_t)sx0;
+                rel = i;
+            } else if (act) {
                 uint32_t lo = 0, hi = nel;  // last element whose offset is <= i (offsets are non-decreasing)
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
@@ -3060,14 +3075,23 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         // the fact records of the ids the closure registered, into their slots' lanes (the decision step at the end wants
         // every slot's; the load is in flight while the counts are made)
         if (!overflow && (uint32_t)lane >= nT_p1 && (uint32_t)lane < nT) fz = g_facts16[reg[lane]];
-        if (!overflow && W > 0) {
+        // One eligible id in the whole read whose ancestors were ALL registered just now (nobody's kept list holds one of them)
+        // and no position set with a negative first: every one of those ancestors is reached by exactly the sets that hold the
+        // id -- its count is the id's own -- and steps (3a) .. (3c) have nothing else to find.  The usual read: strains of one
+        // species, the representative one eligible.  (LMAT_CLOSURE_FAST, compile time.)
+        const bool lone = one && !overflow && W > 0 && nT - nT_p1 == W && cand == nuniq;
+        if (lone) {
+            const uint32_t c0 = cnt[sx0];
+            if ((uint32_t)lane >= nT_p1 && (uint32_t)lane < nT) cnt[lane] = (uint16_t)c0;
+            WSYNC();
+        } else if (!overflow && W > 0) {
             const bool sl_act = (uint32_t)lane < nT;
             uint32_t tin_s = 0xFFFF, tout_s = 0;
             if (sl_act) { tin_s = s_tin[lane]; tout_s = s_tout[lane]; }
             // (3a) for every kept id that is eligible somewhere: the set of slots that are proper ancestors of it, as a
             //      64-bit mask held by the id's own lane
             uint32_t anc_lo = 0, anc_hi = 0;
-            uint64_t todo = __ballot(first[lane] != 0xFFFFFFFFu);
+            uint64_t todo = todo0;
             while (todo) {
                 const int sx = __builtin_ctzll(todo);
                 todo &= todo - 1;
