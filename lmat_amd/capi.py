@@ -567,7 +567,7 @@ class Engine:
         """Reads the last launch passed from class to class (after sync()): fast -> E=512 -> middle tier -> large LDS -> global memory."""
         out = np.zeros(16, dtype=np.uint32)
         self._chk(self.lib.lmat_debug_last_counters(self.ctx, _ptr(out)))
-        return {"past_fast": int(out[2]), "past_e512": int(out[3]), "past_middle": int(out[10]), "past_large": int(out[7])}
+        return {"past_fast": int(out[2]), "past_e512": int(out[3]), "past_middle": int(out[10]), "past_large": int(out[7]), "debug_words_11_15": [int(x) for x in out[11:16]]}
 
     def probe_stats(self, kmers):
         """-> dict: where the lookups of these k-mers end (home bucket / absent at once / overflow hit / overflow miss, overflow buckets read)."""

@@ -3002,7 +3002,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     const uint32_t sl = hent[tid_find(hent, THM, el_ta[e])] >> 16;
                     const bool el = !(dfl[el_d[e]] & kListNegFirst) && ((ES >> sl) & 1ull);
                     sreg[ch] = sl | (el ? 0x100u : 0u);
-                    el_ta[e] = (uint16_t)sl;
+                    el_ta[e] = (uint16_t)sreg[ch];  // (kept for step (3b))
                     if (el) atomicMin(&first[sl], e);
                 }
             }
@@ -3048,7 +3048,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     if ((uint32_t)el_off[mid] <= i) lo = mid + 1; else hi = mid;
                 }
                 const uint32_t e = lo - 1;
-                sl_i = el_ta[e];
+                sl_i = (uint32_t)el_ta[e] & 0xFFu;
                 rel = i - (uint32_t)el_off[e];
             }
             const uint32_t poff_i = (uint32_t)__shfl((int)f_poff, (int)sl_i);  // the chain's start, from the slot's lane
@@ -3100,33 +3100,46 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 const uint64_t am = __ballot(tin_s < tin_x) & __ballot(tout_x <= tout_s);  // (idle slots hold tin 0xFFFF: never below)
                 if (lane == sx) { anc_lo = (uint32_t)am; anc_hi = (uint32_t)(am >> 32); }
             }
-            // (3b) lane d = position set d (at most 64 of them here): the slots it keeps, and the ancestors of its eligible ids
-            const bool d_act = (uint32_t)lane < ndist;
-            const uint32_t dn_ = d_act ? (uint32_t)dn[lane] : 0u, ds_ = d_act ? (uint32_t)dstart[lane] : 0u;
-            const bool d_ok = d_act && !(dfl[lane] & kListNegFirst);
-            uint32_t hit_lo = 0, hit_hi = 0, mem_lo = 0, mem_hi = 0;
-            for (uint32_t j = 0; __ballot(j < dn_) != 0; ++j) {
-                const bool on = j < dn_;
-                const uint32_t sl = on ? (uint32_t)el_ta[ds_ + j] : 0u;  // the slot of the id (stored above)
-                const uint32_t alo = (uint32_t)__shfl((int)anc_lo, (int)sl), ahi = (uint32_t)__shfl((int)anc_hi, (int)sl);
-                if (on) {
-                    const uint32_t bit = 1u << (sl & 31u);
-                    if (sl & 32u) mem_hi |= bit; else mem_lo |= bit;
-                    if (d_ok && ((ES >> sl) & 1ull)) { hit_lo |= alo; hit_hi |= ahi; }
+            // (3b) per position set d (at most 64 of them here): the slots it keeps, and the ancestors of its eligible ids -- two
+            //      64-bit masks per set, OR-ed together in LDS by the set's elements, a lane per element (slot and eligibility
+            //      are in el_ta).  The per-set loop this replaces ran to the longest list's length with ~18 vector
+            //      instructions a step; the vector pipe is what the kernel runs out of.
+            unsigned int* memw = (unsigned int*)el_t;    // [64] {low, high}: the registration-order ids and the item offsets are dead
+            unsigned int* hitw = (unsigned int*)el_off;  // [64] {low, high}
+            static_assert(2 * E >= 512 && sizeof(*el_t) == 2 && sizeof(*el_off) == 2, "64 mask pairs fit each of the two dead arrays");
+            *(u32x2*)(memw + 2 * lane) = u32x2{0u, 0u};
+            *(u32x2*)(hitw + 2 * lane) = u32x2{0u, 0u};
+            WSYNC();
+#pragma unroll
+            for (int ch = 0; ch < EC; ++ch) {
+                if ((uint32_t)ch * 64 < nel) {
+                    const uint32_t e = (uint32_t)ch * 64 + lane;
+                    const uint32_t se = e < nel ? (uint32_t)el_ta[e] : 0u;  // slot | eligible << 8 (stored above)
+                    const uint32_t sl = se & 0xFFu;
+                    const uint32_t alo = (uint32_t)__shfl((int)anc_lo, (int)sl), ahi = (uint32_t)__shfl((int)anc_hi, (int)sl);
+                    if (e < nel) {
+                        const uint32_t d2 = 2u * (uint32_t)el_d[e];
+                        __hip_atomic_fetch_or(&memw[d2 + (sl >> 5)], 1u << (sl & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (se & 0x100u) {
+                            if (alo) __hip_atomic_fetch_or(&hitw[d2], alo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (ahi) __hip_atomic_fetch_or(&hitw[d2 + 1], ahi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
                 }
             }
-            // (3c) count[a] += m_d for every position set d that reaches a without keeping it
-            const uint32_t add_lo = hit_lo & ~mem_lo, add_hi = hit_hi & ~mem_hi;
-            const uint32_t md = d_act ? (uint32_t)dmult[lane] : 0u;
-            const uint32_t my_bit = 1u << (lane & 31);
-            uint32_t add = 0;
-            for (uint32_t d = 0; d < ndist; ++d) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)add_lo, (int)d);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)add_hi, (int)d);
-                const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)md, (int)d);
-                if ((lo | hi) == 0) continue;
-                if ((lane < 32 ? lo : hi) & my_bit) add += m;
+            WSYNC();
+            // (3c) count[a] += m_d for every position set d that reaches a without keeping it: the sets' masks as LDS
+            //      broadcasts (a lane reads the half that holds its slot's bit), one bit test and one multiply-add per set
+            if ((uint32_t)lane < ndist) {
+                const u32x2 me = *(const u32x2*)(memw + 2 * lane), hi_ = *(const u32x2*)(hitw + 2 * lane);
+                *(u32x2*)(hitw + 2 * lane) = u32x2{hi_.x & ~me.x, hi_.y & ~me.y};
             }
+            WSYNC();
+            const unsigned int* aw = hitw + (lane >> 5);
+            const uint32_t sh = (uint32_t)lane & 31u;
+            uint32_t add = 0;
+#pragma unroll 4
+            for (uint32_t d = 0; d < ndist; ++d) add += ((aw[2 * d] >> sh) & 1u) * (uint32_t)dmult[d];
             if (sl_act && add) cnt[lane] = (uint16_t)(cnt[lane] + add);
             WSYNC();
         }
