@@ -15,6 +15,10 @@
 #include <type_traits>
 #include "kernels.hpp"
 
+#ifndef LMAT_ABLATE
+#define LMAT_ABLATE 0         // -DLMAT_ABLATE=1 (scripts/build_variant.sh): finer LMAT_STOP_AFTER points (40 ..) for the instruction-count ablation
+#endif
+#define STOP_AT(n, v) do { if (LMAT_ABLATE && A.prm.stop_after == (n)) { if (lane == 0) { emit(250, (v)); } return; } } while (0)
 #ifndef LMAT_CLOSURE_FAST
 #define LMAT_CLOSURE_FAST 1   // (A/B builds: -DLMAT_CLOSURE_FAST=0)
 #endif
@@ -2089,6 +2093,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
             pass1_chunk((uint32_t)c * 64, kreg[c], hreg[c], treg[c], okm[c], ureg[c], fcm[c]);
         }
+        STOP_AT(47, 0);
         if (CPT) {
             if constexpr (LSH) {  // every lane's m-mer value, parked for its three left neighbours (the packed record under it is through)
                 WSYNC();
@@ -2357,6 +2362,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             nuniq += popc64(okm[c]);
         }
     }
+    STOP_AT(46, nuniq);
     RELANE();
     // ---- probe, chunk by chunk
     uint32_t nov = 0;  // entries of olist
@@ -2828,6 +2834,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     //      taxid registers it (atomicMin on the entry), so order is kept with several lists per chunk.
     //      The same pass makes leaf_track (:1112-1116) and the kept ids' own position counts (:701-721): the hash entry of
     //      an element's id is at hand.  cnt/leaf are packed u16 pairs updated with dword atomics, cleared for all slots.
+    STOP_AT(41, nel);
     for (uint32_t i = lane; i < (uint32_t)T; i += 64) ((unsigned int*)cnt)[i] = 0;  // covers cnt[T] and leaf[T]
     uint32_t nT = 0;
     for (uint32_t e0 = 0; e0 < nel && !overflow; e0 += 64) {
@@ -2991,6 +2998,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         // FIRST eligible occurrence of a kept id has to be walked: a later walk of the same chain meets nothing but
         // registered ids.  (Lists of one genus repeat their ids: without this such a read walked thousands of items,
         // one round trip to memory per 64.)
+        STOP_AT(42, nT);
         uint32_t W = 0;
         uint32_t sreg[EC];  // slot | eligible << 8
 #pragma unroll
@@ -3008,6 +3016,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
         }
         WSYNC();
+        STOP_AT(43, nT);
         // the slots with an eligible element.  One such slot in the whole read (the usual case: strains of one species, the
         // representative one eligible): its chain is the only one to walk -- no offsets to scan, no search per item.
         const uint64_t todo0 = __ballot(first[lane] != 0xFFFFFFFFu);
@@ -3031,6 +3040,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
             WSYNC();
         }
+        STOP_AT(44, W);
         if (W > 65535u) overflow = true;  // item offsets are u16; such a read goes to the large-capacity kernel
         for (uint32_t i0 = 0; i0 < W && !overflow; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -3072,6 +3082,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             nT += newcnt;
             WSYNC();
         }
+        STOP_AT(45, nT);
         // the fact records of the ids the closure registered, into their slots' lanes (the decision step at the end wants
         // every slot's; the load is in flight while the counts are made)
         if (!overflow && (uint32_t)lane >= nT_p1 && (uint32_t)lane < nT) fz = g_facts16[reg[lane]];
@@ -3130,7 +3141,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             WSYNC();
             // (3c) count[a] += m_d for every position set d that reaches a without keeping it: the sets' masks as LDS
             //      broadcasts (a lane reads the half that holds its slot's bit), one bit test and one multiply-add per set
-            if ((uint32_t)lane < ndist) {
+            {   // (every lane: a lane past the last set holds zeros, and the loop below runs over whole groups of four sets)
                 const u32x2 me = *(const u32x2*)(memw + 2 * lane), hi_ = *(const u32x2*)(hitw + 2 * lane);
                 *(u32x2*)(hitw + 2 * lane) = u32x2{hi_.x & ~me.x, hi_.y & ~me.y};
             }
@@ -3138,8 +3149,20 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             const unsigned int* aw = hitw + (lane >> 5);
             const uint32_t sh = (uint32_t)lane & 31u;
             uint32_t add = 0;
-#pragma unroll 4
-            for (uint32_t d = 0; d < ndist; ++d) add += ((aw[2 * d] >> sh) & 1u) * (uint32_t)dmult[d];
+            // four sets a step: their mask words with constant offsets, their four multiplicities as one 8-byte broadcast; per set
+            // a bit-field extract and a 16-bit multiply-add that takes its factor from either half of a register
+            auto mad_lo = [](uint32_t bit, uint32_t mm, uint32_t acc) -> uint32_t { uint32_t r; asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(bit), "v"(mm), "v"(acc)); return r; };
+            auto mad_hi = [](uint32_t bit, uint32_t mm, uint32_t acc) -> uint32_t { uint32_t r; asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(r) : "v"(bit), "v"(mm), "v"(acc)); return r; };
+            static_assert(L::D == 64 && (L::OFF_R2 + 4 * L::D) % 8 == 0, "the multiplicities are read eight bytes at a time, up to set 63");
+            for (uint32_t d = 0; d < ndist; d += 4) {
+                const unsigned int* pw = aw + 2 * d;
+                const uint32_t w0 = pw[0], w1 = pw[2], w2 = pw[4], w3 = pw[6];
+                const u32x2 mm = *(const u32x2*)(dmult + d);
+                add = mad_lo(__builtin_amdgcn_ubfe(w0, sh, 1u), mm.x, add);
+                add = mad_hi(__builtin_amdgcn_ubfe(w1, sh, 1u), mm.x, add);
+                add = mad_lo(__builtin_amdgcn_ubfe(w2, sh, 1u), mm.y, add);
+                add = mad_hi(__builtin_amdgcn_ubfe(w3, sh, 1u), mm.y, add);
+            }
             if (sl_act && add) cnt[lane] = (uint16_t)(cnt[lane] + add);
             WSYNC();
         }
