@@ -1038,6 +1038,8 @@ __device__ __forceinline__ void spread_left(uint64_t& lo, uint64_t& hi, int s) {
 // general path (hand-off record -> k4_*_kernel), which restates the reference statement by statement.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rl(uint32_t v, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
+// lane `from` (0 .. 63) of v, per lane: the bare ds_bpermute (__shfl adds the sub-group arithmetic of its width argument: two vector instructions)
+__device__ __forceinline__ uint32_t lane_of(uint32_t v, uint32_t from) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
 __device__ __forceinline__ uint32_t wave_or(uint32_t x) {
     x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
     x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
@@ -3030,7 +3032,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 if ((uint32_t)ch * 64 < nel) {
                     const uint32_t e = (uint32_t)ch * 64 + lane;
                     const uint32_t sl = sreg[ch] & 0xFFu;
-                    const uint32_t plen = (uint32_t)__shfl((int)f_plen, (int)sl);
+                    const uint32_t plen = lane_of(f_plen, sl);
                     const bool walk = e < nel && first[sl] == e;
                     const uint32_t w = walk ? plen : 0u;
                     const uint32_t incl = wave_scan_incl(w);
@@ -3061,7 +3063,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 sl_i = (uint32_t)el_ta[e] & 0xFFu;
                 rel = i - (uint32_t)el_off[e];
             }
-            const uint32_t poff_i = (uint32_t)__shfl((int)f_poff, (int)sl_i);  // the chain's start, from the slot's lane
+            const uint32_t poff_i = lane_of(f_poff, sl_i);  // the chain's start, from the slot's lane
             if (act) {
                 pe = g_paths8[poff_i + rel];  // id | depth | tin | tout of that ancestor
                 a = (uint32_t)(pe & 0xFFFFu);
@@ -3109,7 +3111,11 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 const uint32_t tin_x = (uint32_t)__builtin_amdgcn_readlane((int)tin_s, sx);
                 const uint32_t tout_x = (uint32_t)__builtin_amdgcn_readlane((int)tout_s, sx);
                 const uint64_t am = __ballot(tin_s < tin_x) & __ballot(tout_x <= tout_s);  // (idle slots hold tin 0xFFFF: never below)
-                if (lane == sx) { anc_lo = (uint32_t)am; anc_hi = (uint32_t)(am >> 32); }
+                // the mask into its id's own lane (one scalar operand per vector instruction on this target: the lane number rides in m0)
+                // (m0 is the compiler's own -- the bucket loads keep the LDS address there --: saved and put back)
+                uint32_t m0_keep;
+                asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+                    : "+v"(anc_lo), "+v"(anc_hi), "=&s"(m0_keep) : "s"((uint32_t)am), "s"(sx), "s"((uint32_t)(am >> 32)));
             }
             // (3b) per position set d (at most 64 of them here): the slots it keeps, and the ancestors of its eligible ids -- two
             //      64-bit masks per set, OR-ed together in LDS by the set's elements, a lane per element (slot and eligibility
@@ -3120,6 +3126,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             static_assert(2 * E >= 512 && sizeof(*el_t) == 2 && sizeof(*el_off) == 2, "64 mask pairs fit each of the two dead arrays");
             *(u32x2*)(memw + 2 * lane) = u32x2{0u, 0u};
             *(u32x2*)(hitw + 2 * lane) = u32x2{0u, 0u};
+            const bool wide_t = nT > 32u;  // slots beyond 31 exist: the high halves of the masks are in play (seldom)
             WSYNC();
 #pragma unroll
             for (int ch = 0; ch < EC; ++ch) {
@@ -3127,13 +3134,13 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     const uint32_t e = (uint32_t)ch * 64 + lane;
                     const uint32_t se = e < nel ? (uint32_t)el_ta[e] : 0u;  // slot | eligible << 8 (stored above)
                     const uint32_t sl = se & 0xFFu;
-                    const uint32_t alo = (uint32_t)__shfl((int)anc_lo, (int)sl), ahi = (uint32_t)__shfl((int)anc_hi, (int)sl);
+                    const uint32_t alo = lane_of(anc_lo, sl), ahi = wide_t ? lane_of(anc_hi, sl) : 0u;
                     if (e < nel) {
                         const uint32_t d2 = 2u * (uint32_t)el_d[e];
                         __hip_atomic_fetch_or(&memw[d2 + (sl >> 5)], 1u << (sl & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (se & 0x100u) {
-                            if (alo) __hip_atomic_fetch_or(&hitw[d2], alo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (ahi) __hip_atomic_fetch_or(&hitw[d2 + 1], ahi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_or(&hitw[d2], alo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (wide_t) __hip_atomic_fetch_or(&hitw[d2 + 1], ahi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }
