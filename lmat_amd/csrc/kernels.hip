@@ -80,6 +80,16 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
     return x;
 }
+// inclusive running maximum over the 64 lanes, same six steps
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return x;
+}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(x), 63); }
 // number of set bits of a wave-uniform mask below this lane (v_mbcnt: two instructions)
 __device__ __forceinline__ uint32_t prefix_count(uint64_t m) {
@@ -1164,10 +1174,11 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     // ---- statistics (read_label.cpp:803-880): sums in registration order; a zero score adds +0.0, so pos_log_sum == log_sum
     float log_sum = 0.0f;
     uint32_t rank = 0;
-    for (uint32_t t = 0; t < nT; t += 2) {   // (two per step: the kernel has no registers to spare for four)
-        const u32x2 q = *(const u32x2*)((const uint32_t*)xs + t), kq = *(const u32x2*)(xk + t);
-        log_sum += __uint_as_float(q.x); log_sum += __uint_as_float(q.y);
-        rank += (kq.x < keyr ? 1u : 0u) + (kq.y < keyr ? 1u : 0u);
+    for (uint32_t t = 0; t < nT; t += 4) {   // (four per step: slots past nT hold a zero score and the largest key -- neutral)
+        const u32x4 q = *(const u32x4*)((const uint32_t*)xs + t);
+        log_sum += __uint_as_float(q.x); log_sum += __uint_as_float(q.y); log_sum += __uint_as_float(q.z); log_sum += __uint_as_float(q.w);
+        const u32x4 kq = *(const u32x4*)(xk + t);
+        rank += (kq.x < keyr ? 1u : 0u) + (kq.y < keyr ? 1u : 0u) + (kq.z < keyr ? 1u : 0u) + (kq.w < keyr ? 1u : 0u);
     }
     const uint32_t pos_sig_hits = (uint32_t)popc64(bal(my_cnt > 0));
     const uint32_t use_sig_hits = pos_sig_hits > 3 ? pos_sig_hits : nT;
@@ -1226,10 +1237,12 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         xo[lane] = act ? oi : 0xFFFFu;
         WSYNC();
         uint32_t mis = 0;  // highest position this candidate does not fit (0: none -- position 0 is above nobody)
-        for (uint32_t j = 0; j < nT; j += 2) {   // (two members per step: four would need eight more registers than the kernel has)
-            const u32x2 tq = *(const u32x2*)(xt + j), oq = *(const u32x2*)(xo + j);
+        for (uint32_t j = 0; j < nT; j += 4) {   // (four members per step; the spare positions relate to everything)
+            const u32x4 tq = *(const u32x4*)(xt + j), oq = *(const u32x4*)(xo + j);
             mis = max(mis, max(ti, tq.x) > min(oi, oq.x) ? j : 0u);
             mis = max(mis, max(ti, tq.y) > min(oi, oq.y) ? j + 1u : 0u);
+            mis = max(mis, max(ti, tq.z) > min(oi, oq.z) ? j + 2u : 0u);
+            mis = max(mis, max(ti, tq.w) > min(oi, oq.w) ? j + 3u : 0u);
         }
         const uint64_t am_ = below_mask((int)nT);
         const uint64_t F = bal(mis > (uint32_t)lane) & am_;
@@ -1289,9 +1302,9 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
             xk[lane] = member ? dkey : 0u;
             WSYNC();
             uint32_t drank = 0;
-            for (uint32_t t = 0; t < nmem; t += 2) {
-                const u32x2 q = *(const u32x2*)(xk + t);
-                drank += (q.x > dkey ? 1u : 0u) + (q.y > dkey ? 1u : 0u);
+            for (uint32_t t = 0; t < nmem; t += 4) {   // (lanes that are no member wrote a zero key: neutral)
+                const u32x4 q = *(const u32x4*)(xk + t);
+                drank += (q.x > dkey ? 1u : 0u) + (q.y > dkey ? 1u : 0u) + (q.z > dkey ? 1u : 0u) + (q.w > dkey ? 1u : 0u);
             }
             const int to_lane = (int)((member ? drank : 63u) << 2);  // (ds_permute wraps modulo 64: the others push to lane 63, an entry only when all 64 are)
             const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_iv);
@@ -2731,6 +2744,12 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     const GAS uint16_t* arena = g_arena;
     uint32_t nel = 0, cand = nuniq, fnd = 0;
     bool any_long = false;
+    // The owner (distinct-list index) of every element: each list marks its first element, a running maximum over the elements
+    // spreads the marks (list indices grow with the element positions).  A loop "for j < n: el_d[s0 + j] = d" in every list's
+    // lane ran to the longest list's length.
+    static_assert((E * sizeof(eld_t)) % 256 == 0, "the owner array is cleared a dword per lane and step");
+    for (uint32_t i = lane; i < (uint32_t)(E * sizeof(eld_t) / 4); i += 64) ((uint32_t*)el_d)[i] = 0u;
+    WSYNC();
     for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
         const uint32_t d = d0 + lane;
         uint32_t n = 0, fl = 0, m = 0, pay = 0;
@@ -2757,8 +2776,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             dn[d] = (uint16_t)n;
             dfl[d] = (uint8_t)fl;
             dstart[d] = (uint16_t)s0;
-            if (s0 + n <= (uint32_t)E) {  // owner index of every element; ids of the short lists
-                for (uint32_t j = 0; j < n; ++j) el_d[s0 + j] = (eld_t)d;
+            if (n != 0 && s0 < (uint32_t)E) el_d[s0] = (eld_t)d;
+            if (s0 + n <= (uint32_t)E) {  // ids of the short lists
                 if (n == 1) { el_t[s0] = (tid_t)w3; el_ta[s0] = (tid_t)w4; }
                 else if (!WIDE && n == 2) {
                     el_t[s0] = (tid_t)w3; el_t[s0 + 1] = (tid_t)w4;
@@ -2785,6 +2804,17 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         return;
     }
     for (int i = lane; i < L::TH; i += 64) { hent[i] = 0; best[i] = 0; }
+    WSYNC();
+    {
+        uint32_t carry = 0;
+        for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            uint32_t v = e < nel ? (uint32_t)el_d[e] : 0u;
+            v = max(wave_scan_max(v), carry);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            if (e < nel) el_d[e] = (eld_t)v;
+        }
+    }
     WSYNC();
     RELANE();
     // ---- K3b stage 2: ids of the longer lists (one more round, only when there are any), then one 16-byte
