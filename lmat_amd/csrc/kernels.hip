@@ -1069,6 +1069,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
     return rl(x, 63);
 }
 __device__ __forceinline__ uint64_t below_mask(int p) { return p <= 0 ? 0ull : (p >= 64 ? ~0ull : ((1ull << p) - 1)); }  // bits < p
+// ... where the range of p is known (the clamps above are four or five scalar instructions a call, and the decision step is scalar-heavy)
+__device__ __forceinline__ uint64_t below_mask_0_63(int p) { return (1ull << p) - 1; }    // p in 0 .. 63
+__device__ __forceinline__ uint64_t below_mask_1_64(int p) { return ~0ull >> (64 - p); }  // p in 1 .. 64
 
 typedef const ClassifyArgs __attribute__((address_space(4))) CArgsK4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1195,7 +1198,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     const float pscore = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)__float_as_uint(sc)));
     const float top_score = __uint_as_float(rl(__float_as_uint(pscore), (int)nT - 1));  // the largest count sorts last
     // top-scoring plasmids by position (:301-304), taken now: the flags are not needed again
-    const uint64_t PLtop = bal(((uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)fz.w) >> 16) & kFlagPlasmid) & bal(pscore >= top_score) & below_mask((int)nT);
+    const uint64_t PLtop = bal(((uint32_t)__builtin_amdgcn_ds_bpermute((int)pslot4, (int)fz.w) >> 16) & kFlagPlasmid) & bal(pscore >= top_score) & below_mask_1_64((int)nT);
     WSYNC();
     float log_std = 0.0f;
     for (uint32_t t = 0; t < nT; t += 4) {
@@ -1244,10 +1247,10 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
             mis = max(mis, max(ti, tq.z) > min(oi, oq.z) ? j + 2u : 0u);
             mis = max(mis, max(ti, tq.w) > min(oi, oq.w) ? j + 3u : 0u);
         }
-        const uint64_t am_ = below_mask((int)nT);
+        const uint64_t am_ = below_mask_1_64((int)nT);   // 1 .. 64 taxids (checked at the top)
         const uint64_t F = bal(mis > (uint32_t)lane) & am_;
         const int lidx = F ? 63 - __builtin_clzll(F) : -1;
-        const uint64_t ACC = am_ & ~below_mask(lidx + 1);
+        const uint64_t ACC = am_ & ~below_mask_0_63(lidx + 1);   // lidx <= nT - 2
         // deepest and shallowest member (:316-321; depths within a lineage are all different)
         const bool accd_ = lane_bit(ACC);
         const uint32_t kmax = wave_max_u32(accd_ ? (PDEP << 6) | (uint32_t)lane : 0u);
@@ -1310,14 +1313,14 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
             const uint32_t d_iv = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_iv);
             const uint32_t d_sc = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_sc);
             const uint32_t d_tid = (uint32_t)__builtin_amdgcn_ds_permute(to_lane, (int)m_tid);
-            const uint64_t lm = below_mask((int)nlin);
+            const uint64_t lm = below_mask_1_64((int)nlin);   // at least the accepted candidate, at most 64 (checked above)
             if (bal(!(d_tid & 0x20000u)) & lm) return false;  // two entries of one depth: the general path replays std::sort on them
             // ---- competitors (:355-362, cmpCompLineage :264-282): candidates from lidx down that are not ancestors of the
             //      shallowest lineage member, each against the lineage from its deepest entry up
             uint64_t NG = 0;
             if (lidx >= 0) {
                 const uint32_t htin = high_iv & 0xFFFFu, htout = high_iv >> 16;
-                const uint64_t comp = below_mask(lidx + 1) & ~(have_add ? bal(ti < htin) & bal(htout <= oi) : 0ull);  // not the added ancestors themselves (:356)
+                const uint64_t comp = below_mask_0_63(lidx + 1) & ~(have_add ? bal(ti < htin) & bal(htout <= oi) : 0ull);  // not the added ancestors themselves (:356)
                 uint64_t active = comp, big = 0;
                 uint32_t mlo = 0, mhi = 0;
                 for (uint32_t j = 0; j < nlin && active; ++j) {
@@ -1336,7 +1339,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
                 }
                 // the first competitor (from lidx down) that meets a lineage score beyond the threshold ends the scan; its own
                 // marks up to that entry stand
-                const uint64_t counted = big ? comp & ~below_mask(63 - __builtin_clzll(big)) : comp;
+                const uint64_t counted = big ? comp & ~below_mask_0_63(63 - __builtin_clzll(big)) : comp;
                 const bool cn = lane_bit(counted);
                 NG = (uint64_t)wave_or(cn ? mlo : 0u) | (nlin > 32 ? (uint64_t)wave_or(cn ? mhi : 0u) << 32 : 0ull);
             }
@@ -2138,7 +2141,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         if (lane == 0) { emit(LMAT_ST_SHORT_VALID, 0); nmacc[0]++; }
         return;
     }
-    if (A.prm.stop_after == 1) { if (lane == 0) { emit(250, 0); } return; }
+    STOP_AT(1, 0);
     RELANE();
     uint32_t nuniq = 0;   // distinct valid k-mers of the read
     uint32_t nscan = 0;   // entries of upay[]: one per distinct k-mer (wide) or per k-mer position (compact)
@@ -2521,7 +2524,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     nscan = P;
     if (A.prm.stop_after == 2) { if (lane == 0) { emit(250, nuniq); } return; }
     }
-    if (A.prm.stop_after == 3) { if (lane == 0) { emit(250, upay[0]); } return; }
+    STOP_AT(3, upay[0]);
     RELANE();
     // ---- K3a: distinct payloads in first-occurrence order with multiplicities.  Identical payload
     //      means identical taxid list, hence identical contribution at every such position.
@@ -2543,9 +2546,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             rm[c] = __ballot(pv[c] != 0u);
         }
         uint32_t dp_reg = 0, dm_reg = 0;
+        uint64_t left = 0;
 #pragma unroll
         for (int c0 = 0; c0 < KP; ++c0) {
-            while (rm[c0] && !many) {
+            while (rm[c0] && ndist < 64u) {
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pv[c0], __builtin_ctzll(rm[c0]));
                 uint32_t cn = 0;
 #pragma unroll
@@ -2554,11 +2558,16 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     cn += (uint32_t)popc64(m);
                     rm[c] &= ~m;
                 }
-                if (ndist >= 64) { many = true; break; }
-                if ((uint32_t)lane == ndist) { dp_reg = v; dm_reg = cn; }
+                // payload and multiplicity into lane ndist of their registers: two v_writelane (the lane number rides in m0, which
+                // is the compiler's own: saved and put back) instead of a compare, two moves and two selects
+                uint32_t m0_keep;
+                asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+                    : "+v"(dp_reg), "+v"(dm_reg), "=&s"(m0_keep) : "s"(v), "s"(ndist), "s"(cn));
                 ++ndist;
             }
+            left |= rm[c0];
         }
+        many = left != 0;  // a 65th distinct payload: positions are left when the 64 lanes are taken
         if (!many) {
             if ((uint32_t)lane < ndist) { dpay[lane] = dp_reg; dmult[lane] = (uint16_t)dm_reg; }  // overlay the (dead) k-mer arrays
             WSYNC();
@@ -2909,7 +2918,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     u32x4 fz = u32x4{0u, 0u, 0u, 0u};
     if constexpr (!INK4) { if ((uint32_t)lane < nT) fz = g_facts16[reg[lane]]; }
     WSYNC();
-    if (A.prm.stop_after == 5) { if (lane == 0) { emit(250, nT); } return; }
+    STOP_AT(5, nT);
     RELANE();
     // representative strain per species (read_label.cpp:1144-1177): max leaf count, ties -> smallest taxid
     // (-s: the whole post pass :1143-1204 is skipped; the list records already hold the lineages)
@@ -3212,7 +3221,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         }
         return;
     }
-    if (A.prm.stop_after == 6) { if (lane == 0) { emit(250, nT); } return; }
+    STOP_AT(6, nT);
     if (A.rand_max) {  // rand_read_label: proc_line + construct_labels of src/rand_read_label.cpp:185-213,372-398
         const uint32_t gcb = ((const GAS uint8_t*)A.rand_gc)[r - A.result_base];
         GAS uint32_t* rmax = (GAS uint32_t*)A.rand_max;
