@@ -1085,8 +1085,11 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
                                         int valid_kmers, uint32_t len, int bin_sel) {
     const float hbias = Ap->prm.hbias, sdiff = Ap->prm.sdiff;
     const int screen_phix = Ap->prm.screen_phix;
-    const int stop = Ap->prm.stop_after;   // 30..33: timing experiments (the step ends early with a placeholder record)
-    if (Ap->nm.active || (stop != 0 && (stop < 30 || stop > 34))) return false;
+    // what does not depend on the read -- no null model, no debug stop outside 30 .. 34, depths that grow along every branch, candidates
+    // only with -p (without it a multi match prints the lineage as built, :917-927: the general path's job; bin/run_rl.sh always
+    // passes -p) -- is one bit the launcher worked out (k4_static_of)
+    if (!(Ap->prm.k4_static & 1)) return false;
+    const int stop = LMAT_ABLATE ? Ap->prm.stop_after : 0;   // 30..34: timing experiments (the step ends early with a placeholder record; ablation builds)
     auto placeholder = [&]() {
         if (lane == 0) {  // (on a zero the compiler cannot see through, as classify_one's emit: constant words would sit in registers across the read loop)
             uint32_t z = 0;
@@ -1100,8 +1103,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         return true;
     };
     if (stop == 30 || (stop == 34 && nT <= 16)) return placeholder();   // 34: only the reads with more than 16 taxids take the step
-    if (cand - 1u > 998u || nT - 1u > 63u || !Ap->tb.depth_consistent) return false;   // cand in 1..999, 1..64 taxids, depths that grow along every branch
-    if (Ap->cands && !Ap->prm.prn_all) return false;  // candidates wanted, but without -p: a multi match prints the lineage as built (:917-927) -- the general path's job (bin/run_rl.sh always passes -p)
+    if (cand - 1u > 998u || nT - 1u > 63u) return false;   // cand in 1..999, 1..64 taxids
     const bool act = (uint32_t)lane < nT;
     const uint32_t dep = act ? (fz.w & 0xFFFFu) : 0u, fl = act ? (fz.w >> 16) : 0u;
     if (bal(my_cnt > cand) | bal(dep > 0x7FFFu) | (hbias != 0.0f ? bal((fl & kFlagHuman) != 0) : 0ull)) return false;  // (a bias of 0 adds 0 * stdev: nothing)
@@ -3261,7 +3263,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         // Where the decision is made: tables of up to 16 taxids go to k4_row_kernel, four reads to a wave (status 251); larger ones
         // are decided right here on the wave (k4_wave) when the read qualifies; everything else -- null models, an effective human
         // bias, -y style experiments, more than 999 candidate k-mers ... -- takes the general path, by table size.
-        const bool rows = A.prm.k4_row && nT <= 16u && !A.nm.active && A.prm.stop_after == 0 && tb.depth_consistent && !(A.cands && !A.prm.prn_all);
+        const bool rows = (A.prm.k4_static & 2) && nT <= 16u;
         if constexpr (!INK4) {
             if (!rows) {
                 const uint32_t my_cnt = (uint32_t)lane < nT ? (uint32_t)cnt[lane] : 0u, my_id = (uint32_t)lane < nT ? (uint32_t)reg[lane] : 0u;
@@ -4009,9 +4011,19 @@ void launch_k4_end(const ClassifyArgs& a, hipStream_t join_stream, hipStream_t s
     hipEventRecord(done, join_stream);
 }
 
+// Which decision paths the launch allows (bit 0: k4_wave, bit 1: k4_row_kernel), from what does not vary with the read.
+static int k4_static_of(const ClassifyArgs& a) {
+    const int stop = a.prm.stop_after;
+    const bool base = !a.nm.active && a.tb.depth_consistent && !(a.cands && !a.prm.prn_all);
+    const bool wave = base && (stop == 0 || (stop >= 30 && stop <= 34));
+    const bool rows = base && a.prm.k4_row && stop == 0;
+    return (wave ? 1 : 0) | (rows ? 2 : 0);
+}
 template <int U, int T, int E, bool INK4, bool PERM, bool CPT, bool WIDE = false>
-static void launch_classify_t(const ClassifyArgs& a, hipStream_t stream) {
+static void launch_classify_t(const ClassifyArgs& a_in, hipStream_t stream) {
     using L = WL<U, T, E, INK4, CPT, WIDE>;
+    ClassifyArgs a = a_in;
+    a.prm.k4_static = k4_static_of(a);
     if (U > 2048) {  // tables in global memory: few workgroups; LDS only for the compact probe's scratch block
         int grid = kGmemGrid;
         if (!a.count_ptr && (uint64_t)grid > a.count) grid = (int)(a.count ? a.count : 1);
@@ -4046,7 +4058,9 @@ void launch_k4_debug_counts(const ClassifyArgs& a, const uint32_t* idx, const ui
     if (!n) return;
     if (on_the_wave) {
         const uint64_t g = n < 256 * 32 ? n : 256 * 32;
-        k4_wave_debug_kernel<<<dim3((unsigned)g), dim3(64), 0, stream>>>(a, idx, cnts, off, cands, n);
+        ClassifyArgs b = a;
+        b.prm.k4_static = k4_static_of(b);
+        k4_wave_debug_kernel<<<dim3((unsigned)g), dim3(64), 0, stream>>>(b, idx, cnts, off, cands, n);
     } else k4_debug_counts_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(a, idx, cnts, off, cands, n);
 }
 

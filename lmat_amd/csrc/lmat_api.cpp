@@ -96,6 +96,7 @@ static KernelParams kparams(const lmat_params& p) {
     // every wave-uniform value of k4_wave into vector work, ~1400 instructions per wave of four reads, no cheaper per read than the
     // ~390 of k4_wave -- and the step takes 7.5 ms instead of 7.1.  Off by default; kept as the measured alternative.
     k.k4_row = getenv("LMAT_K4_ROW") && atoi(getenv("LMAT_K4_ROW")) != 0;
+    k.k4_static = 0;
     return k;
 }
 

@@ -102,6 +102,7 @@ struct KernelParams {
     int permissive;  // -s: no representative-strain / lineage-closure pass (read_label.cpp:1143)
     int stop_after;  // debug/profiling only (env LMAT_STOP_AFTER): 0 = full path, n = return after phase n
     int k4_row;      // LMAT_K4_ROW=1: tables of up to 16 taxids are decided by k4_row_kernel instead of on the classify wave (measured slower)
+    int k4_static;   // set by the launchers (kernels.hip k4_static_of): what the choice of decision path asks of the launch, not of the read
 };
 
 }  // namespace lmat
