@@ -2281,8 +2281,12 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     //      2048-bit filters over the buckets of the groups' first k-mers).
     bool suspect = !CACHE;
     if (CACHE) {
-        uint32_t pb = 0, pq = 0, ps1 = 0, ps2 = 0, ps3 = 0;  // bucket / minimizer position / digests of the last lanes of the previous chunk
-        uint64_t Vp = 0, seen = 0;                   // ... and its valid mask
+        // bucket / minimizer position / digests of the last lanes of the previous chunk.  An invalid window carries the digest and the
+        // minimizer position kNone, which no valid one has (a digest by a 2^-32 chance: a false alarm costs the exact pass below, never
+        // a miss): "lane - d is valid" is then part of the compare, not three shifted copies of the valid mask on the scalar side
+        constexpr uint32_t kNone = 0xFFFFFFFFu;
+        uint32_t pb = 0, pq = kNone, ps1 = kNone, ps2 = kNone, ps3 = kNone;
+        uint64_t seen = 0;
         // LSH: bucket, digest and minimizer position of every k-mer parked in LDS (three zero entries in front: nothing precedes
         // the read), read back at -1, -2, -3
         LAS uint32_t* barr = (LAS uint32_t*)xl;
@@ -2291,13 +2295,13 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         if constexpr (LSH) {
             static_assert(10 * (64 * CH + 4) <= WL<U, T, E, INK4, CPT>::XL_BLOOM, "the parked values end below the repeat filter's bits");
             WSYNC();  // (the m-mer values above are through)
-            if (lane < 3) { barr[lane] = 0u; sarr[lane] = 0u; qarr[lane] = 0; }
+            if (lane < 3) { barr[lane] = 0u; sarr[lane] = kNone; qarr[lane] = 0xFFFF; }
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if ((uint32_t)c * 64 >= P) break;
                 barr[3 + c * 64 + lane] = hreg[c];
-                sarr[3 + c * 64 + lane] = (uint32_t)(kreg[c] ^ (kreg[c] >> 17));
-                qarr[3 + c * 64 + lane] = (uint16_t)((uint32_t)c * 64 + lane + (treg[c] >> 30));
+                sarr[3 + c * 64 + lane] = lane_bit(okm[c]) ? (uint32_t)(kreg[c] ^ (kreg[c] >> 17)) : kNone;
+                qarr[3 + c * 64 + lane] = lane_bit(okm[c]) ? (uint16_t)((uint32_t)c * 64 + lane + (treg[c] >> 30)) : (uint16_t)0xFFFF;
             }
             WSYNC();
         }
@@ -2305,10 +2309,9 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         for (int c = 0; c < CH; ++c) {
             if ((uint32_t)c * 64 >= P) break;
             const uint64_t V = okm[c];
-            const uint64_t V1 = (V << 1) | (Vp >> 63), V2 = (V << 2) | (Vp >> 62), V3 = (V << 3) | (Vp >> 61);  // lane - d is valid
             const uint32_t b = hreg[c];
-            const uint32_t sig = (uint32_t)(kreg[c] ^ (kreg[c] >> 17));
-            const uint32_t q = (uint32_t)c * 64 + lane + (treg[c] >> 30);  // where the k-mer's minimizer starts in the read
+            const uint32_t sig = lane_bit(V) ? (uint32_t)(kreg[c] ^ (kreg[c] >> 17)) : kNone;
+            const uint32_t q = lane_bit(V) ? (uint32_t)c * 64 + lane + (treg[c] >> 30) : (LSH ? 0xFFFFu : kNone);  // where the k-mer's minimizer starts in the read
             uint32_t bprev, qprev, s1, s2, s3;
             if constexpr (LSH) {
                 bprev = barr[c * 64 + lane + 2];
@@ -2323,8 +2326,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             }
             // lane masks, combined on the scalar side: a ballot of `a && b` goes through a 0/1 register and a compare, a ballot of
             // one compare is the compare
-            uint64_t hitm = V & ((V1 & __ballot(sig == s1)) | (V2 & __ballot(sig == s2)) | (V3 & __ballot(sig == s3)));
-            const uint64_t openm = V & ~(V1 & __ballot(b == bprev) & __ballot(q == qprev));  // lanes that open a group
+            uint64_t hitm = V & (__ballot(sig == s1) | __ballot(sig == s2) | __ballot(sig == s3));
+            const uint64_t openm = V & ~(__ballot(b == bprev) & __ballot(q == qprev));  // lanes that open a group
             uint32_t both = 0;
             if (lane_bit(openm)) {
                 const uint32_t h1 = b & 2047u, h2 = (b >> 11) & 2047u;
@@ -2341,7 +2344,6 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 ps2 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 62);
                 ps3 = (uint32_t)__builtin_amdgcn_readlane((int)sig, 61);
             }
-            Vp = V;
         }
         suspect = seen != 0;
     }
@@ -2548,10 +2550,14 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             rm[c] = __ballot(pv[c] != 0u);
         }
         uint32_t dp_reg = 0, dm_reg = 0;
-        uint64_t left = 0;
+        // Payload and multiplicity go into lane ndist of their registers with v_writelane (a compare, two moves and two selects
+        // otherwise).  The lane number rides in m0 -- one scalar operand per vector instruction on this target --, which is the
+        // compiler's own: saved here, put back behind the loops (nothing in between uses it: ballots, counts, scalar bookkeeping).
+        uint32_t m0_keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));
 #pragma unroll
         for (int c0 = 0; c0 < KP; ++c0) {
-            while (rm[c0] && ndist < 64u) {
+            while (rm[c0]) {
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pv[c0], __builtin_ctzll(rm[c0]));
                 uint32_t cn = 0;
 #pragma unroll
@@ -2560,16 +2566,13 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     cn += (uint32_t)popc64(m);
                     rm[c] &= ~m;
                 }
-                // payload and multiplicity into lane ndist of their registers: two v_writelane (the lane number rides in m0, which
-                // is the compiler's own: saved and put back) instead of a compare, two moves and two selects
-                uint32_t m0_keep;
-                asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
-                    : "+v"(dp_reg), "+v"(dm_reg), "=&s"(m0_keep) : "s"(v), "s"(ndist), "s"(cn));
-                ++ndist;
+                asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                             : "+v"(dp_reg), "+v"(dm_reg) : "s"(v), "s"(ndist), "s"(cn));
+                ++ndist;   // (beyond 64 the lane number wraps and earlier entries are overwritten: such a read is handed to a larger class below)
             }
-            left |= rm[c0];
         }
-        many = left != 0;  // a 65th distinct payload: positions are left when the 64 lanes are taken
+        asm volatile("s_mov_b32 m0, %0" : : "s"(m0_keep));
+        many = ndist > 64u;
         if (!many) {
             if ((uint32_t)lane < ndist) { dpay[lane] = dp_reg; dmult[lane] = (uint16_t)dm_reg; }  // overlay the (dead) k-mer arrays
             WSYNC();
