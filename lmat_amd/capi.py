@@ -129,6 +129,7 @@ def load_library(path: str | None = None):
         "lmat_synth_window": (i32, [vp, u32, u64, P(u64), vp, u32, P(u32)]),
         "lmat_debug_last_counters": (i32, [vp, vp]),
         "lmat_debug_probe_stats": (i32, [vp, vp, u64, vp]),
+        "lmat_debug_div_check": (i32, [vp, vp]),
         "lmat_synth_read_windows": (i32, [vp, vp, u32, u64, u64, vp, vp, vp, u32, u32, P(u32), P(u32)]),
         "lmat_table_address": (i32, [i32, u64, u64, P(u64), P(u32), P(u32)]),
         "lmat_format_out": (C.c_int64, [vp, vp, u64, vp, vp, vp, i32, u64, vp, u64]),
@@ -154,7 +155,7 @@ EXPORTED = ["lmat_device_count", "lmat_ctx_create", "lmat_ctx_destroy", "lmat_la
             "lmat_counts_reset", "lmat_counts_layout", "lmat_counts_device_ptr", "lmat_counts_get", "lmat_gather_bench",
             "lmat_table_address", "lmat_format_out", "lmat_stream_create", "lmat_stream_acquire", "lmat_stream_submit", "lmat_stream_submit_from", "lmat_host_alloc", "lmat_host_free",
             "lmat_stream_next", "lmat_stream_release", "lmat_stream_destroy", "lmat_counts_allreduce",
-            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_debug_decide_counts", "lmat_synth_window", "lmat_synth_read_windows", "lmat_debug_probe_stats", "lmat_debug_last_counters"]
+            "lmat_comm_unique_id", "lmat_comm_init", "lmat_comm_allreduce_counts", "lmat_comm_size", "lmat_comm_destroy", "lmat_db_clone", "lmat_debug_decide", "lmat_debug_decide_counts", "lmat_synth_window", "lmat_synth_read_windows", "lmat_debug_probe_stats", "lmat_debug_last_counters", "lmat_debug_div_check"]
 
 
 def _ptr(a):
@@ -568,6 +569,12 @@ class Engine:
         out = np.zeros(16, dtype=np.uint32)
         self._chk(self.lib.lmat_debug_last_counters(self.ctx, _ptr(out)))
         return {"past_fast": int(out[2]), "past_e512": int(out[3]), "past_middle": int(out[10]), "past_large": int(out[7]), "debug_words_11_15": [int(x) for x in out[11:16]]}
+
+    def div_check(self):
+        """-> (pairs whose fast quotient differs from the IEEE one, pairs tried): the small-integer division of the decision step."""
+        out = np.zeros(2, dtype=np.uint64)
+        self._chk(self.lib.lmat_debug_div_check(self.ctx, _ptr(out)))
+        return int(out[0]), int(out[1])
 
     def probe_stats(self, kmers):
         """-> dict: where the lookups of these k-mers end (home bucket / absent at once / overflow hit / overflow miss, overflow buckets read)."""

@@ -1073,6 +1073,25 @@ __device__ __forceinline__ uint64_t below_mask(int p) { return p <= 0 ? 0ull : (
 __device__ __forceinline__ uint64_t below_mask_0_63(int p) { return (1ull << p) - 1; }    // p in 0 .. 63
 __device__ __forceinline__ uint64_t below_mask_1_64(int p) { return ~0ull >> (64 - p); }  // p in 1 .. 64
 
+// a / b for integers 0 <= a < 2^10, 1 <= b < 2^10 held as floats, correctly rounded (the reference divides in IEEE arithmetic,
+// read_label.cpp:821): reciprocal to 1 ulp, a first quotient, its residual -- exact: a multiple of the quotient's ulp below 2^12 of
+// them -- and one correction.  What is rounded at the end lies within 2^-45 (relative) of a / b, and a quotient of two such
+// integers is never nearer than 2^-35 to a rounding boundary: the IEEE result, in 4 instructions instead of the 11 of the
+// general sequence (v_div_scale .. v_div_fixup).  Checked over the whole domain by lmat_debug_div_check (tests/test_gpu_decide.py).
+__device__ __forceinline__ float div_small_ints(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q0 = a * r;
+    const float e = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(e, r, q0);
+}
+__global__ void div_check_kernel(unsigned long long* out) {   // every pair of the domain against the IEEE division
+    const uint32_t a = blockIdx.x, b = threadIdx.x + 1u + 256u * blockIdx.y;
+    if (b >= 1024u) return;
+    const float fa = (float)a, fb = (float)b;
+    float ieee = fa / fb;
+    if (__float_as_uint(div_small_ints(fa, fb)) != __float_as_uint(ieee)) atomicAdd(out, 1ull);
+    atomicAdd(out + 1, 1ull);
+}
 typedef const ClassifyArgs __attribute__((address_space(4))) CArgsK4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint64_t bal(bool b) { return __builtin_amdgcn_ballot_w64(b); }
@@ -1113,7 +1132,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     float* xv = (float*)(xch + 256);  // [64] squared deviations
     uint32_t* xp = xch + 320;     // [64] taxid by sorted position: parked here, fetched where needed (the kernel has 64 registers)
     const float fcand = (float)cand;
-    const float sc = (float)my_cnt / fcand;   // lanes >= nT: 0
+    const float sc = div_small_ints((float)my_cnt, fcand);   // cand in 1 .. 999 and counts up to it (checked above); lanes >= nT: 0
     xs[lane] = sc;
     // ---- std::sort(TCmp) (:892-893).  Element = key << 6 | slot, key = count << 15 | depth; lane p = array position p.
     uint32_t e = act ? (((my_cnt << 15) | dep) << 6) | (uint32_t)lane : 0xFFFFFFFFu;
@@ -1912,14 +1931,15 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         }
         return;
     }
-    // tail mode (tail_kernel): this read's positions from 128 on were looked up beforehand.  Re-derived at each of the three
-    // places that ask (a scalar load and two compares) rather than carried: the kernel has no scalar register to spare.
+    // tail mode (tail_kernel): this read's positions from 128 on were looked up beforehand.  Worked out once and carried as one
+    // 32-bit scalar (re-deriving it at each of the three places that ask was two scalar loads and a dozen scalar instructions a time).
     constexpr bool TAILOK = CPT && U == 160 && !INK4;
-    auto tail_mode = [&]() -> bool {
-        if constexpr (!TAILOK) return false;
+    uint32_t tail_flag = 0;
+    if constexpr (TAILOK) {
         const uint32_t lpr = A.tail_lpr;
-        return lpr != 0 && P > 128u && P <= 128u + lpr && !A.nm.active;
-    };
+        tail_flag = (uint32_t)__builtin_amdgcn_readfirstlane((lpr != 0 && P > 128u && P <= 128u + lpr && !A.nm.active) ? 1 : 0);  // (a scalar, not a lane mask re-materialised from its conditions)
+    }
+    auto tail_mode = [&]() -> bool { return TAILOK && tail_flag != 0; };
     // ---- packed record -> LDS (coalesced), zero tail so windows past the end are invalid
     const uint32_t nb = (len + 15) / 16, nm = (len + 31) / 32;
 #pragma unroll
@@ -3924,6 +3944,8 @@ void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, ui
     hipLaunchKernelGGL(lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tb, kmers, n, counts, tids,
                        stride);
 }
+
+void launch_div_check(unsigned long long* out2, hipStream_t stream) { div_check_kernel<<<dim3(1024, 4), dim3(256), 0, stream>>>(out2); }
 
 void launch_probe_stats(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, unsigned long long* out, hipStream_t stream) {
     if (!n) return;

@@ -76,6 +76,7 @@ void launch_synth_reads(uint32_t* words, const uint64_t* rec_off, const uint32_t
                         uint64_t seed, const SynthGeo& g, hipStream_t stream);
 void launch_lookup(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, uint32_t* counts, uint32_t* tids,
                    uint32_t stride, hipStream_t stream);
+void launch_div_check(unsigned long long* out2, hipStream_t stream);
 void launch_probe_stats(const DeviceTables& tb, const uint64_t* kmers, uint64_t n, unsigned long long* out, hipStream_t stream);
 // fills a.tail16 / a.tail_u for the reads of the launch (a.index / a.first, a.count; not for device-side counts)
 void launch_tail(const ClassifyArgs& a, hipStream_t stream);

@@ -1,5 +1,7 @@
 #!/bin/bash
 # instruction counts of the classify kernel after each phase (debug switch LMAT_STOP_AFTER)
+# Stops 1, 3, 5, 6, 30..34 and 40..47 exist in ablation builds only (the production kernel carries no checks for them):
+#   scripts/build_variant.sh ablate lmat_amd/csrc/kernels.hip -DLMAT_ABLATE=1 && LMAT_LIB=$PWD/lmat_amd/variants/ablate.so <this script>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for s in ${STOPS:-1 2 3 4 5 6 0}; do

@@ -142,3 +142,14 @@ def test_k4_wave_equals_the_general_decision_path_on_a_million_tables(tmp_path):
     assert (kinds[:2] > 1000).all(), kinds     # direct and multi matches both occur among the compared tables (a partial match needs max_val below
                                                # the root's own score, which the max over the entries up to AND including the root never is, :386-404)
     eng.close()
+
+
+def test_small_integer_division_is_the_ieee_division_on_its_whole_domain():
+    """k4_wave scores a taxid count / candidate k-mers (read_label.cpp:821) with a reciprocal, a product and two fused corrections
+    instead of the 11-instruction IEEE sequence; both operands are integers below 1024 there.  Every pair of that domain on the
+    device: the same bits as the IEEE quotient."""
+    from lmat_amd import Engine, Params
+    eng = Engine(0, Params.run_rl())
+    bad, tried = eng.div_check()
+    assert tried == 1024 * 1023 and bad == 0
+    eng.close()
