@@ -568,7 +568,7 @@ class Engine:
         """Reads the last launch passed from class to class (after sync()): fast -> E=512 -> middle tier -> large LDS -> global memory."""
         out = np.zeros(16, dtype=np.uint32)
         self._chk(self.lib.lmat_debug_last_counters(self.ctx, _ptr(out)))
-        return {"past_fast": int(out[2]), "past_e512": int(out[3]), "past_middle": int(out[10]), "past_large": int(out[7]), "debug_words_11_15": [int(x) for x in out[11:16]]}
+        return {"past_fast": int(out[2]), "past_e512": int(out[3]), "past_middle": int(out[10]), "past_large": int(out[7])}
 
     def div_check(self):
         """-> (pairs whose fast quotient differs from the IEEE one, pairs tried): the small-integer division of the decision step."""

@@ -1405,11 +1405,16 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
                 if (chunk) {  // from this workgroup's sub-cursor; an exhausted one takes the next chunk off the bump cursor (kernels.hpp)
                     GAS unsigned long long* sub = (GAS unsigned long long*)(g_cursor + kCursorWords) + 8u * (__builtin_amdgcn_workgroup_id_x() & Ap->cand_sub_mask);
                     const unsigned long long v = __hip_atomic_fetch_add(sub, (unsigned long long)reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    coff = (uint32_t)v;
-                    if ((v & 0xFFFFFFFFull) + reserve > (v >> 32)) {
-                        // (two waves may get here at once: both take a chunk, the later store wins and the other chunk's rest stays unused)
-                        coff = G_ADD(&g_cursor[0], chunk);
-                        __hip_atomic_exchange(sub, (unsigned long long)(coff + reserve) | ((unsigned long long)(coff + chunk) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long nx = v & 0xFFFFFFFFull, en = v >> 32;
+                    coff = (uint32_t)nx;
+                    if (nx + reserve > en) {
+                        // Exactly one read crosses the end of a chunk (next <= end < next + its pairs): that one brings the next chunk and
+                        // installs it.  Those that come while it does (next already past the end) take their pairs straight off the bump
+                        // cursor -- no second chunk is drawn and dropped (which, eight waves to a sub-cursor, cost a near-full buffer its room).
+                        if (nx <= en) {
+                            coff = G_ADD(&g_cursor[0], chunk);
+                            __hip_atomic_exchange(sub, (unsigned long long)(coff + reserve) | ((unsigned long long)(coff + chunk) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else coff = G_ADD(&g_cursor[0], reserve);
                     }
                 } else coff = G_ADD(&g_cursor[0], reserve);
             }

@@ -56,7 +56,8 @@ static const int kK4RecWords = 2 + kK4T;
 // Candidate space (-p): 8 M reads bumping ONE cursor word is 8 M atomics on one address, which the L2 serves one after the
 // other (~8 ns each: the fast class took 88 ms instead of 24).  The fast classes therefore allocate through kCandSubs
 // sub-cursors -- (next free pair | end of the chunk << 32), one per 64-byte line, picked by the workgroup's number -- each of
-// which takes cand_chunk pairs from the bump cursor at a time.
+// which takes cand_chunk pairs from the bump cursor at a time: the read that crosses a chunk's end brings and installs the next one,
+// reads that arrive while it does allocate from the bump cursor directly (what is lost is the crossed chunk's last few pairs).
 static const int kCandSubs = 1024;
 static const int kCursorWords = 16;   // the counter block proper
 static const size_t kCursorBytes = kCursorWords * 4 + (size_t)kCandSubs * 64;
