@@ -165,8 +165,9 @@ int lmat_debug_last_counters(lmat_ctx* ctx, uint32_t* out16);
  * the second request (`overflow_probe_share`). */
 int lmat_debug_probe_stats(lmat_ctx* ctx, const uint64_t* kmers, uint64_t n, uint64_t* out5);
 /* Debug: the 4-instruction division the decision step on the wave uses for count / candidate-k-mers (integers below 1024,
- * read_label.cpp:821) against the IEEE division on every pair of its domain: out2 = {pairs that differ, pairs tried}. */
-int lmat_debug_div_check(lmat_ctx* ctx, uint64_t* out2);
+ * read_label.cpp:821) against the IEEE division on every pair of its domain, and -- the two averages of the statistics, :806-880 --
+ * on 2^26 drawn pairs (float >= 0, integer 1..64): out4 = {pairs that differ, pairs tried, drawn pairs that differ, drawn pairs tried}. */
+int lmat_debug_div_check(lmat_ctx* ctx, uint64_t* out4);
 
 /* Test hook for the synthetic database: what it must hold for the window of `species` (0-based) that starts at base `pos` of the
  * species ancestor -- the canonical k-mer and its taxid list (the strains that carry the window unmutated; with two or more

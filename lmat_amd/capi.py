@@ -571,10 +571,11 @@ class Engine:
         return {"past_fast": int(out[2]), "past_e512": int(out[3]), "past_middle": int(out[10]), "past_large": int(out[7])}
 
     def div_check(self):
-        """-> (pairs whose fast quotient differs from the IEEE one, pairs tried): the small-integer division of the decision step."""
-        out = np.zeros(2, dtype=np.uint64)
+        """-> (pairs whose fast quotient differs from the IEEE one, pairs tried, the same two for 2^26 drawn (float, 1..64) pairs): the
+        divisions of the decision step on the wave."""
+        out = np.zeros(4, dtype=np.uint64)
         self._chk(self.lib.lmat_debug_div_check(self.ctx, _ptr(out)))
-        return int(out[0]), int(out[1])
+        return tuple(int(x) for x in out)
 
     def probe_stats(self, kmers):
         """-> dict: where the lookups of these k-mers end (home bucket / absent at once / overflow hit / overflow miss, overflow buckets read)."""

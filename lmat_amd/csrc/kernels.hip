@@ -1078,6 +1078,10 @@ __device__ __forceinline__ uint64_t below_mask_1_64(int p) { return ~0ull >> (64
 // them -- and one correction.  What is rounded at the end lies within 2^-45 (relative) of a / b, and a quotient of two such
 // integers is never nearer than 2^-35 to a rounding boundary: the IEEE result, in 4 instructions instead of the 11 of the
 // general sequence (v_div_scale .. v_div_fixup).  Checked over the whole domain by lmat_debug_div_check (tests/test_gpu_decide.py).
+// The same holds for ANY normal float a >= 0 over an integer 1 <= b <= 64 (the two averages of the statistics, :806-880): the residual
+// is a multiple of the quotient's ulp below 2^9 of them, and a 24-bit significand over such a b is never nearer than 2^-31 to a
+// rounding boundary (a midpoint would need a 25-bit quotient times an odd factor of b to fit 24 bits).  That domain cannot be walked
+// through; the check draws 2^26 pairs of it.
 __device__ __forceinline__ float div_small_ints(float a, float b) {
     const float r = __builtin_amdgcn_rcpf(b);
     const float q0 = a * r;
@@ -1086,11 +1090,25 @@ __device__ __forceinline__ float div_small_ints(float a, float b) {
 }
 __global__ void div_check_kernel(unsigned long long* out) {   // every pair of the domain against the IEEE division
     const uint32_t a = blockIdx.x, b = threadIdx.x + 1u + 256u * blockIdx.y;
-    if (b >= 1024u) return;
-    const float fa = (float)a, fb = (float)b;
-    float ieee = fa / fb;
-    if (__float_as_uint(div_small_ints(fa, fb)) != __float_as_uint(ieee)) atomicAdd(out, 1ull);
-    atomicAdd(out + 1, 1ull);
+    if (b < 1024u) {
+        const float fa = (float)a, fb = (float)b;
+        float ieee = fa / fb;
+        if (__float_as_uint(div_small_ints(fa, fb)) != __float_as_uint(ieee)) atomicAdd(out, 1ull);
+        atomicAdd(out + 1, 1ull);
+    }
+    // sums of scores and of squared deviations over 1 .. 64: 64 drawn floats in [2^-60, 2^7) per thread (zero among them)
+    const uint32_t tid = (blockIdx.y * 1024u + blockIdx.x) * 256u + threadIdx.x;
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < 64u; ++i) {
+        const uint32_t h = hash32(((uint64_t)tid << 8) | i), h2 = hash32(((uint64_t)h << 32) | tid);
+        const uint32_t ex = 67u + (h2 >> 8) % 67u;                       // biased exponent 67 .. 133
+        const float x = i == 0 ? 0.0f : __uint_as_float((ex << 23) | (h & 0x7FFFFFu));
+        const float d = (float)(1u + (h2 & 63u));
+        float q = x / d;
+        bad += __float_as_uint(div_small_ints(x, d)) != __float_as_uint(q) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(out + 2, (unsigned long long)bad);
+    atomicAdd(out + 3, 64ull);
 }
 typedef const ClassifyArgs __attribute__((address_space(4))) CArgsK4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1206,7 +1224,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
     }
     const uint32_t pos_sig_hits = (uint32_t)popc64(bal(my_cnt > 0));
     const uint32_t use_sig_hits = pos_sig_hits > 3 ? pos_sig_hits : nT;
-    const float log_avg = log_sum / (float)use_sig_hits;
+    const float log_avg = div_small_ints(log_sum, (float)use_sig_hits);   // (a sum of up to 64 scores over 1 .. 64: see div_small_ints)
     const float dv = log_avg - sc;
     xv[lane] = act && (pos_sig_hits > 3 ? my_cnt > 0 : true) ? dv * dv : 0.0f;
     // sorted-position space: lane i holds the candidate at position i of the sorted array (ascending; best = nT - 1)
@@ -1226,7 +1244,7 @@ __device__ __forceinline__ bool k4_wave(CArgsK4* Ap, int lane, uint32_t nT, uint
         const f32x4 q = *(const f32x4*)(xv + t);
         log_std += q.x; log_std += q.y; log_std += q.z; log_std += q.w;
     }
-    const float stdev1 = use_sig_hits > 1 ? sqrtf(log_std / (float)(use_sig_hits - 1)) : 0.0f;
+    const float stdev1 = use_sig_hits > 1 ? sqrtf(div_small_ints(log_std, (float)(use_sig_hits - 1))) : 0.0f;
     if (stop == 31) { if (stdev1 == -1.0f || top_score == -1.0f || piv == 0xFFFFFFFFu || PLtop == 5) G_OR((GAS uint32_t*)Ap->err, 0u); return placeholder(); }
     lmat_read_result res;
     res.status = LMAT_ST_CALL; res.match_type = LMAT_MT_NOMATCH; res.cand_kmer_cnt = (uint16_t)cand; res.valid_kmers = valid_kmers;

@@ -852,14 +852,14 @@ int lmat_db_lookup(lmat_ctx* c, const uint64_t* kmers, uint64_t n, uint32_t* cou
 
 // Measurement hook: where the lookups of these k-mers end -- out[0] home bucket, out[1] absent without a second request,
 // out[2] found in the overflow table, out[3] absent after asking it too, out[4] overflow buckets read.  Compact layout only.
-int lmat_debug_div_check(lmat_ctx* c, uint64_t* out2) {
-    if (!c || !out2) return LMAT_E_ARG;
+int lmat_debug_div_check(lmat_ctx* c, uint64_t* out4) {
+    if (!c || !out4) return LMAT_E_ARG;
     hipSetDevice(c->device);
     unsigned long long* d_o = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_o, 16));
-    HIPCHK(c, hipMemsetAsync(d_o, 0, 16, c->stream));
+    HIPCHK(c, hipMalloc((void**)&d_o, 32));
+    HIPCHK(c, hipMemsetAsync(d_o, 0, 32, c->stream));
     launch_div_check(d_o, c->stream);
-    HIPCHK(c, hipMemcpyAsync(out2, d_o, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out4, d_o, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     hipFree(d_o);
     return LMAT_OK;

@@ -150,6 +150,7 @@ def test_small_integer_division_is_the_ieee_division_on_its_whole_domain():
     device: the same bits as the IEEE quotient."""
     from lmat_amd import Engine, Params
     eng = Engine(0, Params.run_rl())
-    bad, tried = eng.div_check()
+    bad, tried, bad_drawn, drawn = eng.div_check()
     assert tried == 1024 * 1023 and bad == 0
+    assert drawn == 1 << 26 and bad_drawn == 0   # the two averages of the statistics: any float >= 0 over 1 .. 64 (proved in kernels.hip; drawn here)
     eng.close()
