@@ -2885,11 +2885,13 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     const size_t eoff = LMAT_LIST_OFF(dpay[d], tb.list_shift) + kListHdr;
                     const uint32_t j = e - dstart[d];
                     if constexpr (WIDE) {
-                        el_t[e] = (tid_t)((uint32_t)arena[eoff + 2 * j] | ((uint32_t)arena[eoff + 2 * j + 1] << 16));
-                        el_ta[e] = (tid_t)((uint32_t)arena[eoff + 2 * (n + j)] | ((uint32_t)arena[eoff + 2 * (n + j) + 1] << 16));
+                        const uint32_t r0 = arena[eoff + 2 * j], r1 = arena[eoff + 2 * j + 1], a0 = arena[eoff + 2 * (n + j)], a1 = arena[eoff + 2 * (n + j) + 1];
+                        el_t[e] = (tid_t)(r0 | (r1 << 16));
+                        el_ta[e] = (tid_t)(a0 | (a1 << 16));
                     } else {
-                        el_t[e] = arena[eoff + j];
-                        el_ta[e] = arena[eoff + n + j];
+                        const uint16_t t_reg = arena[eoff + j], t_asc = arena[eoff + n + j];  // (both loads in flight before either is stored)
+                        el_t[e] = t_reg;
+                        el_ta[e] = t_asc;
                     }
                 }
             }
