@@ -2806,6 +2806,30 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     // lane ran to the longest list's length.
     static_assert((E * sizeof(eld_t)) % 256 == 0, "the owner array is cleared a dword per lane and step");
     for (uint32_t i = lane; i < (uint32_t)(E * sizeof(eld_t) / 4); i += 64) ((uint32_t*)el_d)[i] = 0u;
+    // The fast classes copy the first 64 bytes of every list record straight into LDS (global_load_lds, four lanes a record, 16
+    // records a wave-instruction, as the probe stages its buckets): header and both id orders of a list of up to 14 ids in ONE
+    // round trip -- the ids of the longer lists were a second one, asked for only once the header had said how long the list is.
+    // The window is the 2560 bytes of the taxid tables (R1: idle until the registration below): the first 40 lists of a read;
+    // what lies beyond -- lists 41.. of a read, ids 15.. of a list -- takes the loads from memory as before.
+    constexpr bool LSTAGE = CPT && !INK4 && !WIDE && U <= 512;
+    constexpr uint32_t kStageLists = 40;
+    static_assert(!LSTAGE || (L::OFF_XL == L::OFF_R1 && L::OFF_R2 - L::OFF_R1 >= (int)kStageLists * 64), "the window lies under the taxid tables");
+    if constexpr (LSTAGE) {
+        const uint32_t nst = ndist < kStageLists ? ndist : kStageLists;
+#pragma unroll
+        for (int sgrp = 0; sgrp < 3; ++sgrp) {
+            if ((uint32_t)sgrp * 16 < nst) {
+                const uint32_t g = (uint32_t)sgrp * 16 + ((uint32_t)lane >> 2);
+                if (g < nst) {
+                    const uint32_t pay = dpay[g];
+                    if (pay >= kListBase)
+                        __builtin_amdgcn_global_load_lds((const GAS void*)((const GAS unsigned char*)(arena + LMAT_LIST_OFF(pay, tb.list_shift)) + 16 * (lane & 3)),
+                                                         (LAS void*)(xl + sgrp * 1024), 16, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
     WSYNC();
     for (uint32_t d0 = 0; d0 < ndist; d0 += 64) {
         const uint32_t d = d0 + lane;
@@ -2817,7 +2841,9 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
             n = 1;
             w3 = w4 = pay;
             if (pay >= kListBase) {
-                const u32x4 ch = *(const GAS u32x4*)(arena + LMAT_LIST_OFF(pay, tb.list_shift));  // [flags][n_kept][n_raw][ids...]
+                u32x4 ch;  // [flags][n_kept][n_raw][ids...]
+                if (LSTAGE && d < kStageLists) ch = *(const LAS u32x4*)(xl + d * 64);
+                else ch = *(const GAS u32x4*)(arena + LMAT_LIST_OFF(pay, tb.list_shift));
                 fl = ch.x & 0xFFFFu;
                 n = ch.x >> 16;
                 if constexpr (WIDE) {  // ids are (low, high) pairs: the first kept id and the first ascending one fit the 16 bytes
@@ -2860,8 +2886,6 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         }
         return;
     }
-    for (int i = lane; i < L::TH; i += 64) { hent[i] = 0; best[i] = 0; }
-    WSYNC();
     {
         uint32_t carry = 0;
         for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
@@ -2889,7 +2913,11 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                         el_t[e] = (tid_t)(r0 | (r1 << 16));
                         el_ta[e] = (tid_t)(a0 | (a1 << 16));
                     } else {
-                        const uint16_t t_reg = arena[eoff + j], t_asc = arena[eoff + n + j];  // (both loads in flight before either is stored)
+                        uint16_t t_reg, t_asc;
+                        if (LSTAGE && d < kStageLists && n <= 14u) {  // both orders lie in the staged 64 bytes
+                            const LAS uint16_t* rec = (const LAS uint16_t*)(xl + d * 64);
+                            t_reg = rec[kListHdr + j]; t_asc = rec[kListHdr + n + j];
+                        } else { t_reg = arena[eoff + j]; t_asc = arena[eoff + n + j]; }  // (both loads in flight before either is stored)
                         el_t[e] = t_reg;
                         el_ta[e] = t_asc;
                     }
@@ -2898,6 +2926,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         }
         WSYNC();
     }
+    for (int i = lane; i < L::TH; i += 64) { hent[i] = 0; best[i] = 0; }  // (behind the list window, which lies under these tables)
+    WSYNC();
     if constexpr (INK4) {
         for (uint32_t e0 = 0; e0 < nel; e0 += 64) {
             const uint32_t e = e0 + lane;
