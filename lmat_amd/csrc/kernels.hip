@@ -3112,6 +3112,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                                     (STR & __ballot(bh != 0u) & __ballot((bh & 0xFFFFu) == (0xFFFFu - my_id))));
         WSYNC();  // leaf and best are dead from here
         unsigned int* first = best;  // per slot: its first eligible element
+        u32x2* anc_zw = (u32x2*)(best + T);  // per slot the closure registers: words 2 and 3 of its fact record (best has 4 T entries; the species votes are through)
+        static_assert(L::TH >= 3 * T && ((L::IDB + 6) * T + L::HB * L::TH + 4 * T) % 8 == 0, "room and alignment behind the first-element array");
         if (sl_p1) { s_tin[lane] = (uint16_t)(f_iv & 0xFFFFu); s_tout[lane] = (uint16_t)(f_iv >> 16); }
         first[lane] = 0xFFFFFFFFu;
         WSYNC();
@@ -3183,8 +3185,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 rel = i - (uint32_t)el_off[e];
             }
             const uint32_t poff_i = lane_of(f_poff, sl_i);  // the chain's start, from the slot's lane
+            uint32_t pf = 0;
             if (act) {
                 pe = g_paths8[poff_i + rel];  // id | depth | tin | tout of that ancestor
+                pf = ((const GAS uint8_t*)tb.paths_fl)[poff_i + rel];  // ... and its flags
                 a = (uint32_t)(pe & 0xFFFFu);
                 h = tid_find_or_claim(hent, THM, a);
                 atomicMin(&hent[h], a | ((0x8000u | (uint32_t)lane) << 16));
@@ -3199,14 +3203,16 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 reg[s] = (uint16_t)a;
                 s_tin[s] = (uint16_t)(pe >> 32);
                 s_tout[s] = (uint16_t)(pe >> 48);
+                anc_zw[s] = u32x2{(uint32_t)(pe >> 32), ((uint32_t)(pe >> 16) & 0xFFFFu) | (pf << 16)};  // interval, depth | flags << 16: words 2 and 3 of the id's fact record
             }
             nT += newcnt;
             WSYNC();
         }
         STOP_AT(45, nT);
-        // the fact records of the ids the closure registered, into their slots' lanes (the decision step at the end wants
-        // every slot's; the load is in flight while the counts are made)
-        if (!overflow && (uint32_t)lane >= nT_p1 && (uint32_t)lane < nT) fz = g_facts16[reg[lane]];
+        // What the decision step wants of the ids the closure registered -- interval, depth, flags -- came with their path entries:
+        // into their slots' lanes from LDS (a gather of their fact records here was one more round trip to memory, and the
+        // usual read had nothing to do while it was out).
+        if (!overflow && (uint32_t)lane >= nT_p1 && (uint32_t)lane < nT) { const u32x2 zw = anc_zw[lane]; fz = u32x4{0u, 0u, zw.x, zw.y}; }
         // One eligible id in the whole read whose ancestors were ALL registered just now (nobody's kept list holds one of them)
         // and no position set with a negative first: every one of those ancestors is reached by exactly the sets that hold the
         // id -- its count is the id's own -- and steps (3a) .. (3c) have nothing else to find.  The usual read: strains of one

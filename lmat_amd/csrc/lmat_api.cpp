@@ -54,10 +54,13 @@ int upload_taxonomy(lmat_ctx* c) {
         if ((rc = dev_upload(c, &c->dev.tin, narrow(T.tin)))) return rc;
         if ((rc = dev_upload(c, &c->dev.tout, narrow(T.tout)))) return rc;
         std::vector<uint64_t> p8(T.paths.size());
+        std::vector<uint8_t> pfl(T.paths.size());
         for (size_t i = 0; i < T.paths.size(); ++i) {
             const uint32_t a = T.paths[i];
             p8[i] = (uint64_t)a | ((uint64_t)T.fdepth[a] << 16) | ((uint64_t)T.tin[a] << 32) | ((uint64_t)T.tout[a] << 48);
+            pfl[i] = (uint8_t)T.flags[a];
         }
+        if ((rc = dev_upload(c, &c->dev.paths_fl, pfl))) return rc;
         std::vector<uint32_t> f16((size_t)(T.n + 1) * 4);
         for (uint32_t i = 0; i <= T.n; ++i) {
             f16[4 * i + 0] = T.path_off[i];
@@ -138,7 +141,7 @@ void lmat_ctx_destroy(lmat_ctx* c) {
     for (auto& e : c->pending_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& e : c->pending_events2) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     void* ptrs[] = {c->dev.slots, c->dev.ovf_slots, c->dev.arena, c->dev.tid32, c->dev.fdepth, c->dev.flags, c->dev.species_of,
-                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->dev.paths32, c->dev.tin32, c->dev.tout32, c->dev.species_of32, c->d_results, c->d_cands, c->d_cursor,
+                    c->dev.path_off, c->dev.path_len, c->dev.paths, c->dev.paths8, c->dev.paths_fl, c->dev.facts16, c->dev.conv, c->dev.tin, c->dev.tout, c->dev.paths32, c->dev.tin32, c->dev.tout32, c->dev.species_of32, c->d_results, c->d_cands, c->d_cursor,
                     c->d_counts, c->d_counts_bak, c->d_synth_strain_idx, c->d_ovf, c->d_ovf2, c->d_ovf3, c->d_ovf4, c->parked.d_ovf4, c->d_k4buf, c->d_k4small, c->d_k4large, c->d_k4bail, c->d_tail, c->parked.d_tail, c->d_gscratch, c->d_rand_max, c->d_rand_cnt, c->d_rand_gc,
                     c->d_err, c->parked.d_results, c->parked.d_cands, c->parked.d_cursor, c->parked.d_ovf, c->parked.d_ovf2, c->parked.d_ovf3, c->parked.d_k4buf, c->parked.d_k4small,
                     c->parked.d_k4large, c->parked.d_k4bail};

@@ -55,6 +55,7 @@ struct DeviceTables {
     uint16_t* tout = nullptr;
     // packed copies for the classify kernels: one load instead of several gathers per id
     uint64_t* paths8 = nullptr;   // parallel to paths: id | fdepth << 16 | tin << 32 | tout << 48
+    uint8_t* paths_fl = nullptr;  // parallel to paths: the ancestor's flags (with paths8: everything the decision step wants of an ancestor the closure registers)
     uint32_t* facts16 = nullptr;  // [n+1][4]: path_off | path_len, species_of << 16 | tin, tout << 16 | fdepth, flags << 16
     // wide taxonomies (HostTaxonomy::wide): 32-bit ids and ticks; the 16-bit arrays above stay null
     uint32_t wide = 0;
