@@ -2595,9 +2595,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         uint32_t dp_reg = 0, dm_reg = 0;
         // Payload and multiplicity go into lane ndist of their registers with v_writelane (a compare, two moves and two selects
         // otherwise).  The lane number rides in m0 -- one scalar operand per vector instruction on this target --, which is the
-        // compiler's own: saved here, put back behind the loops (nothing in between uses it: ballots, counts, scalar bookkeeping).
-        uint32_t m0_keep;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(m0_keep));
+        // compiler's own (the LDS address of the next global_load_lds may already be in it: the scheduler moves that move freely
+        // across an asm that does not name m0): saved and put back inside the one asm statement, never across compiler code.
 #pragma unroll
         for (int c0 = 0; c0 < KP; ++c0) {
             while (rm[c0]) {
@@ -2609,12 +2608,12 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                     cn += (uint32_t)popc64(m);
                     rm[c] &= ~m;
                 }
-                asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                             : "+v"(dp_reg), "+v"(dm_reg) : "s"(v), "s"(ndist), "s"(cn));
+                uint32_t m0_keep;
+                asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+                             : "+v"(dp_reg), "+v"(dm_reg), "=&s"(m0_keep) : "s"(v), "s"(ndist), "s"(cn));
                 ++ndist;   // (beyond 64 the lane number wraps and earlier entries are overwritten: such a read is handed to a larger class below)
             }
         }
-        asm volatile("s_mov_b32 m0, %0" : : "s"(m0_keep));
         many = ndist > 64u;
         if (!many) {
             if ((uint32_t)lane < ndist) { dpay[lane] = dp_reg; dmult[lane] = (uint16_t)dm_reg; }  // overlay the (dead) k-mer arrays

@@ -434,7 +434,7 @@ int load_device_image(lmat_ctx* c, const char* fn) {
     c->db_ready = false;
     HIPCHK(c, hipMalloc((void**)&D.slots, std::max<uint64_t>(h.bytes_slots, 64)));
     if (h.bytes_ovf) HIPCHK(c, hipMalloc((void**)&D.ovf_slots, h.bytes_ovf));
-    HIPCHK(c, hipMalloc((void**)&D.arena, h.bytes_arena + 64));   // (a record's first 16 bytes are one load: slack behind the last)
+    HIPCHK(c, hipMalloc((void**)&D.arena, h.bytes_arena + 64));   // (a record's first 64 bytes are read whatever its length: slack behind the last)
     HIPCHK(c, hipMemset((char*)D.arena + h.bytes_arena, 0, 64));
     std::string err;
     if (!img_stream(c, fd, h.off_slots, (char*)D.slots, h.bytes_slots, false, err) ||
@@ -709,7 +709,7 @@ static int sb_finish(lmat_ctx* c) {
     StreamBuild& S = *c->sb;
     int rc;
     const size_t arena_words = S.arena.size();
-    S.arena.resize(arena_words + 8, 0);  // the kernels read a record's first 16 bytes in one load
+    S.arena.resize(arena_words + 32, 0);  // the fast classes copy a record's first 64 bytes into LDS whatever its length (kernels.hip, K3b stage 1): 64 bytes of slack behind the last record, as every other producer of an arena leaves
     if ((rc = dev_upload(c, &c->dev.arena, S.arena))) return rc;
     c->dev.list_shift = S.shift;
     c->arena_words = arena_words;
@@ -809,7 +809,7 @@ int lmat_db_clone(lmat_ctx* d, lmat_ctx* s) {
     if (D.ovf_slots) { hipFree(D.ovf_slots); D.ovf_slots = nullptr; }
     if (D.arena) { hipFree(D.arena); D.arena = nullptr; }
     const uint64_t nb = S.cpt.nb ? S.cpt.nb : (uint64_t)S.nbuckets;
-    const uint64_t arena_bytes = s->arena_words * 2 + 64;  // (every builder leaves at least 16 bytes of slack behind the records)
+    const uint64_t arena_bytes = s->arena_words * 2 + 64;  // (every builder leaves 64 bytes of slack behind the records: a record's first 64 bytes are read whatever its length)
     HIPCHK(d, hipMalloc((void**)&D.slots, nb * 64));
     HIPCHK(d, hipMemcpyPeerAsync(D.slots, d->device, S.slots, s->device, nb * 64, d->stream));
     if (S.ovf_slots) {
@@ -1093,7 +1093,7 @@ int lmat_synth_db_build3(lmat_ctx* c, int k, uint64_t G, uint64_t seed, uint64_t
             }
     c->dev.list_shift = shift;
     int rc;
-    {   // the device arena: list_replicas copies back to back (+ 16 bytes of slack: a record's first 16 bytes are one load)
+    {   // the device arena: list_replicas copies back to back (+ 64 bytes of slack: a record's first 64 bytes are read whatever its length)
         if (c->dev.arena) { hipFree(c->dev.arena); c->dev.arena = nullptr; }
         const size_t bytes = arena.size() * 2;
         HIPCHK(c, hipMalloc((void**)&c->dev.arena, bytes * list_replicas + 64));
