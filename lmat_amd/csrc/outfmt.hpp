@@ -92,19 +92,47 @@ inline int fmt_float(char* b, float f) {  // b: at least 48 bytes
 }
 // Scores are k-mer fractions: a few thousand distinct floats make up almost every score of a run, so each thread keeps
 // the text of the floats it has formatted in a small direct-mapped table keyed by the float's bits.
+// The record writers below work on a raw buffer (W): a record with its ~15 candidates is ~70 pieces of text, and a
+// std::string append per piece -- size check, possible growth -- was most of the formatter's time.
+struct W {
+    char* p;
+    inline void ch(char c) { *p++ = c; }
+    inline void lit(const char* t, size_t n) { __builtin_memcpy(p, t, n); p += n; }
+    template <size_t N> inline void lit(const char (&t)[N]) { __builtin_memcpy(p, t, N - 1); p += N - 1; }
+    inline void u32(uint32_t v) {  // decimal, two digits a step
+        static const char kPairs[201] =
+            "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+        char b[10];
+        int i = 10;
+        while (v >= 100) { const uint32_t q = v / 100, r = v - q * 100; b[--i] = kPairs[2 * r + 1]; b[--i] = kPairs[2 * r]; v = q; }
+        if (v >= 10) { b[--i] = kPairs[2 * v + 1]; b[--i] = kPairs[2 * v]; } else b[--i] = (char)('0' + v);
+        __builtin_memcpy(p, b + i, (size_t)(10 - i));
+        p += 10 - i;
+    }
+    inline void i64(long long v) {
+        if (v >= 0 && v <= 0xFFFFFFFFll) { u32((uint32_t)v); return; }
+        const auto r = std::to_chars(p, p + 24, v);
+        p = r.ptr;
+    }
+    inline void flt(float f) {
+        struct Ent { uint32_t bits; uint8_t len; char txt[19]; };
+        static thread_local Ent cache[4096];
+        static thread_local bool init = false;
+        if (!init) { for (auto& e : cache) { e.bits = 0x7FC00001u; e.len = 0; } init = true; }  // a NaN payload no score has
+        uint32_t bits;
+        __builtin_memcpy(&bits, &f, 4);
+        Ent& e = cache[(bits * 0x9E3779B1u) >> 20];
+        if (e.bits == bits && e.len) { __builtin_memcpy(p, e.txt, sizeof e.txt); p += e.len; return; }  // (fixed-size copy: the buffer has the room)
+        const int n = fmt_float(p, f);
+        if (n <= (int)sizeof e.txt) { e.bits = bits; e.len = (uint8_t)n; __builtin_memcpy(e.txt, p, (size_t)n); }
+        p += n;
+    }
+};
 inline void put_float(std::string& s, float f) {
-    struct Ent { uint32_t bits; uint8_t len; char txt[19]; };
-    static thread_local Ent cache[4096];
-    static thread_local bool init = false;
-    if (!init) { for (auto& e : cache) { e.bits = 0x7FC00001u; e.len = 0; } init = true; }  // a NaN payload no score has
-    uint32_t bits;
-    __builtin_memcpy(&bits, &f, 4);
-    Ent& e = cache[(bits * 0x9E3779B1u) >> 20];
-    if (e.bits == bits && e.len) { s.append(e.txt, e.len); return; }
-    char b[48];
-    const int n = fmt_float(b, f);
-    if (n <= (int)sizeof e.txt) { e.bits = bits; e.len = (uint8_t)n; __builtin_memcpy(e.txt, b, (size_t)n); }
-    s.append(b, (size_t)n);
+    char b[64];
+    W w{b};
+    w.flt(f);
+    s.append(b, (size_t)(w.p - b));
 }
 inline void put_int(std::string& s, long long v) {
     char b[32];
@@ -123,44 +151,55 @@ inline const char* match_name(int m) {
 }
 
 // Appends the part of the record proc_line/construct_labels write (everything after "hdr\tread\t").
-inline void format_call(std::string& s, const lmat_params& p, int k, const lmat_read_result& r, const lmat_cand* cands) {
+// Room: 160 bytes + 30 per candidate (a taxid of up to 10 digits, a float of up to 16 characters, two blanks) + the float cache's fixed-size copy.
+inline size_t format_call_room(const lmat_read_result& r) { return 192 + 30 * (size_t)r.n_cand; }
+inline char* format_call_raw(char* out, const lmat_params& p, int k, const lmat_read_result& r, const lmat_cand* cands) {
+    W w{out};
     switch (r.status) {
         case LMAT_ST_SHORT_LEN:
-            s += "-1 -1 -1\t-1 -1\t"; put_int(s, r.read_len); s += ' '; put_int(s, k); s += " ReadTooShort\n";
-            return;
+            w.lit("-1 -1 -1\t-1 -1\t"); w.i64(r.read_len); w.ch(' '); w.i64(k); w.lit(" ReadTooShort\n");
+            return w.p;
         case LMAT_ST_SHORT_VALID:
-            s += "-1 -1 -1\t-1 -1\t"; put_int(s, r.valid_kmers); s += ' '; put_int(s, p.min_kmer); s += " ReadTooShort\n";
-            return;
+            w.lit("-1 -1 -1\t-1 -1\t"); w.i64(r.valid_kmers); w.ch(' '); w.i64(p.min_kmer); w.lit(" ReadTooShort\n");
+            return w.p;
         case LMAT_ST_NODBHITS:
-            s += "-1 -1 "; put_int(s, r.valid_kmers); s += "\t-1 -1\t"; put_int(s, r.read_len); s += ' '; put_int(s, k);
-            s += " NoDbHits\n";
-            return;
+            w.lit("-1 -1 "); w.i64(r.valid_kmers); w.lit("\t-1 -1\t"); w.i64(r.read_len); w.ch(' '); w.i64(k);
+            w.lit(" NoDbHits\n");
+            return w.p;
         case LMAT_ST_SILENT:
-            return;  // quirk Q1: nothing, not even a newline
+            return w.p;  // quirk Q1: nothing, not even a newline
         case LMAT_ST_PHIX:
-            s += "-1 -1 "; put_int(s, r.cand_kmer_cnt); s += '\t';
-            put_int(s, r.call_tid); s += ' '; put_float(s, r.call_score); s += '\t';
-            put_int(s, r.call_tid); s += ' '; put_float(s, r.call_score); s += " DirectMatch\n";
-            return;
+            w.lit("-1 -1 "); w.i64(r.cand_kmer_cnt); w.ch('\t');
+            w.i64(r.call_tid); w.ch(' '); w.flt(r.call_score); w.ch('\t');
+            w.i64(r.call_tid); w.ch(' '); w.flt(r.call_score); w.lit(" DirectMatch\n");
+            return w.p;
         default: break;
     }
-    put_float(s, r.log_avg); s += ' '; put_float(s, r.stdev); s += ' '; put_int(s, r.cand_kmer_cnt); s += '\t';
+    w.flt(r.log_avg); w.ch(' '); w.flt(r.stdev); w.ch(' '); w.i64(r.cand_kmer_cnt); w.ch('\t');
     const bool multi = r.match_type == LMAT_MT_MULTI || r.match_type == LMAT_MT_PARTIAL;
     if (p.prn_all || multi) {
-        for (uint32_t i = 0; i < r.n_cand; ++i) {
-            s += ' '; put_int(s, cands[r.cand_off + i].tid); s += ' '; put_float(s, cands[r.cand_off + i].score);
-        }
-        if (r.n_cand == 0) s += "-1 -1";
-        s += '\t';
+        const lmat_cand* c = cands + r.cand_off;
+        for (uint32_t i = 0; i < r.n_cand; ++i) { w.ch(' '); w.u32(c[i].tid); w.ch(' '); w.flt(c[i].score); }
+        if (r.n_cand == 0) w.lit("-1 -1");
+        w.ch('\t');
     }
     if (r.match_type == LMAT_MT_DIRECT || multi) {
-        put_int(s, r.call_tid); s += ' '; put_float(s, r.call_score); s += ' '; s += match_name(r.match_type);
+        w.i64(r.call_tid); w.ch(' '); w.flt(r.call_score); w.ch(' ');
+        const char* mn = match_name(r.match_type);
+        w.lit(mn, __builtin_strlen(mn));
     } else if (r.match_type == LMAT_MT_NOMATCH) {
-        s += "-1 -1 NoMatch";
+        w.lit("-1 -1 NoMatch");
     } else {
-        s += "-1 -1 Unmatched";
+        w.lit("-1 -1 Unmatched");
     }
-    s += '\n';
+    w.ch('\n');
+    return w.p;
+}
+inline void format_call(std::string& s, const lmat_params& p, int k, const lmat_read_result& r, const lmat_cand* cands) {
+    const size_t at = s.size(), room = format_call_room(r);
+    s.resize(at + room);
+    char* b = &s[at];
+    s.resize(at + (size_t)(format_call_raw(b, p, k, r, cands) - b));
 }
 
 }  // namespace lmat
