@@ -3089,12 +3089,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         //      keep a itself -- what the stamps compute -- with the elements broadcast from registers.
         constexpr int EC = E / 64;
         static_assert(E % 64 == 0 && T <= 64, "lane-parallel closure: one lane per registration slot");
-        uint16_t* s_tin = stamp;  // per-slot Euler interval; the stamps are not used on this path and the leaf
-        uint16_t* s_tout = leaf;  // counts are dead after the representative-strain pass
         // facts of the id registered in this lane's slot
         const bool sl_p1 = (uint32_t)lane < nT;
         const uint32_t nT_p1 = nT;
-        const uint32_t f_poff = fz.x, f_plen = fz.y & 0xFFFFu, f_sp = fz.y >> 16, f_fl = (fz.w >> 16) & 0xFFu, f_iv = fz.z;
+        const uint32_t f_poff = fz.x, f_plen = fz.y & 0xFFFFu, f_sp = fz.y >> 16, f_fl = (fz.w >> 16) & 0xFFu;
         const uint32_t my_id = sl_p1 ? (uint32_t)reg[lane] : 0u;
         // representative strain per species, one vote per kept id
         uint32_t hs = 0;  // where the species of this lane's strain sits in the hash (kept for the check below: one search, not two)
@@ -3113,7 +3111,6 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         unsigned int* first = best;  // per slot: its first eligible element
         u32x2* anc_zw = (u32x2*)(best + T);  // per slot the closure registers: words 2 and 3 of its fact record (best has 4 T entries; the species votes are through)
         static_assert(L::TH >= 3 * T && ((L::IDB + 6) * T + L::HB * L::TH + 4 * T) % 8 == 0, "room and alignment behind the first-element array");
-        if (sl_p1) { s_tin[lane] = (uint16_t)(f_iv & 0xFFFFu); s_tout[lane] = (uint16_t)(f_iv >> 16); }
         first[lane] = 0xFFFFFFFFu;
         WSYNC();
         // Per element: the slot of its id and whether it is eligible (closure only where first >= 0, :1179).  Only the
@@ -3200,8 +3197,6 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
                 const uint32_t s = nT + prefix_count(nm_);
                 hent[h] = a | (s << 16);
                 reg[s] = (uint16_t)a;
-                s_tin[s] = (uint16_t)(pe >> 32);
-                s_tout[s] = (uint16_t)(pe >> 48);
                 anc_zw[s] = u32x2{(uint32_t)(pe >> 32), ((uint32_t)(pe >> 16) & 0xFFFFu) | (pf << 16)};  // interval, depth | flags << 16: words 2 and 3 of the id's fact record
             }
             nT += newcnt;
@@ -3224,7 +3219,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         } else if (!overflow && W > 0) {
             const bool sl_act = (uint32_t)lane < nT;
             uint32_t tin_s = 0xFFFF, tout_s = 0;
-            if (sl_act) { tin_s = s_tin[lane]; tout_s = s_tout[lane]; }
+            if (sl_act) { tin_s = fz.z & 0xFFFFu; tout_s = fz.z >> 16; }  // (word 2 of the slot's fact record: its own for a kept id, off the path entry for a new ancestor)
             // (3a) for every kept id that is eligible somewhere: the set of slots that are proper ancestors of it, as a
             //      64-bit mask held by the id's own lane
             uint32_t anc_lo = 0, anc_hi = 0;
