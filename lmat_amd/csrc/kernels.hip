@@ -2973,7 +2973,8 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         if (lane_bit(nm_)) {
             const uint32_t s = nT + prefix_count(nm_);
             hent[h] = (ent_t)t | ((ent_t)s << ESH);
-            reg[s] = (tid_t)t; stamp[s] = 0xFFFF;
+            reg[s] = (tid_t)t;
+            if constexpr (INK4) stamp[s] = 0xFFFF;  // (the lane-parallel closure of the fast classes keeps no stamps)
         }
         nT += newcnt;
         WSYNC();
