@@ -3085,9 +3085,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         // per eligible id) becomes three wave-wide steps:
         //  (1) every ancestor of every eligible id as one flat item list in the walk's order (element, then path
         //      position), so new ids are registered in the same order with the lowest-lane rule of phase 1;
-        //  (2) the Euler interval of every registered slot, one gather;
+        //  (2) the Euler interval of every registered slot in its lane: word 2 of the fact record (a kept id's own; a new
+        //      ancestor's comes with its path entry);
         //  (3) per slot a: count[a] += m_d for each position set d that has an eligible id below a and does not
-        //      keep a itself -- what the stamps compute -- with the elements broadcast from registers.
+        //      keep a itself -- what the stamps compute -- from per-set masks in LDS (steps 3a .. 3c below).
         constexpr int EC = E / 64;
         static_assert(E % 64 == 0 && T <= 64, "lane-parallel closure: one lane per registration slot");
         // facts of the id registered in this lane's slot
