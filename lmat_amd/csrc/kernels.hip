@@ -2957,6 +2957,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     STOP_AT(41, nel);
     for (uint32_t i = lane; i < (uint32_t)T; i += 64) ((unsigned int*)cnt)[i] = 0;  // covers cnt[T] and leaf[T]
     uint32_t nT = 0;
+    u32x4 fz = u32x4{0u, 0u, 0u, 0u};
     for (uint32_t e0 = 0; e0 < nel && !overflow; e0 += 64) {
         const uint32_t e = e0 + lane;
         const bool act = e < nel;
@@ -2978,6 +2979,9 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         }
         nT += newcnt;
         WSYNC();
+        // T <= 64: the fact record of every kept id into the lane of its registration slot -- asked for chunk by chunk, as the slots are
+        // taken, so that the records of the first chunks (most of a read's ids) are on their way while the later ones register
+        if constexpr (!INK4) { if ((uint32_t)lane >= nT - newcnt && (uint32_t)lane < nT) fz = g_facts16[reg[lane]]; }
         if (act) {
             const uint32_t s = (uint32_t)(hent[h] >> ESH);
             const uint32_t m = dmult[el_d[e]];
@@ -2993,10 +2997,6 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
         }
         return;
     }
-    // T <= 64: the fact record of every kept id, one per lane = registration slot (every kept id is registered by now);
-    // the load is in flight while the counts are made
-    u32x4 fz = u32x4{0u, 0u, 0u, 0u};
-    if constexpr (!INK4) { if ((uint32_t)lane < nT) fz = g_facts16[reg[lane]]; }
     WSYNC();
     STOP_AT(5, nT);
     RELANE();
