@@ -1850,7 +1850,7 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     constexpr uint32_t EPEND = WIDE ? 0x80000000u : 0x8000u;  // slot field while a chunk decides
     // RELANE: values derived from the lane id (LDS addresses, masks) are cheap; re-deriving them per phase keeps the
     // register allocator from carrying (and spilling) them across the probe phase, where 34 VGPRs hold loads in flight
-#define RELANE() do { asm volatile("" : "+v"(lane)); asm volatile("" : "+s"(Ap)); } while (0)
+#define RELANE() do { asm volatile("" : "+v"(lane)); } while (0)
 #pragma push_macro("A")
 #pragma push_macro("tb")
 #define A (*Ap)
