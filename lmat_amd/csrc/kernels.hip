@@ -1849,7 +1849,10 @@ __device__ __forceinline__ void classify_one(CArgs* Ap, uint64_t r, unsigned cha
     constexpr ent_t EIDM = WIDE ? (ent_t)0xFFFFFFFFull : (ent_t)0xFFFFu;   // id part of an entry; also "slot = none"
     constexpr uint32_t EPEND = WIDE ? 0x80000000u : 0x8000u;  // slot field while a chunk decides
     // RELANE: values derived from the lane id (LDS addresses, masks) are cheap; re-deriving them per phase keeps the
-    // register allocator from carrying (and spilling) them across the probe phase, where 34 VGPRs hold loads in flight
+    // register allocator from carrying (and spilling) them across the probe phase, where 34 VGPRs hold loads in flight.
+    // (Without it the fast classes spill vector registers to scratch: 27.6 instead of 20.4 ms per 8 M reads.  A second barrier, on
+    // the argument pointer, stood here until the end of round 4: it made every phase boundary reload the pointer from the vector
+    // lanes it is spilled to -- 37 vector instructions a read, 1.3 % of the kernel's time.)
 #define RELANE() do { asm volatile("" : "+v"(lane)); } while (0)
 #pragma push_macro("A")
 #pragma push_macro("tb")
